@@ -1,0 +1,72 @@
+"""CPU oracle for the host-side pieces around the training step -- TEST
+INFRASTRUCTURE, NOT PRODUCT CODE.  (training_loop.py, dataset.py and util.py are
+not importable here -- lightning/h5py/torchvision are absent -- so these follow
+the source text; the known-answer values in tests/golden/kat_host.json were
+computed by running the quoted expressions, see make_golden.py.)
+"""
+from __future__ import annotations
+
+from typing import Iterator, List
+
+import numpy as np
+import torch
+
+
+def seed_from_args(*args) -> int:
+    """util.py:27-29: ``hash(args) % (1 << 31)`` (CPython int-tuple hash is unsalted)."""
+    return hash(args) % (1 << 31)
+
+
+def linear_lr(cur_ndata: int, total_ndata: int, ref_lr: float) -> float:
+    """src/thor/lr.py:17-19."""
+    return ref_lr * (1 - cur_ndata / total_ndata)
+
+
+def infinite_order(dataset_size: int, rank: int, num_replicas: int, seed: int, start_idx: int, count: int,
+                   shuffle: bool = True) -> List[int]:
+    """dataset.py:23-40: rank-strided walk over per-epoch permutations; first ``count`` indices."""
+    out: List[int] = []
+    idx = start_idx + rank
+    epoch = None
+    order = None
+    while len(out) < count:
+        if epoch != idx // dataset_size:
+            epoch = idx // dataset_size
+            order = np.arange(dataset_size)
+            if shuffle:
+                np.random.RandomState(hash((seed, epoch)) % (1 << 31)).shuffle(order)
+        out.append(int(order[idx % dataset_size]))
+        idx += num_replicas
+    return out
+
+
+def window_item(data: torch.Tensor, i: int, window: int) -> torch.Tensor:
+    """dataset.py:114-126: item i = frames i..i+w-1 of x[N,C,H,W] flattened to (w*C,H,W), channel = tau*C+c."""
+    return data[i : i + window].reshape(-1, *data.shape[2:])
+
+
+def ema_update(p_ema: torch.Tensor, p_net: torch.Tensor, rate: float) -> torch.Tensor:
+    """src/thor/ema.py:23-27: p_ema <- rate * p_ema + (1 - rate) * p_net."""
+    return p_ema.mul(rate).add(p_net, alpha=1 - rate)
+
+
+def adamw_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-3):
+    """torch.optim.AdamW single-tensor rule as configured at train.py:176-181 (decoupled decay first)."""
+    p = p * (1 - lr * weight_decay)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1 = 1 - beta1**step
+    bc2 = 1 - beta2**step
+    denom = (v.sqrt() / (bc2**0.5)) + eps
+    p = p - (lr / bc1) * m / denom
+    return p, m, v
+
+
+def batch_split(batch_size: int, world_size: int, batch_gpu=None):
+    """training_loop.py:57-62: per-rank batch and accumulation rounds."""
+    total = batch_size // world_size
+    if batch_gpu is None or batch_gpu > total:
+        batch_gpu = total
+    rounds = total // batch_gpu
+    assert batch_size == batch_gpu * rounds * world_size
+    return batch_gpu, rounds
