@@ -1,0 +1,86 @@
+"""ctypes binding of libc2w_hip.so (the C ABI declared in include/c2w_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libc2w_hip.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SILU = 0, 1
+MUL_PLAIN, MUL_DSILU = 0, 1
+
+
+class C2wError(RuntimeError):
+    pass
+
+
+class ConvArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("mul", c_void_p), ("y", c_void_p),
+        ("B", c_int32), ("Hin", c_int32), ("Win", c_int32), ("Cin", c_int32),
+        ("Hout", c_int32), ("Wout", c_int32), ("Cout", c_int32), ("ldy", c_int32),
+        ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),
+    ]
+
+
+# name -> argtypes (every function returns int status except c2w_target)
+_PROTOS = {
+    "c2w_conv_forward": [POINTER(ConvArgs), c_int, c_int, c_void_p],
+    "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_int, c_void_p],
+    "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
+    "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,
+                        c_int, c_void_p],
+    "c2w_colsum": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
+    "c2w_silu": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "c2w_silu_backward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "c2w_sumpool2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_nchw_to_nhwc": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_mse_loss_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "c2w_timestep_embedding": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],
+    "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "c2w_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_adamw_ema": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
+                      c_float, c_int, c_float, c_float, c_void_p],
+    "c2w_attention_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_attention_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/c2w_hip.h declares (used by the CPU test that the library exports all of them)."""
+    return list(_PROTOS) + ["c2w_target"]
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise C2wError(f"{LIB_PATH} is missing: run `python -m climate2weather_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.c2w_target.restype = c_char_p
+    lib.c2w_target.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        kind = {-1: "bad argument", -2: "bad shape", -3: "unsupported"}.get(status, f"hipError_t {status}")
+        raise C2wError(f"{what} failed: {kind}")

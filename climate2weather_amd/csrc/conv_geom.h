@@ -1,0 +1,34 @@
+// Geometry shared by the forward/dgrad implicit GEMM (conv_igemm.hip) and the weight-gradient GEMM (wgrad.hip).
+#pragma once
+#include "common.h"
+#include "c2w_hip.h"
+
+// source pixel of output pixel (oh,ow) under tap (kh,kw); returns false when it is padding
+template <int MODE, typename A>
+__device__ __forceinline__ bool src_pixel(const A& p, int oh, int ow, int kh, int kw, int& ih, int& iw) {
+    if constexpr (MODE == C2W_CONV_1X1) {
+        ih = oh; iw = ow;
+        return true;
+    } else if constexpr (MODE == C2W_CONV_S1) {
+        ih = oh + kh - 1; iw = ow + kw - 1;
+        return (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+    } else if constexpr (MODE == C2W_CONV_S2) {
+        ih = 2 * oh + kh - 1; iw = 2 * ow + kw - 1;
+        return (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+    } else if constexpr (MODE == C2W_CONV_UP) {  // conv3x3(nearest_up2(x)): zero padding lives in the upsampled frame
+        int uh = oh + kh - 1, uw = ow + kw - 1;
+        ih = uh >> 1; iw = uw >> 1;
+        return (unsigned)uh < (unsigned)p.Hout && (unsigned)uw < (unsigned)p.Wout;
+    } else {  // C2W_CONV_TS2: input-gradient of the stride-2 conv; x := dy, y := dx, ih = (oh + 1 - kh)/2
+        int th = oh + 1 - kh, tw = ow + 1 - kw;
+        ih = th >> 1; iw = tw >> 1;
+        return ((th | tw) & 1) == 0 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+    }
+}
+
+
+// exact n / d for n < 2^31 with a host-precomputed (magic, shift): q = umulhi(n, magic) >> shift; magic == 0 means d == 1
+struct FastDiv {
+    uint32_t magic, shift;
+};
+__device__ __forceinline__ int fast_div(int n, FastDiv d) { return d.magic ? (int)(__umulhi((uint32_t)n, d.magic) >> d.shift) : n; }

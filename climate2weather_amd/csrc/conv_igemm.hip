@@ -1,0 +1,303 @@
+// Implicit-GEMM convolution on MFMA for gfx950 -- the forward/dgrad work-horse.
+//
+// Replaces every torch Conv2d / Conv1d(k=1) / Linear on the reference hot path
+// (model/nn.py:45,47,149,155,157,169-174,185-194; model/score.py:56-57) and, with
+// re-arranged weights, their input gradients.
+//
+// GEMM view (per tap t and K-chunk c):   D[co][pixel] += W[co][t][c*CK..] . X[src(pixel,t)][c*CK..]
+//   * MFMA "A" operand = weights  (rows = output channel)
+//   * MFMA "B" operand = pixels   (cols = output pixel)  -> each lane ends up with 4 consecutive
+//     output channels of one pixel = one contiguous NHWC store.
+// Block tile: 256 output pixels x 128 output channels, 8 waves (2 over channels x 4 over pixels),
+// each wave a 64x64 sub-tile = 4x4 MFMA 16x16 accumulators.
+// K loop: stage = (K-chunk of 128 bytes per pixel row, tap).  Both operand tiles are staged with
+// direct-to-LDS buffer loads (16 B/lane) into a 2-deep ring; out-of-image taps and out-of-range
+// rows are fetched through a buffer descriptor with an out-of-range offset, which returns zeros --
+// zero padding costs no instructions.  LDS rows are 128 B and XOR-swizzled on the SOURCE address
+// (chunk ^= row&7), so ds_read_b128 fragment reads are bank-conflict free.
+// The element type only changes how a 16-byte fragment is fed to the matrix core:
+//   bf16 : 1 x v_mfma_f32_16x16x32_bf16     (8 k-values per lane)
+//   fp32 : 4 x v_mfma_f32_16x16x4_f32       (4 k-values per lane, exact fp32 fma chain)
+#include "conv_geom.h"
+
+namespace {
+
+constexpr int BM = 256;       // pixels per block tile
+constexpr int BN = 128;       // output channels per block tile
+constexpr int NTHREADS = 512;
+constexpr int PBYTES = BM * 128;  // one pixel-tile stage  (32 KiB)
+constexpr int WBYTES = BN * 128;  // one weight-tile stage (16 KiB)
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
+    constexpr int CK = 128 / ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * PBYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    // ---- block -> (pixel tile, channel tile); blocks b, b+8, ... share an XCD (own L2): give each XCD a
+    //      contiguous run of tiles so neighbouring pixel tiles (shared halo rows, same weights) hit its L2.
+    const int nN = (p.Cout + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * BN;
+    const int HWo = p.Hout * p.Wout;
+    const int npix = p.B * HWo;
+
+    // ---- buffer descriptors (wave-uniform).  x: rebased at the tile's first image so offsets stay < 2^31.
+    const int b0 = (tm * BM) / HWo;
+    const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
+    size_t xrem = (size_t)(p.B - b0) * img_bytes;
+    if (xrem > 0x7fffffffu) xrem = 0x7fffffffu;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b0 * img_bytes, (uint32_t)xrem);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * NT * p.Cin * ESZ));
+
+    // ---- per-thread staging slots: pixel tile = 256 rows x 8 slots(16 B) = 4 rounds; weight tile = 2 rounds
+    int pb[4], pyx[4];
+    uint32_t plc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (tid >> 3) + 64 * i;
+        const int Q = tm * BM + q;
+        const int b = Q / HWo;
+        const int rem = Q - b * HWo;
+        const int oh = rem / p.Wout;
+        const int ow = rem - oh * p.Wout;
+        pb[i] = (Q < npix) ? (b - b0) * p.Hin : -1;
+        pyx[i] = (oh << 16) | ow;
+        plc[i] = (uint32_t)(((tid & 7) ^ (q & 7)) << 4);
+    }
+    uint32_t wvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(NT * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * NT;
+
+    auto issue = [&](int s, int buf) {
+        const int chunk = s / NT;
+        const int tap = s - chunk * NT;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        char* const pdst = Pbuf + buf * PBYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih, iw;
+            const bool ok = src_pixel<MODE>(p, pyx[i] >> 16, pyx[i] & 0xffff, kh, kw, ih, iw) && pb[i] >= 0;
+            const uint32_t voff = ok ? (uint32_t)(((pb[i] + ih) * p.Win + iw) * p.Cin) * ESZ + plc[i] : C2W_OOB;
+            glds16(rx, pdst + i * 8192, voff, (uint32_t)chunk * 128u);
+        }
+        char* const wdst = Wbuf + buf * WBYTES + wid * 1024;
+        const uint32_t wso = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rw, wdst + i * 8192, wvo[i], wso);
+    };
+
+    // ---- fragment read offsets (bytes inside a stage buffer); k-half ks toggles bit 6
+    uint32_t offA[4], offB[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = wm * 64 + m * 16 + li;
+        offA[m] = (uint32_t)(row * 128 + ((lg ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int row = wn * 64 + n * 16 + li;
+        offB[n] = (uint32_t)(row * 128 + ((lg ^ (row & 7)) << 4));
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    for (int s = 0; s < NS; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage s landed for every wave; every wave is done reading ring slot (s+1)&1
+        if (s + 1 < NS) issue(s + 1, (s + 1) & 1);
+        const char* const Pb = Pbuf + (s & 1) * PBYTES;
+        const char* const Wb = Wbuf + (s & 1) * WBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4_t a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *(const u32x4_t*)(Wb + (offA[m] ^ (ks * 64)));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = *(const u32x4_t*)(Pb + (offB[n] ^ (ks * 64)));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::run(a[m], b[n], acc[m][n]);
+        }
+    }
+
+    // ---- epilogue: bias/activation in registers -> LDS tile [pixel][channel] -> coalesced 16-B NHWC stores
+    constexpr int OS = BN * ESZ + 16;  // padded row stride
+    __syncthreads();
+    char* const O = smem;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int col = wm * 64 + m * 16 + lg * 4;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (p.bias != nullptr && co0 + col + r < p.wrows) ? p.bias[co0 + col + r] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = wn * 64 + n * 16 + li;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[m][n][r] + bv[r];
+                if (p.act == C2W_ACT_SILU) v[r] = silu_f(v[r]);
+            }
+            if constexpr (ESZ == 4) {
+                *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int SEGS = BN * ESZ / 16;
+    constexpr int PER16 = 16 / ESZ;
+    for (int seg = tid; seg < BM * SEGS; seg += NTHREADS) {
+        const int row = seg / SEGS, cs = seg - row * SEGS;
+        const int Q = tm * BM + row;
+        const int c = co0 + cs * PER16;
+        if (Q < npix && c < p.Cout) {
+            u32x4_t v = *(const u32x4_t*)(O + row * OS + cs * 16);
+            const size_t off = ((size_t)Q * p.ldy + c) * ESZ;
+            if (p.mul != nullptr || p.res != nullptr) {
+                float f[PER16];
+                unpack16<T>(v, f);
+                if (p.mul != nullptr) {
+                    float g[PER16];
+                    unpack16<T>(*(const u32x4_t*)((const char*)p.mul + off), g);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) f[e] *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(g[e]) : g[e];
+                }
+                if (p.res != nullptr) {
+                    float g[PER16];
+                    unpack16<T>(*(const u32x4_t*)((const char*)p.res + off), g);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) f[e] += g[e];
+                }
+                v = pack16<T>(f);
+            }
+            *(u32x4_t*)((char*)p.y + off) = v;
+        }
+    }
+}
+
+// ---- slow, obviously-correct direct convolution with the same argument block (debug / cross-check only)
+template <typename T, int MODE>
+__global__ void conv_naive_kernel(const C2wConvArgs p) {
+    constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
+    const int HWo = p.Hout * p.Wout;
+    const long long total = (long long)p.B * HWo * p.Cout;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % p.Cout);
+        const long long Q = idx / p.Cout;
+        const int b = (int)(Q / HWo);
+        const int rem = (int)(Q - (long long)b * HWo);
+        const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+        float acc = 0.f;
+        for (int tap = 0; tap < NT; ++tap) {
+            int ih, iw;
+            if (!src_pixel<MODE>(p, oh, ow, tap / 3, tap % 3, ih, iw)) continue;
+            const T* xp = (const T*)p.x + (((size_t)b * p.Hin + ih) * p.Win + iw) * p.Cin;
+            const T* wp = (const T*)p.w + ((size_t)co * NT + tap) * p.Cin;
+            if (co >= p.wrows) continue;
+            for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(Elem<T>::ld(wp + ci), Elem<T>::ld(xp + ci), acc);
+        }
+        if (p.bias && co < p.wrows) acc += p.bias[co];
+        if (p.act == C2W_ACT_SILU) acc = silu_f(acc);
+        const size_t off = (size_t)Q * p.ldy + co;
+        if (p.mul) {
+            float g = Elem<T>::ld((const T*)p.mul + off);
+            acc *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(g) : g;
+        }
+        if (p.res) acc += Elem<T>::ld((const T*)p.res + off);
+        Elem<T>::st((T*)p.y + off, acc);
+    }
+}
+
+template <typename T, int MODE>
+int launch_mode(const C2wConvArgs& a, int naive, hipStream_t st) {
+    const long long npix = (long long)a.B * a.Hout * a.Wout;
+    if (naive) {
+        long long total = npix * a.Cout;
+        int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        conv_naive_kernel<T, MODE><<<grid, 256, 0, st>>>(a);
+        return (int)hipGetLastError();
+    }
+    constexpr int ESZ = sizeof(T);
+    constexpr int lds = (2 * PBYTES + 2 * WBYTES) > BM * (BN * ESZ + 16) ? (2 * PBYTES + 2 * WBYTES) : BM * (BN * ESZ + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int nM = (int)((npix + BM - 1) / BM), nN = (a.Cout + BN - 1) / BN;
+    conv_igemm_kernel<T, MODE><<<nM * nN, NTHREADS, lds, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_dtype(const C2wConvArgs& a, int naive, hipStream_t st) {
+    switch (a.mode) {
+        case C2W_CONV_1X1: return launch_mode<T, C2W_CONV_1X1>(a, naive, st);
+        case C2W_CONV_S1: return launch_mode<T, C2W_CONV_S1>(a, naive, st);
+        case C2W_CONV_S2: return launch_mode<T, C2W_CONV_S2>(a, naive, st);
+        case C2W_CONV_UP: return launch_mode<T, C2W_CONV_UP>(a, naive, st);
+        case C2W_CONV_TS2: return launch_mode<T, C2W_CONV_TS2>(a, naive, st);
+    }
+    return C2W_ERR_BAD_ARG;
+}
+
+}  // namespace
+
+extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void* stream) {
+    if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return C2W_ERR_BAD_ARG;
+    const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
+    const int ck = 128 / esz;
+    if (a->Cin <= 0 || a->Cin % ck != 0) return C2W_ERR_BAD_SHAPE;            // K-chunk granularity
+    if (a->Cout <= 0 || a->Cout % (16 / esz) != 0 || a->ldy % (16 / esz) != 0) return C2W_ERR_BAD_SHAPE;
+    if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
+    if (a->Hout >= 65536 || a->Wout >= 65536) return C2W_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, naive, st);
+    return C2W_ERR_BAD_ARG;
+}

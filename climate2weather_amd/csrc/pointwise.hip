@@ -1,0 +1,528 @@
+// HBM-bound kernels around the convolutions: channel LayerNorm (+ time modulation) forward/backward,
+// layout changes at the NCHW fp32 boundary, noise process / loss, reductions, optimizer.
+// All are streaming kernels: 16-byte vector accesses, fp32 math, wave-level (16-lane sub-group) reductions.
+#include "common.h"
+#include "c2w_hip.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;  // 16 lanes x LN_MAXV vectors of 16 B per pixel  (C <= 1024 bf16 / 512 fp32)
+
+__device__ __forceinline__ float sub16_sum(float v) {  // sum over the 16 lanes that share a pixel
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = LN_C(x + m[b])   zuko.nn.LayerNorm as used at model/nn.py:44,154,183 fused with the broadcast add of
+// model/nn.py:28.  16 lanes per pixel, whole channel row in registers, two-pass mean/variance.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ m, T* __restrict__ y,
+                                                     long long npix, int HW, int C, int ldm, float eps, float inv_den) {
+    constexpr int P = Elem<T>::PER16;
+    const int sub = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int nv = (C + 16 * P - 1) / (16 * P);
+    for (long long pix = (long long)blockIdx.x * 16 + sub; pix < npix; pix += (long long)gridDim.x * 16) {
+        const T* xr = x + pix * C;
+        const float* mr = m ? m + (size_t)(ldm ? (pix / HW) : 0) * ldm : nullptr;
+        float f[LN_MAXV][P];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+                unpack16<T>(*(const u32x4_t*)(xr + c), f[v]);
+                if (mr) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) f[v][e] += mr[c + e];
+                }
+#pragma unroll
+                for (int e = 0; e < P; ++e) s += f[v][e];
+            }
+        }
+        const float mean = sub16_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    f[v][e] -= mean;
+                    q += f[v][e] * f[v][e];
+                }
+            }
+        }
+        const float rs = 1.0f / sqrtf(sub16_sum(q) * inv_den + eps);
+        T* yr = y + pix * C;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) f[v][e] *= rs;
+                *(u32x4_t*)(yr + c) = pack16<T>(f[v]);
+            }
+        }
+    }
+}
+
+// dx = dres + d/dx [ LN_C(x + m) ] . dy ;  dm[b] += sum_pixels of the LN part (the modulation gradient).
+// With s = sqrt(var + eps), xh = (x+m-mean)/s, den = C-1 (unbiased) or C:
+//   dxm = ( dy - mean(dy) - xh * sum(dy*xh)/den ) / s
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ m,
+                                                     const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dm,
+                                                     long long npix, int HW, int C, int ldm, float eps, float inv_den, int pix_per_block) {
+    constexpr int P = Elem<T>::PER16;
+    const int sub = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int nv = (C + 16 * P - 1) / (16 * P);
+    float am[LN_MAXV][P];
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v)
+#pragma unroll
+        for (int e = 0; e < P; ++e) am[v][e] = 0.f;
+    long long cur_b = -1;
+    auto flush = [&]() {
+        if (dm == nullptr || cur_b < 0) return;
+        float* dr = dm + (size_t)(ldm ? cur_b : 0) * ldm;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    atomicAdd(dr + c + e, am[v][e]);
+                    am[v][e] = 0.f;
+                }
+            }
+        }
+    };
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+    for (long long pix = p0 + sub; pix < p1; pix += 16) {
+        const long long b = pix / HW;
+        if (b != cur_b) {
+            flush();
+            cur_b = b;
+        }
+        const T* xr = x + pix * C;
+        const T* gr = dy + pix * C;
+        const float* mr = m ? m + (size_t)(ldm ? b : 0) * ldm : nullptr;
+        float f[LN_MAXV][P], g[LN_MAXV][P];
+        float s = 0.f, sg = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+                unpack16<T>(*(const u32x4_t*)(xr + c), f[v]);
+                unpack16<T>(*(const u32x4_t*)(gr + c), g[v]);
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    if (mr) f[v][e] += mr[c + e];
+                    s += f[v][e];
+                    sg += g[v][e];
+                }
+            }
+        }
+        const float mean = sub16_sum(s) / (float)C;
+        const float gmean = sub16_sum(sg) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    f[v][e] -= mean;
+                    q += f[v][e] * f[v][e];
+                }
+            }
+        }
+        const float rs = 1.0f / sqrtf(sub16_sum(q) * inv_den + eps);
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    f[v][e] *= rs;  // xhat
+                    d += g[v][e] * f[v][e];
+                }
+            }
+        }
+        const float dot = sub16_sum(d) * inv_den;
+        T* dxr = dx + pix * C;
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+                float o[P];
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    o[e] = (g[v][e] - gmean - f[v][e] * dot) * rs;
+                    am[v][e] += o[e];
+                }
+                if (dres) {
+                    float r[P];
+                    unpack16<T>(*(const u32x4_t*)(dres + pix * C + c), r);
+#pragma unroll
+                    for (int e = 0; e < P; ++e) o[e] += r[e];
+                }
+                *(u32x4_t*)(dxr + c) = pack16<T>(o);
+            }
+        }
+    }
+    flush();
+}
+
+// out[c] += sum over rows of a[row][c]   (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, float* __restrict__ out, long long rows, int C, int lda,
+                                                     int rows_per_block) {
+    constexpr int P = Elem<T>::PER16;
+    const int nvec = C / P;  // 16-B vectors per row
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    for (int vec = threadIdx.x; vec < nvec; vec += blockDim.x) {
+        float acc[P];
+#pragma unroll
+        for (int e = 0; e < P; ++e) acc[e] = 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            float f[P];
+            unpack16<T>(*(const u32x4_t*)(a + r * lda + vec * P), f);
+#pragma unroll
+            for (int e = 0; e < P; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < P; ++e) atomicAdd(out + vec * P + e, acc[e]);
+    }
+}
+
+template <typename T, int OP>  // OP 0: y = silu(x); 1: y = a * silu'(x)
+__global__ __launch_bounds__(256) void silu_kernel(const T* __restrict__ x, const T* __restrict__ a, T* __restrict__ y, long long nvec) {
+    constexpr int P = Elem<T>::PER16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float f[P];
+        unpack16<T>(((const u32x4_t*)x)[i], f);
+        if (OP == 0) {
+#pragma unroll
+            for (int e = 0; e < P; ++e) f[e] = silu_f(f[e]);
+        } else {
+            float g[P];
+            unpack16<T>(((const u32x4_t*)a)[i], g);
+#pragma unroll
+            for (int e = 0; e < P; ++e) f[e] = g[e] * dsilu_f(f[e]);
+        }
+        ((u32x4_t*)y)[i] = pack16<T>(f);
+    }
+}
+
+// dx[b][h][w][:] = sum_{i,j<2} g[b][2h+i][2w+j][:]      (adjoint of Upsample(nearest, x2), model/nn.py:184)
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2_kernel(const T* __restrict__ g, T* __restrict__ dx, int B, int H, int W, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int nvec = C / P;
+    const long long total = (long long)B * H * W * nvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int vec = (int)(i % nvec);
+        long long pix = i / nvec;
+        const int w = (int)(pix % W);
+        pix /= W;
+        const int h = (int)(pix % H);
+        const int b = (int)(pix / H);
+        float acc[P];
+#pragma unroll
+        for (int e = 0; e < P; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                float f[P];
+                unpack16<T>(*(const u32x4_t*)(g + ((((size_t)b * 2 * H + 2 * h + di) * 2 * W) + 2 * w + dj) * C + vec * P), f);
+#pragma unroll
+                for (int e = 0; e < P; ++e) acc[e] += f[e];
+            }
+        ((u32x4_t*)dx)[i] = pack16<T>(acc);
+    }
+}
+
+// NCHW fp32 -> NHWC T with channel padding (zeros).  Optional fused noise process xt = mu[b] x + sigma[b] eps
+// (src/thor/pipelines.py:22-25): pass eps (NCHW fp32) and musig[b] = {mu, sigma}.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                           const float* __restrict__ musig, T* __restrict__ y, int B, int C, int HW, int ldc) {
+    constexpr int P = Elem<T>::PER16;
+    const int nvec = ldc / P;
+    const long long total = (long long)B * HW * nvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // consecutive threads -> consecutive pixels of one (b, channel-vector): reads coalesce per channel plane
+        const int pix = (int)(i % HW);
+        const long long r = i / HW;
+        const int vec = (int)(r % nvec);
+        const int b = (int)(r / nvec);
+        float f[P];
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            const int c = vec * P + e;
+            float v = 0.f;
+            if (c < C) {
+                const size_t o = ((size_t)b * C + c) * HW + pix;
+                v = x[o];
+                if (eps) v = musig[2 * b] * v + musig[2 * b + 1] * eps[o];
+            }
+            f[e] = v;
+        }
+        *(u32x4_t*)(y + ((size_t)b * HW + pix) * ldc + vec * P) = pack16<T>(f);
+    }
+}
+
+// NHWC T -> NCHW fp32 (first C channels)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ y, float* __restrict__ out, int B, int C, int HW, int ldc) {
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const long long r = i / HW;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        out[i] = Elem<T>::ld(y + ((size_t)b * HW + pix) * ldc + c);
+    }
+}
+
+// Training loss tail (src/thor/pipelines.py:35 + training_loop.py:377):  l = mean((y - eps)^2) * scale
+//   dy[b][pix][c] = 2 (y - eps) * scale / N   (NHWC T, padded channels = 0);  loss_sum += sum (y-eps)^2 (fp32 atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void mse_loss_grad_kernel(const T* __restrict__ y, const float* __restrict__ eps, T* __restrict__ dy,
+                                                            float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale) {
+    constexpr int P = Elem<T>::PER16;
+    const int nvec = ldc / P;
+    const long long total = (long long)B * HW * nvec;
+    float local = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const long long r = i / HW;
+        const int vec = (int)(r % nvec);
+        const int b = (int)(r / nvec);
+        const size_t o = ((size_t)b * HW + pix) * ldc + vec * P;
+        float f[P];
+        unpack16<T>(*(const u32x4_t*)(y + o), f);
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            const int c = vec * P + e;
+            float d = 0.f;
+            if (c < C) {
+                d = f[e] - eps[((size_t)b * C + c) * HW + pix];
+                local += d * d;
+            }
+            f[e] = d * gscale;
+        }
+        *(u32x4_t*)(dy + o) = pack16<T>(f);
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
+}
+
+// timestep_embedding (model/score.py:14-34): out[b] = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(max_period) i/half)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim, float max_period) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    const int b = i / dim, k = i - b * dim;
+    float v = 0.f;
+    if (k < 2 * half) {
+        const int kk = k < half ? k : k - half;
+        const float freq = expf(-logf(max_period) * (float)kk / (float)half);
+        const float a = t[b] * freq;
+        v = k < half ? cosf(a) : sinf(a);
+    }
+    out[i] = v;
+}
+
+// VP-cosine schedule (src/thor/pipelines.py:13-20): musig[b] = {mu(t_b), sigma(t_b)}
+__global__ void mu_sigma_kernel(const float* __restrict__ t, float* __restrict__ musig, int n, float eta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = cosf(acosf(sqrtf(eta)) * t[i]);
+    const float a = c * c;
+    musig[2 * i] = a;
+    musig[2 * i + 1] = sqrtf(1.f - a * a + eta * eta);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        Elem<TO>::st(out + i, in[i]);
+}
+
+// w[r][tap][k] (fp32, row stride NT*ldk) -> out[k][tap'][r] (T, row stride NT*ldr), tap' = NT-1-tap when flip:
+// the operand of the input-gradient convolution.  Only r < R, k < K are written (padding stays as initialised).
+template <typename TO>
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, TO* __restrict__ out, int R, int NT, int K,
+                                                               int ldk, int ldr, int flip) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int otap = flip ? NT - 1 - tap : tap;
+    const int r0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, k = k0 + tx;
+        tile[i][tx] = (r < R && k < K) ? w[((size_t)r * NT + tap) * ldk + k] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, r = r0 + tx;
+        if (k < K && r < R) Elem<TO>::st(out + ((size_t)k * NT + otap) * ldr + r, tile[tx][i]);
+    }
+}
+
+// Fused AdamW (torch.optim.AdamW, train.py:176-181) + EMA (src/thor/ema.py:23-27) + low-precision shadow refresh.
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ shadow,
+                                                        long long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                        float bc2_sqrt, float ema_rate, float grad_scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+        if (ema) ema[i] = ema_rate * ema[i] + (1.f - ema_rate) * pi;
+        if (shadow) shadow[i] = f32_to_bf16(pi);
+    }
+}
+
+inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                                         \
+    do {                                                                                \
+        if ((dtype) == C2W_DTYPE_F32) { using T = float; CALL; }                        \
+        else if ((dtype) == C2W_DTYPE_BF16) { using T = bf16_t; CALL; }                 \
+        else return C2W_ERR_BAD_ARG;                                                    \
+    } while (0)
+
+static inline bool vec_ok(int dtype, int C) { return C > 0 && C % (dtype == C2W_DTYPE_F32 ? 4 : 8) == 0; }
+
+extern "C" int c2w_ln_forward(const void* x, const float* m, void* y, long long npix, int HW, int C, int ldm, float eps, int unbiased,
+                              int dtype, void* stream) {
+    if (!x || !y || !vec_ok(dtype, C) || C > 16 * LN_MAXV * (dtype == C2W_DTYPE_F32 ? 4 : 8) || C < 2) return C2W_ERR_BAD_SHAPE;
+    const float inv_den = 1.0f / (float)(unbiased ? C - 1 : C);
+    DISPATCH_T(dtype, (ln_fwd_kernel<T><<<grid_for(npix, 16, 16384), 256, 0, (hipStream_t)stream>>>((const T*)x, m, (T*)y, npix, HW, C, ldm,
+                                                                                                    eps, inv_den)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_ln_backward(const void* dy, const void* x, const float* m, const void* dres, void* dx, float* dm, long long npix, int HW,
+                               int C, int ldm, float eps, int unbiased, int dtype, void* stream) {
+    if (!dy || !x || !dx || !vec_ok(dtype, C) || C > 16 * LN_MAXV * (dtype == C2W_DTYPE_F32 ? 4 : 8) || C < 2) return C2W_ERR_BAD_SHAPE;
+    const float inv_den = 1.0f / (float)(unbiased ? C - 1 : C);
+    const int ppb = 256;
+    const int grid = (int)((npix + ppb - 1) / ppb);
+    DISPATCH_T(dtype, (ln_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)x, m, (const T*)dres, (T*)dx, dm, npix,
+                                                                                 HW, C, ldm, eps, inv_den, ppb)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_colsum(const void* a, float* out, long long rows, int C, int lda, int dtype, void* stream) {
+    if (!a || !out || !vec_ok(dtype, C) || !vec_ok(dtype, lda)) return C2W_ERR_BAD_SHAPE;
+    const int rpb = 128;
+    const int grid = (int)((rows + rpb - 1) / rpb);
+    DISPATCH_T(dtype, (colsum_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)a, out, rows, C, lda, rpb)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_silu(const void* x, void* y, long long n, int dtype, void* stream) {
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    if (!x || !y || n % P) return C2W_ERR_BAD_SHAPE;
+    DISPATCH_T(dtype, (silu_kernel<T, 0><<<grid_for(n / P), 256, 0, (hipStream_t)stream>>>((const T*)x, nullptr, (T*)y, n / P)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_silu_backward(const void* x, const void* dy, void* dx, long long n, int dtype, void* stream) {
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    if (!x || !dy || !dx || n % P) return C2W_ERR_BAD_SHAPE;
+    DISPATCH_T(dtype, (silu_kernel<T, 1><<<grid_for(n / P), 256, 0, (hipStream_t)stream>>>((const T*)x, (const T*)dy, (T*)dx, n / P)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_sumpool2(const void* g, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!g || !dx || !vec_ok(dtype, C)) return C2W_ERR_BAD_SHAPE;
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    DISPATCH_T(dtype, (sumpool2_kernel<T><<<grid_for((long long)B * H * W * (C / P)), 256, 0, (hipStream_t)stream>>>((const T*)g, (T*)dx, B, H,
+                                                                                                                  W, C)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* musig, void* y, int B, int C, int HW, int ldc, int dtype,
+                                void* stream) {
+    if (!x || !y || !vec_ok(dtype, ldc) || ldc < C || (eps && !musig)) return C2W_ERR_BAD_SHAPE;
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    DISPATCH_T(dtype, (nchw_to_nhwc_kernel<T><<<grid_for((long long)B * HW * (ldc / P)), 256, 0, (hipStream_t)stream>>>(x, eps, musig, (T*)y,
+                                                                                                                     B, C, HW, ldc)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_nhwc_to_nchw(const void* y, float* out, int B, int C, int HW, int ldc, int dtype, void* stream) {
+    if (!y || !out || ldc < C) return C2W_ERR_BAD_SHAPE;
+    DISPATCH_T(dtype, (nhwc_to_nchw_kernel<T><<<grid_for((long long)B * C * HW), 256, 0, (hipStream_t)stream>>>((const T*)y, out, B, C, HW,
+                                                                                                             ldc)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc, float gscale,
+                                 int dtype, void* stream) {
+    if (!y || !eps || !dy || !loss_sum || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    DISPATCH_T(dtype, (mse_loss_grad_kernel<T><<<grid_for((long long)B * HW * (ldc / P), 256, 2048), 256, 0, (hipStream_t)stream>>>(
+                          (const T*)y, eps, (T*)dy, loss_sum, B, C, HW, ldc, gscale)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {
+    if (!t || !out || n <= 0 || dim <= 0) return C2W_ERR_BAD_SHAPE;
+    timestep_embedding_kernel<<<(n * dim + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, out, n, dim, max_period);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_mu_sigma(const float* t, float* musig, int n, float eta, void* stream) {
+    if (!t || !musig || n <= 0) return C2W_ERR_BAD_SHAPE;
+    mu_sigma_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, musig, n, eta);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_cast_f32(const float* in, void* out, long long n, int dtype, void* stream) {
+    if (!in || !out) return C2W_ERR_BAD_ARG;
+    DISPATCH_T(dtype, (cast_f32_kernel<T><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(in, (T*)out, n)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_weight_transpose(const float* w, void* out, int R, int NT, int K, int ldk, int ldr, int flip, int dtype, void* stream) {
+    if (!w || !out || R <= 0 || NT <= 0 || K <= 0 || ldk < K || ldr < R) return C2W_ERR_BAD_SHAPE;
+    dim3 grid((K + 31) / 32, (R + 31) / 32, NT);
+    DISPATCH_T(dtype, (weight_transpose_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(w, (T*)out, R, NT, K, ldk, ldr, flip)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float ema_rate, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || step < 1) return C2W_ERR_BAD_ARG;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    adamw_ema_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps,
+                                                                   weight_decay, bc1, bc2_sqrt, ema_rate, grad_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" const char* c2w_target(void) { return "gfx950"; }

@@ -1,0 +1,306 @@
+// Weight-gradient GEMM on MFMA for gfx950:   dW[co][tap][ci] += sum_q dY[q][co] * X[src(q,tap)][ci]
+// (the wgrad third of the 346 GFLOP/window training step; replaces autograd's conv/linear weight backward
+// for model/nn.py:45,47,149,155,157,169-174,185-194 and model/score.py:56-57).
+//
+// GEMM view: M = output channel, N = (tap, input channel), K = output pixel -- the reduction runs over the
+// NHWC *row* index, so both MFMA operands are K-strided in memory.  Tiles are staged exactly as they lie in HBM
+// ([pixel][channel], direct-to-LDS 16-B loads, zero padding by out-of-range buffer offsets) and transposed on the
+// way to the matrix core:  bf16 -> ds_read_b64_tr_b16 (hardware transpose read),  fp32 -> one dword per lane.
+// LDS rows are XOR-swizzled on 16-B chunks (chunk ^= ((row&3)<<2 | (row>>2)&3)), applied on the source address,
+// which makes both kinds of read bank-conflict free.
+// Block tile (same bytes for both dtypes): 256 B of output channels x 4 "column blocks" of 128 B of (tap, ci)
+// x 64 pixels per stage; 8 waves = 2 (M) x 4 (N: one column block each).  Split-K over pixel ranges across
+// workgroups; partial tiles are combined with fp32 global atomics issued as 256-B contiguous wave instructions
+// (tile staged through LDS first).  dW must be zero-initialised (or hold the value to accumulate onto).
+#include "conv_geom.h"
+
+namespace {
+
+constexpr int KT = 64;  // pixels per stage
+constexpr int NTHREADS = 512;
+constexpr int ABYTES = KT * 256;  // dY stage  (16 KiB)
+constexpr int BBYTES = KT * 512;  // X stage   (32 KiB)
+
+struct WgradArgs {
+    const void* dy;  // [npix][ldy]
+    const void* x;   // [B][Hin][Win][Cin]
+    float* dw;       // [Cout][NT][Cin] fp32, accumulated
+    int B, Hin, Win, Cin, Hout, Wout, Cout, ldy;
+    int nsplit, ktiles_per_split;
+    FastDiv div_hw, div_w;
+};
+
+__device__ __forceinline__ uint32_t swz(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
+    constexpr int COT = 256 / ESZ;  // output channels per block tile
+    constexpr int CIB = 128 / ESZ;  // input channels per column block
+    constexpr int MT = (ESZ == 2) ? 4 : 2;  // 16x16 MFMA tiles per wave along M
+    constexpr int NTL = MT;                 // and along N (one column block per wave)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Abuf = smem;
+    char* const Bbuf = smem + 2 * ABYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int cib_per_tap = p.Cin / CIB;
+    const int nb_total = NT * cib_per_tap;       // column blocks in the whole (tap, ci) axis
+    const int tilesN = (nb_total + 3) / 4;
+    const int tilesM = (p.Cout + COT - 1) / COT;
+    const int tilesMN = tilesM * tilesN;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int split = L / tilesMN, mn = L - split * tilesMN;
+    const int tm = mn / tilesN, tn = mn - tm * tilesN;
+    const int co0 = tm * COT;
+    const int HWo = p.Hout * p.Wout;
+    const int npix = p.B * HWo;
+    const int nkt = (npix + KT - 1) / KT;
+    const int kt0 = split * p.ktiles_per_split;
+    const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;
+
+    // ---- staging slots.  dY: 64 rows x 16 chunks = 2 rounds; X: 64 rows x 32 chunks = 4 rounds.
+    uint32_t avo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = tid + NTHREADS * i, row = s >> 4, pc = s & 15;
+        const uint32_t lc = (uint32_t)pc ^ swz(row);
+        const int c = co0 + (int)lc * (16 / ESZ);
+        avo[i] = (c < p.Cout) ? (uint32_t)row * (uint32_t)(p.ldy * ESZ) + (uint32_t)c * ESZ : C2W_OOB;
+    }
+    int brow[4], btap[4];
+    uint32_t bco[4];  // byte offset inside the source pixel row, or OOB when the column block does not exist
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = tid + NTHREADS * i, row = s >> 5, pc = s & 31;
+        const uint32_t lc = (uint32_t)pc ^ swz(row);
+        const int nb = tn * 4 + (int)(lc >> 3);
+        const int tap = nb / cib_per_tap;
+        brow[i] = row;
+        btap[i] = (nb < nb_total) ? tap : -1;
+        bco[i] = (uint32_t)((nb - tap * cib_per_tap) * 128 + (lc & 7) * 16);
+    }
+    const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
+    const size_t dy_total = (size_t)npix * p.ldy * ESZ;
+
+    auto issue = [&](int kt, int buf) {
+        const int q0 = kt * KT;
+        // dY rows q0 .. q0+63 (rows past the end fall outside the descriptor -> zeros)
+        const size_t aoff = (size_t)q0 * p.ldy * ESZ;
+        size_t arem = dy_total - aoff;
+        if (arem > 0x7fffffffu) arem = 0x7fffffffu;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.dy + aoff, (uint32_t)arem);
+        char* const adst = Abuf + buf * ABYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(ra, adst + i * 8192, avo[i], 0);
+        // X rows gathered through the tap geometry, rebased at the first image of this K tile
+        const int b0 = fast_div(q0, p.div_hw);
+        size_t xrem = (size_t)(p.B - b0) * img_bytes;
+        if (xrem > 0x7fffffffu) xrem = 0x7fffffffu;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b0 * img_bytes, (uint32_t)xrem);
+        char* const bdst = Bbuf + buf * BBYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int Q = q0 + brow[i];
+            const int b = fast_div(Q, p.div_hw);
+            const int rem = Q - b * HWo;
+            const int oh = fast_div(rem, p.div_w);
+            const int ow = rem - oh * p.Wout;
+            const int tap = btap[i];
+            const int kh = tap / 3, kw = tap - kh * 3;
+            int ih, iw;
+            const bool ok = src_pixel<MODE>(p, oh, ow, kh, kw, ih, iw) && tap >= 0 && Q < npix;
+            const uint32_t voff = ok ? (uint32_t)((((b - b0) * p.Hin + ih) * p.Win + iw) * p.Cin) * ESZ + bco[i] : C2W_OOB;
+            glds16(rx, bdst + i * 8192, voff, 0);
+        }
+    };
+
+    f32x4_t acc[MT][NTL];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment read offsets
+    uint32_t offA[MT][2], offB[NTL][2];  // bf16: [tile][h]; fp32: [tile][0] holds the (row-independent) part
+    if constexpr (ESZ == 2) {
+        const int q = li >> 2, pp = li & 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 8 * lg + q + 4 * h;  // + 32*ks
+            const uint32_t f = swz(row);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                offA[m][h] = (uint32_t)(row * 256 + ((((wm * 8 + m * 2 + (pp >> 1)) ^ f) & 15) << 4) + 8 * (pp & 1));
+#pragma unroll
+            for (int n = 0; n < NTL; ++n) {
+                const uint32_t lcg = (uint32_t)(wn * 8 + n * 2 + (pp >> 1));
+                offB[n][h] = (uint32_t)(row * 512 + ((lcg ^ f) << 4) + 8 * (pp & 1));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            offA[m][0] = (uint32_t)((wm * 8 + m * 4 + (li >> 2)) ^ (lg << 2));  // chunk ^ (row&3)<<2 ; (kk&3) xored per step
+            offA[m][1] = (uint32_t)((li & 3) * 4);
+        }
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) {
+            offB[n][0] = (uint32_t)((wn * 8 + n * 4 + (li >> 2)) ^ (lg << 2));
+            offB[n][1] = (uint32_t)((li & 3) * 4);
+        }
+    }
+
+    if (kt0 < kt1) issue(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
+        const char* const Ab = Abuf + buf * ABYTES;
+        const char* const Bb = Bbuf + buf * BBYTES;
+        if constexpr (ESZ == 2) {
+            typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t a[MT], b[NTL];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ab + offA[m][0] + ks * 32 * 256));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ab + offA[m][1] + ks * 32 * 256));
+                    a[m] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int n = 0; n < NTL; ++n) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bb + offB[n][0] + ks * 32 * 512));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bb + offB[n][1] + ks * 32 * 512));
+                    b[n] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {  // 4 pixels per MFMA: lane (i,g) feeds k = 4*kk + g
+                const int row = kk * 4 + lg;
+                float a[MT], b[NTL];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = *(const float*)(Ab + row * 256 + ((offA[m][0] ^ (kk & 3)) << 4) + offA[m][1]);
+#pragma unroll
+                for (int n = 0; n < NTL; ++n) b[n] = *(const float*)(Bb + row * 512 + ((offB[n][0] ^ (kk & 3)) << 4) + offB[n][1]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: tile -> LDS [co][column] fp32 -> atomics, one (co, column block) row per wave instruction
+    constexpr int NCOL = 4 * CIB;
+    constexpr int OS = NCOL + 4;  // padded row stride (floats)
+    __syncthreads();
+    float* const O = (float*)smem;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) {
+            const int col = wn * CIB + n * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) O[(wm * (COT / 2) + m * 16 + lg * 4 + r) * OS + col] = acc[m][n][r];
+        }
+    __syncthreads();
+    if (kt0 >= kt1) return;
+    for (int idx = tid; idx < COT * NCOL; idx += NTHREADS) {
+        const int row = idx / NCOL, col = idx - row * NCOL;
+        const int cb = col / CIB, cil = col - cb * CIB;
+        const int nb = tn * 4 + cb;
+        const int co = co0 + row;
+        if (nb < nb_total && co < p.Cout) {
+            const int tap = nb / cib_per_tap;
+            const int ci = (nb - tap * cib_per_tap) * CIB + cil;
+            atomicAdd(p.dw + ((size_t)co * NT + tap) * p.Cin + ci, O[row * OS + col]);
+        }
+    }
+}
+
+FastDiv make_div(uint32_t d) {
+    FastDiv r{0, 0};
+    if (d <= 1) return r;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;  // s = ceil(log2 d) >= 1
+    r.magic = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+    r.shift = s - 1;
+    return r;
+}
+
+template <typename T, int MODE>
+int launch(const C2wConvArgs& a, float* dw, hipStream_t st) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    WgradArgs p;
+    p.dy = a.y; p.x = a.x; p.dw = dw;
+    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Cin = a.Cin; p.Hout = a.Hout; p.Wout = a.Wout; p.Cout = a.Cout; p.ldy = a.ldy;
+    const long long npix = (long long)a.B * a.Hout * a.Wout;
+    const int nkt = (int)((npix + KT - 1) / KT);
+    const int tilesN = (NT * (a.Cin / CIB) + 3) / 4, tilesM = (a.Cout + COT - 1) / COT;
+    const int tilesMN = tilesM * tilesN;
+    int nsplit = (768 + tilesMN - 1) / tilesMN;  // ~3 workgroups per CU in flight over the launch
+    if (nsplit > nkt) nsplit = nkt;
+    if (nsplit < 1) nsplit = 1;
+    p.ktiles_per_split = (nkt + nsplit - 1) / nsplit;
+    p.nsplit = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    p.div_hw = make_div((uint32_t)(a.Hout * a.Wout));
+    p.div_w = make_div((uint32_t)a.Wout);
+    constexpr int lds_main = 2 * ABYTES + 2 * BBYTES;
+    constexpr int lds_epi = COT * (4 * CIB + 4) * 4;
+    constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    wgrad_kernel<T, MODE><<<tilesMN * p.nsplit, NTHREADS, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_dtype(const C2wConvArgs& a, float* dw, hipStream_t st) {
+    switch (a.mode) {
+        case C2W_CONV_1X1: return launch<T, C2W_CONV_1X1>(a, dw, st);
+        case C2W_CONV_S1: return launch<T, C2W_CONV_S1>(a, dw, st);
+        case C2W_CONV_S2: return launch<T, C2W_CONV_S2>(a, dw, st);
+        case C2W_CONV_UP: return launch<T, C2W_CONV_UP>(a, dw, st);
+    }
+    return C2W_ERR_BAD_ARG;
+}
+
+}  // namespace
+
+// Geometry is passed with the forward call's argument block: x = the forward input, y = dY (gradient w.r.t. the forward
+// output, [B*Hout*Wout][ldy]); w/bias/res/mul/act are ignored.  dw is [Cout][taps][Cin] fp32 and is accumulated into.
+extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, int dtype, void* stream) {
+    if (a == nullptr || a->x == nullptr || a->y == nullptr || dw == nullptr) return C2W_ERR_BAD_ARG;
+    const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
+    if (a->Cin <= 0 || a->Cin % (128 / esz) != 0) return C2W_ERR_BAD_SHAPE;
+    if (a->Cout <= 0 || a->ldy % (16 / esz) != 0 || a->Cout > a->ldy) return C2W_ERR_BAD_SHAPE;
+    if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
+    if ((long long)a->B * a->Hout * a->Wout >= (1ll << 31)) return C2W_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, st);
+    return C2W_ERR_BAD_ARG;
+}

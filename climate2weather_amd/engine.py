@@ -1,0 +1,549 @@
+"""Host-side engine: lays the ScoreUNet parameters out for the HIP kernels and sequences the launches of one
+forward (and, for training / exact guidance, the hand-written backward) of the reference's hot path
+
+    ScoreUNet.forward  (model/score.py:59-70)  ->  UNet.forward  (model/nn.py:220-242)
+    ModResidualBlock   (model/nn.py:27-28)         AttentionBlock (model/nn.py:49-59)
+
+Data layout in HBM
+  * parameters: ONE flat fp32 buffer; every nn.Parameter is a strided view into it.  Conv2d weights are stored
+    [Cout][kh][kw][Cin] (a channels_last view of the reference's OIHW tensor) which is exactly the K-contiguous
+    operand the implicit GEMM wants; the 30 modulation Linears sit back to back so that one GEMM produces every
+    block's modulation vector.  bf16 mode keeps a bf16 shadow of the same buffer (same offsets).
+  * gradients: one flat fp32 buffer with the same offsets (a single RCCL all-reduce covers all 228 tensors).
+  * activations: NHWC rows [B*H*W][C] in the compute dtype (fp32 or bf16); the reference's NCHW fp32 tensors only
+    exist at the module boundary.
+Everything runs on torch's current stream; torch is the allocator, nothing else.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .nn import BlockSpec, LevelSpec
+from .ops import (ACT_NONE, ACT_SILU, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F32, MUL_DSILU, TORCH_DTYPE)
+
+LN_EPS = 1e-5
+ALIGN = 64  # elements; keeps every region 256-B aligned in fp32 and 128-B aligned in the bf16 shadow
+
+
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+@dataclass
+class ConvRec:
+    """One weight matrix [rows][taps][kstride] (+ bias[rows]) inside the flat buffer."""
+    name: str
+    rows: int  # Cout
+    cin: int  # real input channels
+    kstride: int  # channel stride of the forward operand (>= cin, padded for the network input)
+    taps: int
+    w_off: int = 0
+    b_off: int = 0
+    lin: bool = False  # fp32-only GEMM (time MLP, modulation projections)
+    dg_ld: int = 0  # K stride of the input-gradient operand = channel stride of this layer's output rows
+    dg_off: int = -1  # offset inside the dgrad weight buffer (-1: not needed)
+    flip: bool = False
+
+
+class Layout:
+    """Flat parameter layout derived from the module tree."""
+
+    def __init__(self, net):
+        unet = net.unet
+        self.levels: List[LevelSpec] = unet.spec()
+        self.E = unet.mod_features
+        self.in_channels, self.out_channels = unet.in_channels, unet.out_channels
+        self.cin_pad = _round_up(unet.in_channels, 64)
+        self.cout_pad = _round_up(unet.out_channels, 64)
+        self.noise_features = net.noise_features
+        self.convs: Dict[str, ConvRec] = {}
+        self.views: Dict[str, Tuple[int, Tuple[int, ...], Tuple[int, ...]]] = {}  # param name -> (offset, shape, strides)
+        off = 0
+        # 1) modulation projections, back to back in execution order:  Wp_all [sumC][E], bp_all [sumC]
+        blocks: List[BlockSpec] = []
+        for lv in self.levels:
+            blocks += [b for b in lv.descent if b.kind == "res"]
+        for lv in reversed(self.levels):
+            blocks += [b for b in lv.ascent if b.kind == "res"]
+        mo = 0
+        for b in blocks:
+            b.mod_offset = mo
+            mo += b.channels
+        self.sum_c = mo
+        self.proj_w_off = off
+        for b in blocks:
+            self.views[f"unet.{b.key}.project.0.weight"] = (off, (b.channels, self.E), (self.E, 1))
+            off += b.channels * self.E
+        off = _round_up(off, ALIGN)
+        self.proj_b_off = off
+        for b in blocks:
+            self.views[f"unet.{b.key}.project.0.bias"] = (off, (b.channels,), (1,))
+            off += b.channels
+        off = _round_up(off, ALIGN)
+        self.convs["proj"] = ConvRec("proj", self.sum_c, self.E, self.E, 1, self.proj_w_off, self.proj_b_off, lin=True, dg_ld=self.sum_c)
+
+        def add(name: str, rows: int, cin: int, taps: int, kstride: Optional[int] = None, lin=False, dg_ld=None, flip=False, ndim=4):
+            nonlocal off
+            ks = kstride or cin
+            rec = ConvRec(name, rows, cin, ks, taps, lin=lin, dg_ld=dg_ld if dg_ld is not None else rows, flip=flip)
+            rec.w_off = off
+            if taps == 9:
+                self.views[name + ".weight"] = (off, (rows, cin, 3, 3), (9 * ks, 1, 3 * ks, ks))
+            elif ndim == 3:
+                self.views[name + ".weight"] = (off, (rows, cin, 1), (ks, 1, 1))
+            else:
+                self.views[name + ".weight"] = (off, (rows, cin), (ks, 1))
+            off = _round_up(off + rows * taps * ks, ALIGN)
+            rec.b_off = off
+            self.views[name + ".bias"] = (off, (rows,), (1,))
+            off = _round_up(off + rows, ALIGN)
+            self.convs[name] = rec
+            return rec
+
+        L = len(self.levels)
+        for i, lv in enumerate(self.levels):
+            if i == 0:
+                add("unet." + lv.head_key, lv.channels, self.in_channels, 9, kstride=self.cin_pad, dg_ld=lv.channels, flip=True)
+            else:
+                add("unet." + lv.head_key, lv.channels, self.levels[i - 1].channels, 9, flip=False)
+            for b in lv.descent:
+                self._add_block(add, b)
+        for i in reversed(range(L)):
+            lv = self.levels[i]
+            for b in lv.ascent:
+                self._add_block(add, b)
+            if i > 0:
+                add("unet." + lv.tail_key, self.levels[i - 1].channels, lv.channels, 9, flip=True)
+            else:
+                add("unet." + lv.tail_key, self.out_channels, lv.channels, 9, dg_ld=self.cout_pad, flip=True)
+        add("map_layer0", self.E, self.noise_features, 1, lin=True)
+        add("map_layer1", self.E, self.E, 1, lin=True)
+        self.numel = off
+        # dgrad operand buffers: [cin][taps][dg_ld]
+        dg = 0
+        dgl = 0
+        for rec in self.convs.values():
+            if rec.name == "map_layer0":
+                continue
+            size = _round_up(rec.cin * rec.taps * rec.dg_ld, ALIGN)
+            if rec.lin:
+                rec.dg_off = dgl
+                dgl += size
+            else:
+                rec.dg_off = dg
+                dg += size
+        self.dg_numel, self.dg_lin_numel = dg, dgl
+
+    @staticmethod
+    def _add_block(add, b: BlockSpec):
+        p = "unet." + b.key
+        if b.kind == "res":
+            add(p + ".residue.1", b.channels, b.channels, 9, flip=True)
+            add(p + ".residue.3", b.channels, b.channels, 9, flip=True)
+        else:
+            add(p + ".qkv", 3 * b.channels, b.channels, 1, ndim=3)
+            add(p + ".proj_out", b.channels, b.channels, 1, ndim=3)
+
+
+class Tape:
+    """Backward closures recorded by a training forward (applied in reverse)."""
+
+    def __init__(self):
+        self.steps: List[Callable] = []
+        self.gskip: Dict[int, torch.Tensor] = {}
+        self.meta: dict = {}
+
+
+class Engine:
+    def __init__(self, net):
+        self.layout = Layout(net)
+        self.ln_unbiased = bool(getattr(net, "ln_unbiased", True))
+        self.flat: Optional[torch.Tensor] = None
+        self.flat_grad: Optional[torch.Tensor] = None
+        self.shadow: Optional[torch.Tensor] = None
+        self._shadow_ver = -1
+        self.dg: Dict[int, torch.Tensor] = {}
+        self.dg_lin: Optional[torch.Tensor] = None
+        self._dg_ver: Dict[object, int] = {}
+        self._manual_ver = 0
+        self.attach(net)
+
+    # ------------------------------------------------------------------ parameter storage
+    def attach(self, net) -> None:
+        """(Re)build the flat buffer from the module's current parameters and make them views into it."""
+        lay = self.layout
+        params = dict(net.named_parameters())
+        missing = set(lay.views) ^ set(params)
+        if missing:
+            raise RuntimeError(f"parameter set mismatch between module and layout: {sorted(missing)[:4]} ...")
+        dev = next(iter(params.values())).device
+        flat = torch.zeros(lay.numel, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for name, (off, shape, strides) in lay.views.items():
+                view = torch.as_strided(flat, shape, strides, off)
+                view.copy_(params[name].detach().to(torch.float32))
+                mod, attr = _resolve(net, name)
+                newp = torch.nn.Parameter(view, requires_grad=params[name].requires_grad)
+                mod._parameters[attr] = newp
+        self.flat = flat
+        self.flat_grad = None
+        self.shadow = None
+        self.dg.clear()
+        self.dg_lin = None
+        self._shadow_ver = -1
+        self._dg_ver.clear()
+
+    def is_attached(self, net) -> bool:
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        for name, (off, _, _) in self.layout.views.items():
+            mod, attr = _resolve(net, name)
+            p = mod._parameters[attr]
+            if p.dtype != torch.float32 or p.data_ptr() != base + 4 * off:
+                return False
+        return True
+
+    def ensure_grad_buffer(self, net=None, bind: bool = False) -> torch.Tensor:
+        """Flat fp32 gradient buffer (same offsets as the parameters).  With ``bind`` every Parameter's ``.grad`` becomes
+        a view into it, so optimizers / all-reduce see one contiguous tensor."""
+        if self.flat_grad is None:
+            self.flat_grad = torch.zeros_like(self.flat)
+        if bind and net is not None:
+            for name, (off, shape, strides) in self.layout.views.items():
+                mod, attr = _resolve(net, name)
+                mod._parameters[attr].grad = torch.as_strided(self.flat_grad, shape, strides, off)
+        return self.flat_grad
+
+    def _version(self):
+        return (self.flat._version, self._manual_ver)
+
+    def weights_changed(self, shadow_fresh: bool = False) -> None:
+        """Call after the flat buffer was rewritten through raw pointers (fused optimizer): torch's version counter
+        does not see those writes.  ``shadow_fresh``: the writer also refreshed the bf16 shadow."""
+        self._manual_ver += 1
+        if shadow_fresh and self.shadow is not None:
+            self._shadow_ver = self._version()
+
+    def _w(self, rec: ConvRec, dt: int) -> torch.Tensor:
+        if rec.lin or dt == DTYPE_F32:
+            return self.flat[rec.w_off:]
+        if self.shadow is None:
+            self.shadow = torch.empty(self.layout.numel, dtype=torch.bfloat16, device=self.flat.device)
+        if self._shadow_ver != self._version():
+            ops.cast_f32(self.flat, self.shadow, self.layout.numel, DTYPE_BF16)
+            self._shadow_ver = self._version()
+        return self.shadow[rec.w_off:]
+
+    def _b(self, rec: ConvRec) -> torch.Tensor:
+        return self.flat[rec.b_off:]
+
+    def _wT(self, rec: ConvRec, dt: int) -> torch.Tensor:
+        """Operand of the input-gradient GEMM for ``rec`` ([cin][taps][dg_ld]); rebuilt when the weights changed."""
+        lay = self.layout
+        key = "lin" if rec.lin else dt
+        if rec.lin:
+            if self.dg_lin is None:
+                self.dg_lin = torch.zeros(max(lay.dg_lin_numel, 1), dtype=torch.float32, device=self.flat.device)
+            buf, d = self.dg_lin, DTYPE_F32
+        else:
+            if dt not in self.dg:
+                self.dg[dt] = torch.zeros(max(lay.dg_numel, 1), dtype=TORCH_DTYPE[dt], device=self.flat.device)
+            buf, d = self.dg[dt], dt
+        if self._dg_ver.get(key, -1) != self._version():
+            for r in lay.convs.values():
+                if r.dg_off < 0 or r.lin != rec.lin:
+                    continue
+                ops.weight_transpose(self.flat[r.w_off:], buf[r.dg_off:], r.rows, r.taps, r.cin, r.kstride, r.dg_ld, r.flip, d)
+            self._dg_ver[key] = self._version()
+        return buf[rec.dg_off:]
+
+    def _gw(self, rec: ConvRec) -> torch.Tensor:
+        return self.flat_grad[rec.w_off:]
+
+    def _gb(self, rec: ConvRec) -> torch.Tensor:
+        return self.flat_grad[rec.b_off:]
+
+    # ------------------------------------------------------------------ small helpers
+    @staticmethod
+    def _geom(B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows, mode):
+        return dict(B=B, Hin=Hin, Win=Win, Cin=Cin, Hout=Hout, Wout=Wout, Cout=Cout, ldy=ldy, wrows=wrows, mode=mode)
+
+    def _linear(self, name: str, x: torch.Tensor, rows: int, act: int, tape: Optional[Tape], need_dx: bool = True) -> torch.Tensor:
+        """fp32 GEMM  y[rows_x][out] = x . W^T + b  on the fp32 matrix-core path (Linear layers of model/score.py:56-57,
+        model/nn.py:149)."""
+        rec = self.layout.convs[name]
+        y = torch.empty((rows, rec.rows), dtype=torch.float32, device=x.device)
+        g = self._geom(rows, 1, 1, rec.kstride, 1, 1, rec.rows, rec.rows, rec.rows, CONV_1X1)
+        ops.conv(x, self._w(rec, DTYPE_F32), self._b(rec), y, g, DTYPE_F32, act=act)
+        if tape is not None:
+            def bw(gy: torch.Tensor) -> Optional[torch.Tensor]:
+                ops.colsum(gy, self._gb(rec), rows, rec.rows, rec.rows, DTYPE_F32)
+                ops.conv_wgrad(x, gy, self._gw(rec), g, DTYPE_F32)
+                if not need_dx:
+                    return None
+                dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
+                gd = self._geom(rows, 1, 1, rec.dg_ld, 1, 1, rec.cin, rec.cin, rec.cin, CONV_1X1)
+                ops.conv(gy, self._wT(rec, DTYPE_F32), None, dx, gd, DTYPE_F32)
+                return dx
+            tape.steps.append(bw)
+        return y
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, t: torch.Tensor, dt: int, tape: Optional[Tape] = None, noise: Optional[Tuple] = None,
+                want_dx: bool = False, nhwc_out: bool = False):
+        """eps_pred = ScoreUNet(x, t).  x: (B,C,H,W) fp32 on the GPU; t: numel 1 or B.
+        noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion.
+        With ``tape`` every op records its backward closure (training / exact guidance)."""
+        lay = self.layout
+        T = TORCH_DTYPE[dt]
+        dev = x.device
+        B, C, H, W = x.shape
+        L = len(lay.levels)
+        if C != lay.in_channels:
+            raise ValueError(f"expected {lay.in_channels} channels, got {C}")
+        if H % (1 << (L - 1)) or W % (1 << (L - 1)):
+            raise ValueError("spatial size must be divisible by 2**(levels-1) (skip connections, model/nn.py:238)")
+        ck = ops.CK[dt]
+        for lv in lay.levels:
+            if lv.channels % ck:
+                raise ValueError(f"hidden_channels must be multiples of {ck} for this compute dtype")
+        train = tape is not None
+        x = x.contiguous().float()
+        tt = t.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        Bt = tt.numel()
+        if Bt not in (1, B):
+            raise ValueError("t must hold 1 or B values (model/score.py:60)")
+        ldm = lay.sum_c if (Bt == B and B > 1) else 0
+
+        # ---- time embedding MLP + all modulation vectors (fp32)
+        pe = torch.empty((Bt, lay.noise_features), dtype=torch.float32, device=dev)
+        ops.timestep_embedding(tt, pe, Bt, lay.noise_features)
+        emb = self._mlp_layer("map_layer0", pe, Bt, tape, need_dx=False)
+        emb = self._mlp_layer("map_layer1", emb, Bt, tape)
+        m_all = self._linear("proj", emb, Bt, ACT_NONE, tape)
+        if train:
+            dm_all = torch.zeros_like(m_all)
+            tape.meta["dm_all"] = dm_all
+        else:
+            dm_all = None
+
+        # ---- network input -> NHWC
+        x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
+        ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
+
+        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None):
+            rec = lay.convs[name]
+            ldy_ = ldy or rec.rows
+            y = torch.empty((B * Ho * Wo, ldy_), dtype=T, device=dev)
+            g = self._geom(B, Hi, Wi, rec.kstride, Ho, Wo, cout or rec.rows, ldy_, rec.rows, mode)
+            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res)
+            return y, g, rec
+
+        def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None):
+            """input gradient = implicit GEMM over gy with the transposed (and flipped) weights; (Hi,Wi) = gy's grid"""
+            dx = torch.empty((B * Ho * Wo, ld_out), dtype=T, device=dev)
+            g = self._geom(B, Hi, Wi, rec.dg_ld, Ho, Wo, ld_out, ld_out, rec.cin, mode)
+            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=MUL_DSILU)
+            return dx
+
+        def res_block(b: BlockSpec, xin, Hc, Wc):
+            p = "unet." + b.key
+            Cc = b.channels
+            npix = B * Hc * Wc
+            m = m_all.view(-1)[b.mod_offset:]
+            h0 = torch.empty((npix, Cc), dtype=T, device=dev)
+            ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
+            a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE if train else ACT_SILU)
+            if train:
+                h1 = torch.empty_like(a1)
+                ops.silu(a1, h1, a1.numel(), dt)
+            else:
+                h1 = a1
+            out, g2, r2 = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin)
+            if train:
+                def bw(gy):
+                    ops.colsum(gy, self._gb(r2), npix, Cc, Cc, dt)
+                    ops.conv_wgrad(h1, gy, self._gw(r2), g2, dt)
+                    da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=a1)
+                    ops.colsum(da1, self._gb(r1), npix, Cc, Cc, dt)
+                    ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt)
+                    dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
+                    dx = torch.empty_like(dh0)
+                    ops.ln_backward(dh0, xin, m, gy, dx, dm_all.view(-1)[b.mod_offset:], npix, Hc * Wc, Cc, ldm, LN_EPS,
+                                    self.ln_unbiased, dt)
+                    return dx
+                tape.steps.append(bw)
+            return out
+
+        def attn_block(b: BlockSpec, xin, Hc, Wc):
+            p = "unet." + b.key
+            Cc = b.channels
+            Tn = Hc * Wc
+            npix = B * Tn
+            rq, rp = lay.convs[p + ".qkv"], lay.convs[p + ".proj_out"]
+            hl = torch.empty((npix, Cc), dtype=T, device=dev)
+            ops.ln_forward(xin, None, hl, npix, Tn, Cc, 0, LN_EPS, self.ln_unbiased, dt)
+            qkv = torch.empty((npix, 3 * Cc), dtype=T, device=dev)
+            gq = self._geom(npix, 1, 1, Cc, 1, 1, 3 * Cc, 3 * Cc, 3 * Cc, CONV_1X1)
+            ops.conv(hl, self._w(rq, dt), self._b(rq), qkv, gq, dt)
+            o = torch.empty((npix, Cc), dtype=T, device=dev)
+            lse = torch.empty((npix,), dtype=torch.float32, device=dev) if train else None
+            ops.attention_forward(qkv, o, lse, B, Tn, Cc, dt)
+            out = torch.empty((npix, Cc), dtype=T, device=dev)
+            gp = self._geom(npix, 1, 1, Cc, 1, 1, Cc, Cc, Cc, CONV_1X1)
+            ops.conv(o, self._w(rp, dt), self._b(rp), out, gp, dt, res=xin)
+            if train:
+                def bw(gy):
+                    ops.colsum(gy, self._gb(rp), npix, Cc, Cc, dt)
+                    ops.conv_wgrad(o, gy, self._gw(rp), gp, dt)
+                    do = torch.empty((npix, Cc), dtype=T, device=dev)
+                    ops.conv(gy, self._wT(rp, dt), None, do, self._geom(npix, 1, 1, Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
+                    dqkv = torch.empty_like(qkv)
+                    delta = torch.empty((npix,), dtype=torch.float32, device=dev)
+                    ops.attention_backward(qkv, o, do, lse, delta, dqkv, B, Tn, Cc, dt)
+                    ops.colsum(dqkv, self._gb(rq), npix, 3 * Cc, 3 * Cc, dt)
+                    ops.conv_wgrad(hl, dqkv, self._gw(rq), gq, dt)
+                    dhl = torch.empty((npix, Cc), dtype=T, device=dev)
+                    ops.conv(dqkv, self._wT(rq, dt), None, dhl, self._geom(npix, 1, 1, 3 * Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
+                    dx = torch.empty_like(dhl)
+                    ops.ln_backward(dhl, xin, None, gy, dx, None, npix, Tn, Cc, 0, LN_EPS, self.ln_unbiased, dt)
+                    return dx
+                tape.steps.append(bw)
+            return out
+
+        # ---- descent
+        Hc, Wc = H, W
+        lv0 = lay.levels[0]
+        cur, g_h0, r_h0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1)
+        if train:
+            def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
+                ops.colsum(gy, self._gb(rec), B * H * W, rec.rows, rec.rows, dt)
+                ops.conv_wgrad(x0, gy, self._gw(rec), g, dt)
+                if not want_dx:
+                    return None
+                return dgrad(rec, gy, H, W, H, W, CONV_S1, lay.cin_pad)
+            tape.steps.append(bw_head0)
+        skips: List[torch.Tensor] = []
+        for i, lv in enumerate(lay.levels):
+            if i > 0:
+                xin = cur
+                Hp, Wp = Hc, Wc
+                Hc, Wc = Hc // 2, Wc // 2
+                cur, g_h, r_h = conv3("unet." + lv.head_key, xin, Hp, Wp, Hc, Wc, CONV_S2)
+                if train:
+                    def bw_head(gy, xin=xin, g=g_h, rec=r_h, Hp=Hp, Wp=Wp, Hc=Hc, Wc=Wc, lvl=i - 1):
+                        ops.colsum(gy, self._gb(rec), B * Hc * Wc, rec.rows, rec.rows, dt)
+                        ops.conv_wgrad(xin, gy, self._gw(rec), g, dt)
+                        # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
+                        return dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
+                    tape.steps.append(bw_head)
+            for b in lv.descent:
+                cur = res_block(b, cur, Hc, Wc) if b.kind == "res" else attn_block(b, cur, Hc, Wc)
+            if i < L - 1:
+                skips.append(cur)
+        # ---- ascent
+        for i in reversed(range(L)):
+            lv = lay.levels[i]
+            for b in lv.ascent:
+                cur = res_block(b, cur, Hc, Wc) if b.kind == "res" else attn_block(b, cur, Hc, Wc)
+            if i > 0:
+                xin = cur
+                Cc = lv.channels
+                npix = B * Hc * Wc
+                hl = torch.empty((npix, Cc), dtype=T, device=dev)
+                ops.ln_forward(xin, None, hl, npix, Hc * Wc, Cc, 0, LN_EPS, self.ln_unbiased, dt)
+                Hl, Wl = Hc, Wc
+                Hc, Wc = Hc * 2, Wc * 2
+                cur, g_t, r_t = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop())
+                if train:
+                    def bw_tail(gy, xin=xin, hl=hl, g=g_t, rec=r_t, Hl=Hl, Wl=Wl, Hu=Hc, Wu=Wc, Cc=Cc, lvl=i - 1):
+                        tape.gskip[lvl] = gy  # the skip operand receives the same gradient
+                        ops.colsum(gy, self._gb(rec), B * Hu * Wu, rec.rows, rec.rows, dt)
+                        ops.conv_wgrad(hl, gy, self._gw(rec), g, dt)
+                        gu = dgrad(rec, gy, Hu, Wu, Hu, Wu, CONV_S1, Cc)  # gradient w.r.t. the upsampled map
+                        gl = torch.empty((B * Hl * Wl, Cc), dtype=T, device=dev)
+                        ops.sumpool2(gu, gl, B, Hl, Wl, Cc, dt)
+                        dx = torch.empty_like(gl)
+                        ops.ln_backward(gl, xin, None, None, dx, None, B * Hl * Wl, Hl * Wl, Cc, 0, LN_EPS, self.ln_unbiased, dt)
+                        return dx
+                    tape.steps.append(bw_tail)
+            else:
+                xin = cur
+                cur, g_t, r_t = conv3("unet." + lv.tail_key, xin, Hc, Wc, Hc, Wc, CONV_S1, ldy=lay.cout_pad, cout=lay.cout_pad)
+                if train:
+                    def bw_tail0(gy, xin=xin, g=g_t, rec=r_t, Hc=Hc, Wc=Wc, Cc=lv.channels):
+                        ops.colsum(gy, self._gb(rec), B * Hc * Wc, lay.cout_pad, lay.cout_pad, dt)
+                        gw = dict(g)
+                        gw["Cout"] = rec.rows
+                        ops.conv_wgrad(xin, gy, self._gw(rec), gw, dt)
+                        return dgrad(rec, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc)
+                    tape.steps.append(bw_tail0)
+        if train:
+            tape.meta.update(B=B, C=C, H=H, W=W, dt=dt, out_nhwc=cur, ldm=ldm, Bt=Bt)
+        if nhwc_out:
+            return cur
+        y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(cur, y, B, lay.out_channels, H * W, lay.cout_pad, dt)
+        return y
+
+    def _mlp_layer(self, name: str, x: torch.Tensor, rows: int, tape: Optional[Tape], need_dx: bool = True) -> torch.Tensor:
+        """silu(Linear(x)) of the time-embedding MLP (model/score.py:62-67); keeps the pre-activation when taping."""
+        if tape is None:
+            return self._linear(name, x, rows, ACT_SILU, None)
+        z = self._linear(name, x, rows, ACT_NONE, None)
+        h = torch.empty_like(z)
+        ops.silu(z, h, z.numel(), DTYPE_F32)
+        rec = self.layout.convs[name]
+        g = self._geom(rows, 1, 1, rec.kstride, 1, 1, rec.rows, rec.rows, rec.rows, CONV_1X1)
+
+        def bw(gh: torch.Tensor) -> Optional[torch.Tensor]:
+            gz = torch.empty_like(z)
+            ops.silu_backward(z, gh, gz, z.numel(), DTYPE_F32)
+            ops.colsum(gz, self._gb(rec), rows, rec.rows, rec.rows, DTYPE_F32)
+            ops.conv_wgrad(x, gz, self._gw(rec), g, DTYPE_F32)
+            if not need_dx:
+                return None
+            dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
+            ops.conv(gz, self._wT(rec, DTYPE_F32), None, dx, self._geom(rows, 1, 1, rec.dg_ld, 1, 1, rec.cin, rec.cin, rec.cin, CONV_1X1),
+                     DTYPE_F32)
+            return dx
+        tape.steps.append(bw)
+        return h
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool = False) -> Optional[torch.Tensor]:
+        """Run the recorded closures in reverse.  ``gy_nhwc``: gradient w.r.t. the network output in NHWC rows
+        [B*H*W][cout_pad] (padding channels zero).  Parameter gradients are ACCUMULATED into ``flat_grad``."""
+        if self.flat_grad is None:
+            raise RuntimeError("call ensure_grad_buffer() before backward")
+        steps = tape.steps
+        n_mlp = 3  # map_layer0, map_layer1, proj were recorded first
+        g = gy_nhwc
+        for bw in reversed(steps[n_mlp:]):
+            g = bw(g)
+        dx0 = g
+        # modulation path: dm_all -> proj -> map_layer1 -> map_layer0
+        gm = tape.meta["dm_all"]
+        for bw in reversed(steps[:n_mlp]):
+            gm = bw(gm)
+        tape.steps = []
+        tape.gskip.clear()
+        if not want_dx or dx0 is None:
+            return None
+        m = tape.meta
+        dx = torch.empty((m["B"], m["C"], m["H"], m["W"]), dtype=torch.float32, device=dx0.device)
+        ops.nhwc_to_nchw(dx0, dx, m["B"], m["C"], m["H"] * m["W"], self.layout.cin_pad, m["dt"])
+        return dx
+
+
+def _resolve(net, name: str):
+    parts = name.split(".")
+    mod = net
+    for p in parts[:-1]:
+        mod = getattr(mod, p) if not p.isdigit() else mod[int(p)]
+    return mod, parts[-1]

@@ -1,0 +1,117 @@
+"""Tensor-level launchers: one Python function per C-ABI entry point of libc2w_hip.so.
+
+Every function takes torch tensors that already live on the GPU (torch is the allocator and the stream
+provider, nothing more), hands their device pointers to the HIP library and enqueues on torch's current
+stream.  There is no fallback: a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_SILU, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F32, MUL_DSILU,  # noqa: F401
+                   MUL_PLAIN, ConvArgs, check)
+
+TORCH_DTYPE = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
+ESZ = {DTYPE_F32: 4, DTYPE_BF16: 2}
+CK = {DTYPE_F32: 32, DTYPE_BF16: 64}  # channels per 128-byte K chunk
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.C2wError("climate2weather_amd kernels need GPU tensors (no CPU fallback in the product path)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv_args(x, w, bias, res, mul, y, g, act, mulmode) -> ConvArgs:
+    return ConvArgs(_p(x), _p(w), _p(bias), _p(res), _p(mul), _p(y), g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"],
+                    g["Cout"], g["ldy"], g["wrows"], g["mode"], act, mulmode)
+
+
+def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive: bool = False):
+    """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode)."""
+    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode)
+    check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")
+
+
+def conv_wgrad(x, dy, dw, g: dict, dtype: int):
+    a = _conv_args(x, None, None, None, None, dy, g, 0, 0)
+    a.w = None
+    check(_lib.load().c2w_conv_wgrad(ctypes.byref(a), _p(dw), dtype, _stream()), "c2w_conv_wgrad")
+
+
+def ln_forward(x, m, y, npix, HW, C, ldm, eps, unbiased, dtype):
+    check(_lib.load().c2w_ln_forward(_p(x), _p(m), _p(y), npix, HW, C, ldm, eps, int(unbiased), dtype, _stream()), "c2w_ln_forward")
+
+
+def ln_backward(dy, x, m, dres, dx, dm, npix, HW, C, ldm, eps, unbiased, dtype):
+    check(_lib.load().c2w_ln_backward(_p(dy), _p(x), _p(m), _p(dres), _p(dx), _p(dm), npix, HW, C, ldm, eps, int(unbiased), dtype,
+                                      _stream()), "c2w_ln_backward")
+
+
+def colsum(a, out, rows, C, lda, dtype):
+    check(_lib.load().c2w_colsum(_p(a), _p(out), rows, C, lda, dtype, _stream()), "c2w_colsum")
+
+
+def silu(x, y, n, dtype):
+    check(_lib.load().c2w_silu(_p(x), _p(y), n, dtype, _stream()), "c2w_silu")
+
+
+def silu_backward(x, dy, dx, n, dtype):
+    check(_lib.load().c2w_silu_backward(_p(x), _p(dy), _p(dx), n, dtype, _stream()), "c2w_silu_backward")
+
+
+def sumpool2(g, dx, B, H, W, C, dtype):
+    check(_lib.load().c2w_sumpool2(_p(g), _p(dx), B, H, W, C, dtype, _stream()), "c2w_sumpool2")
+
+
+def nchw_to_nhwc(x, eps, musig, y, B, C, HW, ldc, dtype):
+    check(_lib.load().c2w_nchw_to_nhwc(_p(x), _p(eps), _p(musig), _p(y), B, C, HW, ldc, dtype, _stream()), "c2w_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(y, out, B, C, HW, ldc, dtype):
+    check(_lib.load().c2w_nhwc_to_nchw(_p(y), _p(out), B, C, HW, ldc, dtype, _stream()), "c2w_nhwc_to_nchw")
+
+
+def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype):
+    check(_lib.load().c2w_mse_loss_grad(_p(y), _p(eps), _p(dy), _p(loss_sum), B, C, HW, ldc, gscale, dtype, _stream()),
+          "c2w_mse_loss_grad")
+
+
+def timestep_embedding(t, out, n, dim, max_period=10000.0):
+    check(_lib.load().c2w_timestep_embedding(_p(t), _p(out), n, dim, max_period, _stream()), "c2w_timestep_embedding")
+
+
+def mu_sigma(t, musig, n, eta):
+    check(_lib.load().c2w_mu_sigma(_p(t), _p(musig), n, eta, _stream()), "c2w_mu_sigma")
+
+
+def cast_f32(src, dst, n, dtype):
+    check(_lib.load().c2w_cast_f32(_p(src), _p(dst), n, dtype, _stream()), "c2w_cast_f32")
+
+
+def weight_transpose(w, out, R, NT, K, ldk, ldr, flip, dtype):
+    check(_lib.load().c2w_weight_transpose(_p(w), _p(out), R, NT, K, ldk, ldr, int(flip), dtype, _stream()), "c2w_weight_transpose")
+
+
+def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale):
+    check(_lib.load().c2w_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(shadow), n, lr, beta1, beta2, eps, weight_decay, step,
+                                    ema_rate, grad_scale, _stream()), "c2w_adamw_ema")
+
+
+def attention_forward(qkv, o, lse, B, T, C, dtype):
+    check(_lib.load().c2w_attention_forward(_p(qkv), _p(o), _p(lse), B, T, C, dtype, _stream()), "c2w_attention_forward")
+
+
+def attention_backward(qkv, o, d_o, lse, delta_ws, dqkv, B, T, C, dtype):
+    check(_lib.load().c2w_attention_backward(_p(qkv), _p(o), _p(d_o), _p(lse), _p(delta_ws), _p(dqkv), B, T, C, dtype, _stream()),
+          "c2w_attention_backward")

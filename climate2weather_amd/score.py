@@ -1,0 +1,167 @@
+"""Drop-in for the reference's ``model.score.ScoreUNet`` (model/score.py:37-70).
+
+Point ``network_kwargs.class_name`` (train.py:164-173, util.py:117-127) at
+``climate2weather_amd.score.ScoreUNet`` and the reference's drivers get the MI355X engine: same constructor
+keywords, same 228 state_dict keys and creation-order initialisation, same ``forward(x, t, forcing=None)``.
+
+Precision follows the caller the way the reference's modules do: fp32 arithmetic unless ``torch.autocast`` is
+active (the reference hard-codes Fabric ``precision="16-mixed"``, train.py:98), in which case the bf16 MFMA
+path runs.  ``net.precision = "fp32" | "bf16"`` pins it.
+"""
+from __future__ import annotations
+
+import itertools
+import weakref
+from typing import Optional
+
+import torch
+
+from .engine import Engine, Tape
+from .nn import UNet
+from .ops import DTYPE_BF16, DTYPE_F32, TORCH_DTYPE
+
+
+def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    """model/score.py:14-34 on the GPU (HIP kernel); ``timesteps`` 1-D."""
+    from . import ops
+    t = timesteps.reshape(-1).float().contiguous()
+    out = torch.empty((t.numel(), dim), dtype=torch.float32, device=t.device)
+    ops.timestep_embedding(t, out, t.numel(), dim, max_period)
+    return out.to(timesteps.dtype)
+
+
+_TAPES = {}
+_tape_ids = itertools.count()
+
+
+class _ScoreUNetFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward and backward are the engine's hand-written HIP sequences.
+    New-style (setup_context) so ``torch.func.jacrev`` / ``vjp`` can drive it (src/thor/score.py:28-33)."""
+
+    @staticmethod
+    def forward(x, t, net, dt, *params):
+        eng = net._get_engine()
+        tape = Tape()
+        y = eng.forward(x, t, dt, tape=tape, want_dx=True)
+        key = next(_tape_ids)
+        _TAPES[key] = tape
+        return y, key
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, t, net, dt = inputs[:4]
+        ctx.net = net
+        key = output[1]
+        ctx.tape = _TAPES[key]
+        weakref.finalize(ctx, _TAPES.pop, key, None)
+        ctx.x_needs_grad = x.requires_grad
+        ctx.set_materialize_grads(False)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy, _gkey=None):
+        from . import ops
+        net = ctx.net
+        eng: Engine = net._get_engine()
+        lay = eng.layout
+        tape = ctx.tape
+        m = tape.meta
+        n_params = len(lay.views)
+        if gy is None:
+            return (None, None, None, None) + (None,) * n_params
+        # gradients of this call only: use a private flat buffer so autograd's accumulation semantics hold
+        saved = eng.flat_grad
+        eng.flat_grad = torch.zeros_like(eng.flat)
+        try:
+            dt = m["dt"]
+            gy = gy.contiguous().float()
+            g_nhwc = torch.empty((m["B"] * m["H"] * m["W"], lay.cout_pad), dtype=TORCH_DTYPE[dt], device=gy.device)
+            ops.nchw_to_nhwc(gy, None, None, g_nhwc, m["B"], m["C"], m["H"] * m["W"], lay.cout_pad, dt)
+            dx = eng.backward(tape, g_nhwc, want_dx=ctx.x_needs_grad)
+            fg = eng.flat_grad
+        finally:
+            eng.flat_grad = saved
+        grads = tuple(torch.as_strided(fg, shape, strides, off) for (off, shape, strides) in lay.views.values())
+        return (dx, None, None, None) + grads
+
+
+class ScoreUNet(torch.nn.Module):
+    r"""U-Net score network on the MI355X engine.
+
+    Arguments (as model/score.py:46): channels, embedding_dim, forcing_dim=0, **UNet kwargs
+    (hidden_channels, hidden_blocks, attention_levels, kernel_size, activation, spatial, padding_mode).
+    """
+
+    def __init__(self, channels, embedding_dim, forcing_dim=0, **kwargs):
+        super().__init__()
+        if forcing_dim > 0:
+            raise NotImplementedError("forcing is never passed by the reference's callers (SURVEY.md a2)")
+        self.map_forcing = None
+        self.embedding_dim = embedding_dim
+        self.noise_features = 32
+        self.unet = UNet(channels, channels, embedding_dim, **kwargs)
+        self.map_layer0 = torch.nn.Linear(self.noise_features, embedding_dim)
+        self.map_layer1 = torch.nn.Linear(embedding_dim, embedding_dim)
+        self.precision = "auto"  # "auto" (bf16 under torch.autocast, else fp32) | "fp32" | "bf16"
+        self.ln_unbiased = True  # zuko.nn.LayerNorm uses torch.var_mean's default; see oracle/_shim/zuko/nn.py
+        self.__dict__["_engine"] = None
+
+    # ---- engine plumbing (kept out of state_dict / pickles / deep copies)
+    def _get_engine(self) -> Engine:
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = Engine(self)
+            self.__dict__["_engine"] = eng
+        elif not eng.is_attached(self):
+            eng.attach(self)  # parameters were replaced (.to(device), load via assign, dtype cast): re-flatten
+        return eng
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__["_engine"] = None
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+        return new
+
+    def compute_dtype(self) -> int:
+        if self.precision == "fp32":
+            return DTYPE_F32
+        if self.precision == "bf16":
+            return DTYPE_BF16
+        return DTYPE_BF16 if torch.is_autocast_enabled() else DTYPE_F32
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, forcing: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert forcing is None, "forcing_dim == 0"
+        eng = self._get_engine()
+        dt = self.compute_dtype()
+        params = [p for _, p in self._ordered_params(eng)]
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        shape = x.shape
+        x4 = x.reshape(-1, *shape[-3:]) if x.dim() != 4 else x
+        if needs_grad or _in_functorch_transform(x):
+            y, _ = _ScoreUNetFn.apply(x4, t, self, dt, *params)
+        else:
+            y = eng.forward(x4, t, dt)
+        return y.reshape(shape).to(x.dtype)
+
+    def _ordered_params(self, eng: Engine):
+        named = dict(self.named_parameters())
+        return [(k, named[k]) for k in eng.layout.views]
+
+
+def _in_functorch_transform(x: torch.Tensor) -> bool:
+    try:
+        return torch._C._functorch.is_functorch_wrapped_tensor(x)
+    except Exception:  # pragma: no cover
+        return False

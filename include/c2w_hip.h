@@ -1,0 +1,118 @@
+/* c2w_hip.h -- C ABI of libc2w_hip.so, the MI355X (gfx950) kernel library under
+ * climate2weather_amd.
+ *
+ * The reference (schmidtjonathan/Climate2Weather) is pure Python and has no FFI:
+ * its hot path dispatches torch ops.  Each entry point below names
+ * the reference call sites whose arithmetic it replaces.  Conventions:
+ *   - caller owns every buffer (device pointers from the caller's allocator); nothing is
+ *     allocated, freed or synchronised inside; work is enqueued on `stream` (a hipStream_t);
+ *   - activations are NHWC: [B][H][W][ld] with `ld` the channel stride in elements;
+ *   - `dtype` selects the storage/MFMA-operand type: C2W_DTYPE_F32 (exact fp32 matrix-core
+ *     path, the <=1e-4 parity mode) or C2W_DTYPE_BF16 (throughput mode); accumulation and all
+ *     pointwise math are fp32 in both;
+ *   - return value: 0 on success, a positive hipError_t, or a negative C2W_ERR_* code.
+ *     Nothing throws across this boundary.
+ */
+#ifndef C2W_HIP_H
+#define C2W_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { C2W_DTYPE_F32 = 0, C2W_DTYPE_BF16 = 1 };
+enum { C2W_ERR_BAD_ARG = -1, C2W_ERR_BAD_SHAPE = -2, C2W_ERR_UNSUPPORTED = -3 };
+
+/* geometry of the implicit GEMM */
+enum {
+    C2W_CONV_1X1 = 0, /* Linear / Conv1d(k=1): model/nn.py:45,47,149; model/score.py:56-57 */
+    C2W_CONV_S1 = 1,  /* Conv2d 3x3 stride 1 pad 1: model/nn.py:155,157,193-194 (and its dgrad with flipped weights) */
+    C2W_CONV_S2 = 2,  /* Conv2d 3x3 stride 2 pad 1: model/nn.py:169-174 */
+    C2W_CONV_UP = 3,  /* Upsample(nearest,x2) -> Conv2d 3x3: model/nn.py:184-189, upsample folded into the gather */
+    C2W_CONV_TS2 = 4  /* input-gradient of C2W_CONV_S2 (x := dy, y := dx) */
+};
+enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1 };
+enum { C2W_MUL_PLAIN = 0, C2W_MUL_DSILU = 1 };
+
+/* y[q][co] = act( sum_{tap,ci} w[co][tap][ci] * x[src(q,tap)][ci] + bias[co] ) (* mul' ) (+ res)
+ * q runs over the B*Hout*Wout output pixels in NHWC raster order. */
+typedef struct C2wConvArgs {
+    const void* x;     /* [B][Hin][Win][Cin]  (Cin = channel stride; multiple of 32 (f32) / 64 (bf16)) */
+    const void* w;     /* [wrows][taps][Cin], taps = 1 or 9 (kh*3+kw); rows >= wrows read as zero */
+    const float* bias; /* [wrows] fp32 or NULL */
+    const void* res;   /* [B*Hout*Wout][ldy] added last, or NULL   (residual / skip: model/nn.py:28,238) */
+    const void* mul;   /* [B*Hout*Wout][ldy] or NULL: y *= mul (C2W_MUL_PLAIN) or y *= silu'(mul) (C2W_MUL_DSILU) */
+    void* y;           /* [B*Hout*Wout][ldy] */
+    int32_t B, Hin, Win, Cin;
+    int32_t Hout, Wout, Cout, ldy;
+    int32_t wrows;
+    int32_t mode;    /* C2W_CONV_* */
+    int32_t act;     /* C2W_ACT_* */
+    int32_t mulmode; /* C2W_MUL_* */
+} C2wConvArgs;
+
+/* naive != 0 runs a one-thread-per-output direct convolution with identical semantics
+ * (debug cross-check of the MFMA kernel; never used by the product path). */
+int c2w_conv_forward(const C2wConvArgs* args, int dtype, int naive, void* stream);
+
+/* dW[co][tap][ci] (fp32) += sum_q dY[q][co] * x[src(q,tap)][ci]  -- weight gradient of the same geometry.
+ * Pass the forward call's block with y := dY; w/bias/res/mul/act are ignored.  Split-K over pixels across
+ * workgroups, combined with fp32 atomics: zero dw (or leave the value to accumulate onto) beforehand.
+ * Replaces autograd's weight backward of every Conv2d/Conv1d/Linear cited above. */
+int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, int dtype, void* stream);
+
+/* y = LN_C(x + m[b]): parameter-free channel LayerNorm (zuko.nn.LayerNorm at model/nn.py:44,154,183) fused with
+ * the time-modulation add of model/nn.py:28.  x,y: [npix][C]; m: fp32 rows of C (row b = pixel / HW, stride ldm;
+ * ldm == 0 -> one row shared by every pixel; m == NULL -> no add).  unbiased selects the N-1 variance. */
+int c2w_ln_forward(const void* x, const float* m, void* y, long long npix, int HW, int C, int ldm, float eps,
+                   int unbiased, int dtype, void* stream);
+/* dx = dres + dLN(dy; x+m);  dm[b][c] += sum over the image's pixels of the LN part (fp32 atomics; dm may be NULL). */
+int c2w_ln_backward(const void* dy, const void* x, const float* m, const void* dres, void* dx, float* dm,
+                    long long npix, int HW, int C, int ldm, float eps, int unbiased, int dtype, void* stream);
+
+/* out[c] += sum_rows a[row][c]   (bias gradients; fp32 atomics) */
+int c2w_colsum(const void* a, float* out, long long rows, int C, int lda, int dtype, void* stream);
+/* y = silu(x) ; dx = dy * silu'(x)   (the activation train.py:171 passes; model/nn.py:156, model/score.py:63,67) */
+int c2w_silu(const void* x, void* y, long long n, int dtype, void* stream);
+int c2w_silu_backward(const void* x, const void* dy, void* dx, long long n, int dtype, void* stream);
+/* adjoint of Upsample(nearest, x2) (model/nn.py:184): dx[b][h][w] = sum of the 2x2 block of g ([B][2H][2W][C]) */
+int c2w_sumpool2(const void* g, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+
+/* NCHW fp32 <-> NHWC (padded to ldc channels).  With eps != NULL the forward noise process of
+ * src/thor/pipelines.py:22-25 is fused: y = mu[b] x + sigma[b] eps, musig = {mu_0, sigma_0, mu_1, ...}. */
+int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* musig, void* y, int B, int C, int HW, int ldc,
+                     int dtype, void* stream);
+int c2w_nhwc_to_nchw(const void* y, float* out, int B, int C, int HW, int ldc, int dtype, void* stream);
+/* loss tail (src/thor/pipelines.py:35, training_loop.py:377): loss_sum += sum (y-eps)^2 ; dy = (y-eps) * gscale */
+int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
+                      float gscale, int dtype, void* stream);
+/* model/score.py:14-34 */
+int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream);
+/* src/thor/pipelines.py:13-20: musig[i] = {mu(t_i), sigma(t_i)} */
+int c2w_mu_sigma(const float* t, float* musig, int n, float eta, void* stream);
+int c2w_cast_f32(const float* in, void* out, long long n, int dtype, void* stream);
+/* w[r][tap][k] (fp32, k-stride ldk) -> out[k][tap'][r] (dtype, r-stride ldr), taps reversed when flip: the operand of the
+ * input-gradient convolution (dgrad = the same implicit GEMM over dy with these weights). */
+int c2w_weight_transpose(const float* w, void* out, int R, int NT, int K, int ldk, int ldr, int flip, int dtype,
+                         void* stream);
+/* fused torch.optim.AdamW step (train.py:176-181) + EMA (src/thor/ema.py:23-27) + bf16 shadow refresh over a flat
+ * parameter buffer; ema / shadow_bf16 may be NULL; g is multiplied by grad_scale first. */
+int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float ema_rate, float grad_scale,
+                  void* stream);
+
+/* QKVAttention, one head (model/nn.py:62-85).  qkv: [B][T][3C] (q|k|v), o: [B][T][C], lse: [B][T] fp32 (may be NULL
+ * for inference).  backward recomputes probabilities from lse; delta_ws is a [B][T] fp32 scratch. */
+int c2w_attention_forward(const void* qkv, void* o, float* lse, int B, int T, int C, int dtype, void* stream);
+int c2w_attention_backward(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
+                           int B, int T, int C, int dtype, void* stream);
+
+/* library identity: returns the gfx target string the kernels were compiled for ("gfx950") */
+const char* c2w_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C2W_HIP_H */

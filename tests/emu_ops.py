@@ -1,0 +1,241 @@
+"""TEST DOUBLE for climate2weather_amd.ops: every launcher re-stated with plain PyTorch ops on the same buffers.
+
+Two uses, both inside tests/ only:
+  * CPU (`-m "not gpu"`): monkeypatched over `climate2weather_amd.ops` so the engine's orchestration (buffer wiring,
+    flat parameter layout, the hand-written backward tape, the sampler) is checked against the oracle without a GPU;
+  * GPU (`-m gpu`): the per-kernel "plain PyTorch fp32 reference of the same op" each HIP kernel is compared with.
+The product never imports this module.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SILU = 0, 1
+MUL_PLAIN, MUL_DSILU = 0, 1
+TD = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
+
+
+def _rows(t, n, ld):
+    return t.reshape(-1)[: n * ld].view(n, ld)
+
+
+def _dsilu(a):
+    s = torch.sigmoid(a)
+    return s * (1 + a * (1 - s))
+
+
+def _conv_core(X, Wt, g):
+    """X: (B,Cin,Hin,Win) fp32; Wt: (rows,taps,Cin) fp32 -> (B,rows,Hout,Wout)"""
+    mode = g["mode"]
+    rows = Wt.shape[0]
+    if mode == CONV_1X1:
+        return torch.einsum("bchw,oc->bohw", X, Wt[:, 0])
+    W4 = Wt.view(rows, 3, 3, -1).permute(0, 3, 1, 2)
+    if mode == CONV_S1:
+        return F.conv2d(X, W4, padding=1)
+    if mode == CONV_S2:
+        return F.conv2d(X, W4, stride=2, padding=1)
+    if mode == CONV_UP:
+        return F.conv2d(F.interpolate(X, scale_factor=2.0, mode="nearest"), W4, padding=1)
+    if mode == CONV_TS2:
+        op = (g["Hout"] - (2 * g["Hin"] - 1), g["Wout"] - (2 * g["Win"] - 1))
+        return F.conv_transpose2d(X, W4.permute(1, 0, 2, 3), stride=2, padding=1, output_padding=op)
+    raise ValueError(mode)
+
+
+def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False):
+    B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows = (g[k] for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ldy", "wrows"))
+    taps = 1 if g["mode"] == CONV_1X1 else 9
+    T = TD[dtype]
+    X = _rows(x, B * Hin * Win, Cin).view(B, Hin, Win, Cin).float().permute(0, 3, 1, 2)
+    rows = min(wrows, Cout)
+    Wt = w.reshape(-1)[: wrows * taps * Cin].view(wrows, taps, Cin)[:rows].float()
+    out = _conv_core(X, Wt, g)
+    assert out.shape[2] == Hout and out.shape[3] == Wout, (out.shape, Hout, Wout)
+    if bias is not None:
+        out = out + bias.reshape(-1)[:rows].float().view(1, -1, 1, 1)
+    if rows < Cout:
+        out = F.pad(out, (0, 0, 0, 0, 0, Cout - rows))
+    if act == ACT_SILU:
+        out = F.silu(out)
+    npix = B * Hout * Wout
+    out = out.permute(0, 2, 3, 1).reshape(npix, Cout).to(T).float()
+    if mul is not None:
+        mm = _rows(mul, npix, ldy)[:, :Cout].float()
+        out = out * (_dsilu(mm) if mulmode == MUL_DSILU else mm)
+    if res is not None:
+        out = out + _rows(res, npix, ldy)[:, :Cout].float()
+    _rows(y, npix, ldy)[:, :Cout] = out.to(T)
+
+
+def conv_wgrad(x, dy, dw, g, dtype):
+    B, Hin, Win, Cin, Hout, Wout, Cout, ldy = (g[k] for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ldy"))
+    taps = 1 if g["mode"] == CONV_1X1 else 9
+    X = _rows(x, B * Hin * Win, Cin).view(B, Hin, Win, Cin).float().permute(0, 3, 1, 2)
+    with torch.enable_grad():
+        Wt = torch.zeros(Cout, taps, Cin, dtype=torch.float32, device=x.device, requires_grad=True)
+        out = _conv_core(X, Wt, g)
+        gy = _rows(dy, B * Hout * Wout, ldy)[:, :Cout].float().view(B, Hout, Wout, Cout).permute(0, 3, 1, 2)
+        (gw,) = torch.autograd.grad(out, Wt, gy)
+    dw.reshape(-1)[: Cout * taps * Cin] += gw.reshape(-1)
+
+
+def _ln(xm, unbiased, eps):
+    var, mean = torch.var_mean(xm, dim=-1, keepdim=True, unbiased=bool(unbiased))
+    return (xm - mean) / (var + eps).sqrt()
+
+
+def _mrows(m, npix, HW, C, ldm):
+    if m is None:
+        return 0.0
+    if ldm == 0:
+        return m.reshape(-1)[:C].float().view(1, C)
+    nb = npix // HW
+    mm = torch.as_strided(m.reshape(-1), (nb, C), (ldm, 1))
+    return mm.float().repeat_interleave(HW, dim=0)
+
+
+def ln_forward(x, m, y, npix, HW, C, ldm, eps, unbiased, dtype):
+    xm = _rows(x, npix, C).float() + _mrows(m, npix, HW, C, ldm)
+    _rows(y, npix, C)[:] = _ln(xm, unbiased, eps).to(TD[dtype])
+
+
+def ln_backward(dy, x, m, dres, dx, dm, npix, HW, C, ldm, eps, unbiased, dtype):
+    with torch.enable_grad():
+        xm = (_rows(x, npix, C).float() + _mrows(m, npix, HW, C, ldm)).detach().requires_grad_(True)
+        out = _ln(xm, unbiased, eps)
+        (g,) = torch.autograd.grad(out, xm, _rows(dy, npix, C).float())
+    if dm is not None:
+        if ldm == 0:
+            dm.reshape(-1)[:C] += g.sum(0)
+        else:
+            nb = npix // HW
+            torch.as_strided(dm.reshape(-1), (nb, C), (ldm, 1)).add_(g.view(nb, HW, C).sum(1))
+    if dres is not None:
+        g = g + _rows(dres, npix, C).float()
+    _rows(dx, npix, C)[:] = g.to(TD[dtype])
+
+
+def colsum(a, out, rows, C, lda, dtype):
+    out.reshape(-1)[:C] += _rows(a, rows, lda)[:, :C].float().sum(0)
+
+
+def silu(x, y, n, dtype):
+    y.reshape(-1)[:n] = F.silu(x.reshape(-1)[:n].float()).to(TD[dtype])
+
+
+def silu_backward(x, dy, dx, n, dtype):
+    dx.reshape(-1)[:n] = (dy.reshape(-1)[:n].float() * _dsilu(x.reshape(-1)[:n].float())).to(TD[dtype])
+
+
+def sumpool2(g, dx, B, H, W, C, dtype):
+    G = _rows(g, B * 2 * H * 2 * W, C).view(B, H, 2, W, 2, C).float().sum(dim=(2, 4))
+    _rows(dx, B * H * W, C)[:] = G.reshape(B * H * W, C).to(TD[dtype])
+
+
+def nchw_to_nhwc(x, eps, musig, y, B, C, HW, ldc, dtype):
+    X = x.reshape(-1)[: B * C * HW].view(B, C, HW).float()
+    if eps is not None:
+        ms = musig.reshape(-1)[: 2 * B].view(B, 2)
+        X = ms[:, 0].view(B, 1, 1) * X + ms[:, 1].view(B, 1, 1) * eps.reshape(-1)[: B * C * HW].view(B, C, HW).float()
+    Y = _rows(y, B * HW, ldc)
+    Y[:] = 0
+    Y[:, :C] = X.permute(0, 2, 1).reshape(B * HW, C).to(TD[dtype])
+
+
+def nhwc_to_nchw(y, out, B, C, HW, ldc, dtype):
+    Y = _rows(y, B * HW, ldc)[:, :C].float().view(B, HW, C).permute(0, 2, 1)
+    out.reshape(-1)[: B * C * HW] = Y.reshape(-1)
+
+
+def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype):
+    Y = _rows(y, B * HW, ldc)[:, :C].float()
+    E = eps.reshape(-1)[: B * C * HW].view(B, C, HW).permute(0, 2, 1).reshape(B * HW, C).float()
+    d = Y - E
+    loss_sum.reshape(-1)[0] += (d * d).sum()
+    D = _rows(dy, B * HW, ldc)
+    D[:] = 0
+    D[:, :C] = (d * gscale).to(TD[dtype])
+
+
+def timestep_embedding(t, out, n, dim, max_period=10000.0):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    a = t.reshape(-1)[:n, None].float() * freqs[None]
+    o = out.reshape(-1)[: n * dim].view(n, dim)
+    o[:] = 0
+    o[:, : 2 * half] = torch.cat((a.cos(), a.sin()), -1)
+
+
+def mu_sigma(t, musig, n, eta):
+    a = torch.cos(math.acos(math.sqrt(eta)) * t.reshape(-1)[:n].float()) ** 2
+    ms = musig.reshape(-1)[: 2 * n].view(n, 2)
+    ms[:, 0] = a
+    ms[:, 1] = (1 - a * a + eta * eta).sqrt()
+
+
+def cast_f32(src, dst, n, dtype):
+    dst.reshape(-1)[:n] = src.reshape(-1)[:n].to(TD[dtype])
+
+
+def weight_transpose(w, out, R, NT, K, ldk, ldr, flip, dtype):
+    Wm = torch.as_strided(w.reshape(-1), (R, NT, K), (NT * ldk, ldk, 1)).float()
+    if flip:
+        Wm = Wm.flip(1)
+    O = torch.as_strided(out.reshape(-1), (K, NT, R), (NT * ldr, ldr, 1))
+    O[:] = Wm.permute(2, 1, 0).to(TD[dtype])
+
+
+def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale):
+    P, G, M, V = (a.reshape(-1)[:n] for a in (p, g, m, v))
+    gi = G * grad_scale
+    P.mul_(1 - lr * weight_decay)
+    M.mul_(beta1).add_(gi, alpha=1 - beta1)
+    V.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+    bc1 = 1 - beta1**step
+    bc2 = 1 - beta2**step
+    P.addcdiv_(M, V.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+    if ema is not None:
+        ema.reshape(-1)[:n].mul_(ema_rate).add_(P, alpha=1 - ema_rate)
+    if shadow is not None:
+        shadow.reshape(-1)[:n] = P.to(torch.bfloat16)
+
+
+def _attn(qkv, B, T, C):
+    q, k, v = _rows(qkv, B * T, 3 * C).view(B, T, 3 * C).split(C, dim=-1)
+    s = torch.einsum("btc,bsc->bts", q, k) / math.sqrt(C)
+    lse = torch.logsumexp(s, dim=-1)
+    o = torch.einsum("bts,bsc->btc", torch.softmax(s, dim=-1), v)
+    return o, lse
+
+
+def attention_forward(qkv, o, lse, B, T, C, dtype):
+    oo, l = _attn(qkv.float(), B, T, C)
+    _rows(o, B * T, C)[:] = oo.reshape(B * T, C).to(TD[dtype])
+    if lse is not None:
+        lse.reshape(-1)[: B * T] = l.reshape(-1)
+
+
+def attention_backward(qkv, o, d_o, lse, delta_ws, dqkv, B, T, C, dtype):
+    with torch.enable_grad():
+        q = _rows(qkv, B * T, 3 * C).float().detach().clone().requires_grad_(True)
+        oo, _ = _attn(q, B, T, C)
+        (g,) = torch.autograd.grad(oo, q, _rows(d_o, B * T, C).float().view(B, T, C))
+    _rows(dqkv, B * T, 3 * C)[:] = g.to(TD[dtype])
+
+
+ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("F",)]
+
+
+def install(monkeypatch, target):
+    """Replace every launcher of `target` (climate2weather_amd.ops) with its PyTorch re-statement."""
+    import sys
+    me = sys.modules[__name__]
+    for name in ALL:
+        if hasattr(target, name) and name not in ("install",):
+            monkeypatch.setattr(target, name, getattr(me, name))

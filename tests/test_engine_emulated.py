@@ -1,0 +1,127 @@
+"""CPU checks of the host engine (flat parameter layout, launch sequencing, hand-written backward tape) with the HIP
+launchers replaced by the PyTorch test double tests/emu_ops.py.  The kernels themselves are checked on the GPU
+(tests/test_gpu_*.py); this file makes sure that what they are asked to do adds up to the reference network."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from climate2weather_amd import ops as c2w_ops
+from climate2weather_amd.score import ScoreUNet
+from oracle import diffusion as od
+from oracle import unet as ou
+
+TINY = dict(embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3,
+            padding_mode="zeros")
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    emu_ops.install(monkeypatch, c2w_ops)
+
+
+def _golden(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name), allow_pickle=False).items()}
+
+
+def _tiny(seed=3):
+    torch.manual_seed(seed)
+    return ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY)
+
+
+def test_creation_order_init_matches_reference(golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    net = _tiny()
+    sd = net.state_dict()
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), ref[k]), k
+    assert [n for n, _ in net.named_parameters()] == [str(n) for n in g["param_order"]]
+
+
+def test_full_size_state_dict_fingerprint(golden_dir):
+    fp = json.load(open(os.path.join(golden_dir, "full_net_fingerprint.json")))
+    import yaml
+    cfg = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3,
+               padding_mode="zeros", attention_levels=[4])
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=52, spatial=2, activation=torch.nn.SiLU, **cfg)
+    sd = net.state_dict()
+    assert list(sd.keys()) == fp["keys"]
+    assert [list(v.shape) for v in sd.values()] == fp["shapes"]
+    assert sum(p.numel() for p in net.parameters()) == fp["n_params"] == 72102964
+    assert sd["unet.heads.0.weight"].double().sum().item() == pytest.approx(fp["heads0_sum"], rel=1e-12)
+    assert sum(v.double().abs().sum().item() for v in sd.values()) == pytest.approx(fp["abs_sum"], rel=1e-12)
+
+
+def test_flatten_keeps_values_and_views(emu, golden_dir):
+    net = _tiny()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    eng = net._get_engine()
+    assert eng.is_attached(net)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    # parameters alias the flat buffer; conv weights are K-contiguous [co][kh][kw][ci]
+    w = net.unet.descent[0][0].residue[1].weight
+    assert w.stride() == (9 * 32, 1, 3 * 32, 32)
+    w0 = net.unet.heads[0].weight
+    assert w0.shape == (32, 6, 3, 3) and w0.stride() == (9 * 64, 1, 3 * 64, 64)
+    # deepcopy / state_dict round trip / pickle
+    import copy, pickle
+    net2 = copy.deepcopy(net)
+    assert net2.__dict__["_engine"] is None
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    net3 = pickle.loads(pickle.dumps(net))
+    net3.load_state_dict(net.state_dict())
+    x = torch.randn(1, 6, 16, 16)
+    t = torch.tensor([0.4])
+    with torch.no_grad():
+        assert torch.allclose(net(x, t), net2(x, t), atol=1e-6)
+        assert torch.allclose(net(x, t), net3(x, t), atol=1e-6)
+
+
+def test_forward_matches_golden(emu, golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    net = _tiny().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]))
+        y32 = net(torch.from_numpy(g["x32"]), torch.tensor(0.3))
+    assert torch.allclose(y, torch.from_numpy(g["y"]), atol=2e-5)
+    assert torch.allclose(y32, torch.from_numpy(g["y32"]), atol=2e-5)
+
+
+def test_backward_matches_golden(emu, golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    net = _tiny()
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    loss = od.loss(net, x, t, eps).mean()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for n, p in net.named_parameters():
+        ref = torch.from_numpy(g["grad." + n])
+        assert p.grad is not None, n
+        assert torch.allclose(p.grad, ref, atol=1e-5 + 2e-4 * ref.abs().max().item()), (n, (p.grad - ref).abs().max().item())
+
+
+def test_input_gradient_and_jacrev(emu, golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    net = _tiny()
+    x = torch.from_numpy(g["x32"])[:2].clone().requires_grad_(True)
+    t = torch.tensor(0.3)
+    w = torch.randn(2, 6, 32, 32, generator=torch.Generator().manual_seed(0))
+    (gx,) = torch.autograd.grad((net(x, t) * w).sum(), x)
+    xo = x.detach().clone().requires_grad_(True)
+    yo = ou.score_unet_forward(sd, xo, t, hidden_blocks=[1, 1], attention_levels=[1])
+    (gxo,) = torch.autograd.grad((yo * w).sum(), xo)
+    assert torch.allclose(gx, gxo, atol=1e-5 + 2e-4 * gxo.abs().max().item())
+    # functorch path used by the guided score function (src/thor/score.py:28-33)
+    def f(xx):
+        return (net(xx, t) * w).sum()
+    J = torch.func.jacrev(f, chunk_size=1)(x.detach())
+    assert torch.allclose(J, gxo, atol=1e-5 + 2e-4 * gxo.abs().max().item())
