@@ -1,0 +1,140 @@
+"""End-to-end GPU parity of the HIP ScoreUNet against (a) the golden vectors generated from the imported reference
+and (b) the CPU oracle on fresh seeded inputs.  fp32 mode: <= 1e-4 relative (BASELINE.json north_star);
+bf16 mode: <= 3e-2 of the output scale (stated tolerance for the throughput mode)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from climate2weather_amd.score import ScoreUNet
+from oracle import diffusion as od
+from oracle import unet as ou
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3,
+            padding_mode="zeros")
+DEFAULT = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3,
+               padding_mode="zeros", attention_levels=[4])
+
+
+def _golden(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name), allow_pickle=False).items()}
+
+
+def _rel(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().max().item() / max(b.float().abs().max().item(), 1e-12)
+
+
+def test_library_is_the_hip_build():
+    from climate2weather_amd import _lib
+    assert _lib.load().c2w_target() == b"gfx950"
+    assert torch.cuda.is_available()
+
+
+def test_tiny_net_fp32_forward_and_grads_vs_golden(golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).cuda()
+    net.precision = "fp32"
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.cpu().numpy(), g["sd." + k]), k
+    x, t, eps, xt = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "eps", "xt"))
+    with torch.no_grad():
+        y = net(xt, t)
+        y32 = net(torch.from_numpy(g["x32"]).cuda(), torch.tensor(0.3))
+    assert _rel(y, torch.from_numpy(g["y"])) <= 1e-4
+    assert _rel(y32, torch.from_numpy(g["y32"])) <= 1e-4
+    loss = od.loss(net, x, t, eps).mean()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-4)
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in net.named_parameters():
+        ref = torch.from_numpy(g["grad." + n])
+        assert p.grad is not None, n
+        r = _rel(p.grad, ref)
+        worst = max(worst, r)
+        assert r <= 2e-4, (n, r)  # wgrad sums are order-dependent (atomics): 2e-4 of the tensor's scale
+    print("worst relative grad error", worst)
+
+
+def test_tiny_net_input_gradient_fp32(golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).cuda()
+    net.precision = "fp32"
+    x = torch.from_numpy(g["x32"])[:2]
+    w = torch.randn(2, 6, 32, 32, generator=torch.Generator().manual_seed(0))
+    xo = x.clone().requires_grad_(True)
+    (gxo,) = torch.autograd.grad((ou.score_unet_forward(sd, xo, torch.tensor(0.3), [1, 1], [1]) * w).sum(), xo)
+    xg = x.cuda().requires_grad_(True)
+    (gx,) = torch.autograd.grad((net(xg, torch.tensor(0.3)) * w.cuda()).sum(), xg)
+    assert _rel(gx, gxo) <= 2e-4
+    J = torch.func.jacrev(lambda xx: (net(xx, torch.tensor(0.3)) * w.cuda()).sum(), chunk_size=1)(x.cuda())
+    assert _rel(J, gxo) <= 2e-4
+
+
+@pytest.mark.parametrize("per_sample_t", [True, False])
+def test_small_net_bf16_vs_oracle(per_sample_t):
+    cfg = dict(embedding_dim=128, hidden_channels=[64, 128, 128], hidden_blocks=[2, 1, 1], attention_levels=[2], kernel_size=3,
+               padding_mode="zeros")
+    torch.manual_seed(5)
+    net = ScoreUNet(channels=13, spatial=2, activation=torch.nn.SiLU, **cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 13, 32, 32, generator=g)
+    t = torch.rand(3, generator=g) if per_sample_t else torch.tensor(0.6)
+    eps = torch.randn(3, 13, 32, 32, generator=g)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = ou.score_unet_forward(sdo, x, t, cfg["hidden_blocks"], cfg["attention_levels"])
+    lo = ((yo - eps) ** 2).mean()
+    go = torch.autograd.grad(lo, list(sdo.values()))
+    for prec, tol_y, tol_g in (("fp32", 1e-4, 3e-4), ("bf16", 3e-2, 8e-2)):
+        net.precision = prec
+        net.zero_grad(set_to_none=True)
+        y = net(x.cuda(), t.cuda())
+        assert _rel(y, yo.detach()) <= tol_y, (prec, _rel(y, yo.detach()))
+        l = ((y - eps.cuda()) ** 2).mean()
+        l.backward()
+        named = dict(net.named_parameters())
+        for (k, _), gr in zip(sdo.items(), go):
+            r = _rel(named[k].grad, gr)
+            assert r <= tol_g, (prec, k, r)
+
+
+def test_autocast_selects_bf16_and_matches():
+    torch.manual_seed(5)
+    cfg = dict(embedding_dim=128, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[], kernel_size=3)
+    net = ScoreUNet(channels=4, spatial=2, activation=torch.nn.SiLU, **cfg).cuda().eval()
+    x = torch.randn(2, 4, 16, 16, device="cuda")
+    t = torch.tensor([0.2, 0.9], device="cuda")
+    with torch.no_grad():
+        y32 = net(x, t)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y16 = net(x, t)
+        assert net.compute_dtype() == 0
+    assert _rel(y16, y32) <= 3e-2 and not torch.equal(y16, y32)
+
+
+def test_full_size_net_fp32_vs_reference_fingerprint(golden_dir):
+    """Default configs/sda_unet.yml network, C=52, 128x128: output of the imported reference captured as a strided slice."""
+    fp = json.load(open(os.path.join(golden_dir, "full_net_fingerprint.json")))
+    ref = torch.from_numpy(np.load(os.path.join(golden_dir, "full_net_slice.npz"))["y_slice"])
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=52, spatial=2, activation=torch.nn.SiLU, **DEFAULT).cuda().eval()
+    net.precision = "fp32"
+    x = torch.randn(1, 52, 128, 128, generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        y = net(x.cuda(), torch.tensor([0.3], device="cuda")).cpu()
+    assert y.double().mean().item() == pytest.approx(fp["y_mean"], abs=1e-5)
+    assert y.double().std().item() == pytest.approx(fp["y_std"], rel=1e-4)
+    assert _rel(y[:, :, ::16, ::16], ref) <= 1e-4
+    net.precision = "bf16"
+    with torch.no_grad():
+        yb = net(x.cuda(), torch.tensor([0.3], device="cuda")).cpu()
+    assert _rel(yb[:, :, ::16, ::16], ref) <= 3e-2

@@ -1,0 +1,272 @@
+"""GPU parity of every HIP kernel (called through the C ABI via climate2weather_amd.ops) against the plain PyTorch
+restatement of the same op (tests/emu_ops.py) on the same seeded inputs.
+
+Tolerances (written here, per SURVEY 8d / BASELINE.json): fp32 mode <= 1e-4 of the output scale (the parity gate);
+bf16 mode <= 2e-2 of the output scale (bf16 has 8 significand bits; K up to 4608 products are accumulated in fp32).
+"""
+import math
+
+import pytest
+import torch
+
+import emu_ops as E
+from climate2weather_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = ops.DTYPE_F32, ops.DTYPE_BF16
+TD = ops.TORCH_DTYPE
+TOL = {F32: 1e-4, BF16: 2e-2}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(TD[dt]).to(dev())
+
+
+def close(a, b, dt, what="", scale=None, tol=None):
+    a, b = a.float(), b.float()
+    s = scale if scale is not None else max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert math.isfinite(err) and err <= (tol or TOL[dt]) * s, f"{what}: max err {err:.3e} vs scale {s:.3e}"
+
+
+def geom(B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows, mode):
+    return dict(B=B, Hin=Hin, Win=Win, Cin=Cin, Hout=Hout, Wout=Wout, Cout=Cout, ldy=ldy, wrows=wrows, mode=mode)
+
+
+CONV_CASES = [
+    # (mode, B, Hin, Win, Cin, Cout, wrows, ldy)
+    (ops.CONV_S1, 2, 16, 16, 64, 128, 128, 128),
+    (ops.CONV_S1, 3, 8, 8, 128, 192, 192, 192),     # ragged pixel tile (192 px), two channel tiles, second partial
+    (ops.CONV_S1, 1, 32, 32, 128, 64, 52, 64),      # output conv: 52 real rows, padded output rows stay zero
+    (ops.CONV_S1, 2, 4, 4, 64, 64, 64, 64),         # tiny spatial (plumbing config depth)
+    (ops.CONV_S2, 2, 16, 16, 64, 128, 128, 128),
+    (ops.CONV_S2, 1, 32, 32, 128, 256, 256, 256),
+    (ops.CONV_UP, 2, 8, 8, 128, 64, 64, 64),
+    (ops.CONV_UP, 1, 16, 16, 64, 128, 128, 128),
+    (ops.CONV_TS2, 2, 8, 8, 128, 64, 64, 64),       # dgrad of a stride-2 conv: 8x8 dy -> 16x16 dx
+    (ops.CONV_1X1, 5, 1, 1, 64, 320, 320, 320),     # Linear on 5 rows
+    (ops.CONV_1X1, 2, 8, 8, 128, 384, 384, 384),    # qkv-style 1x1
+]
+
+
+def _out_hw(mode, Hin, Win):
+    if mode == ops.CONV_S2:
+        return Hin // 2, Win // 2
+    if mode in (ops.CONV_UP, ops.CONV_TS2):
+        return Hin * 2, Win * 2
+    return Hin, Win
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("naive", [False, True])
+def test_conv_forward(case, dt, naive):
+    mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
+    taps = 1 if mode == ops.CONV_1X1 else 9
+    Hout, Wout = _out_hw(mode, Hin, Win)
+    g = geom(B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows, mode)
+    x = rnd((B * Hin * Win, Cin), dt, 1)
+    w = rnd((wrows, taps, Cin), dt, 2, scale=1.0 / math.sqrt(taps * Cin))
+    bias = rnd((wrows,), F32, 3)
+    res = rnd((B * Hout * Wout, ldy), dt, 4)
+    mul = rnd((B * Hout * Wout, ldy), dt, 5)
+    for variant in range(4):
+        kw = [dict(), dict(act=ops.ACT_SILU), dict(res=res), dict(mul=mul, mulmode=ops.MUL_DSILU, res=res)][variant]
+        b = None if variant == 3 else bias
+        y = torch.full((B * Hout * Wout, ldy), 7.0, dtype=TD[dt], device=dev())
+        y_ref = y.clone()
+        ops.conv(x, w, b, y, g, dt, naive=naive, **kw)
+        E.conv(x, w, b, y_ref, g, dt, **kw)
+        torch.cuda.synchronize()
+        close(y, y_ref, dt, f"conv mode={mode} variant={variant} naive={naive}")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] != ops.CONV_TS2])
+def test_conv_wgrad(case, dt):
+    mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
+    taps = 1 if mode == ops.CONV_1X1 else 9
+    Hout, Wout = _out_hw(mode, Hin, Win)
+    Cw = wrows  # gradient rows = real output channels
+    g = geom(B, Hin, Win, Cin, Hout, Wout, Cw, ldy, wrows, mode)
+    x = rnd((B * Hin * Win, Cin), dt, 1)
+    dy = rnd((B * Hout * Wout, ldy), dt, 2)
+    dw = torch.zeros(Cw * taps * Cin + 64, dtype=torch.float32, device=dev())
+    dw_ref = dw.clone()
+    ops.conv_wgrad(x, dy, dw, g, dt)
+    E.conv_wgrad(x, dy, dw_ref, g, dt)
+    torch.cuda.synchronize()
+    close(dw, dw_ref, dt, f"wgrad mode={mode}", tol=1e-4 if dt == F32 else 1e-2)
+    assert dw[-64:].abs().max().item() == 0.0  # nothing written past the tensor
+    # accumulation semantics: a second call adds
+    ops.conv_wgrad(x, dy, dw, g, dt)
+    close(dw, 2 * dw_ref, dt, "wgrad accumulate", tol=1e-4 if dt == F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 64, 128, True), (3, 16, 256, True), (1, 1024, 384, False), (2, 64, 512, True), (4, 4, 64, True)])
+def test_layernorm_fwd_bwd(shape, dt):
+    B, HW, C, per_sample = shape
+    if dt == F32 and C > 512:
+        pytest.skip("fp32 rows hold at most 512 channels in registers")
+    npix = B * HW
+    x = rnd((npix, C), dt, 1)
+    ldm_total = C + 64
+    m = rnd((B if per_sample else 1, ldm_total), F32, 2)
+    ldm = ldm_total if per_sample else 0
+    for use_m in (True, False):
+        mm = m.view(-1)[32:] if use_m else None
+        y = torch.empty_like(x)
+        y_ref = torch.empty_like(x)
+        ops.ln_forward(x, mm, y, npix, HW, C, ldm, 1e-5, True, dt)
+        E.ln_forward(x, mm, y_ref, npix, HW, C, ldm, 1e-5, True, dt)
+        close(y, y_ref, dt, "ln fwd")
+        dy = rnd((npix, C), dt, 3)
+        dres = rnd((npix, C), dt, 4)
+        dx, dx_ref = torch.empty_like(x), torch.empty_like(x)
+        dm = torch.zeros_like(m) if use_m else None
+        dm_ref = torch.zeros_like(m) if use_m else None
+        ops.ln_backward(dy, x, mm, dres, dx, dm.view(-1)[32:] if use_m else None, npix, HW, C, ldm, 1e-5, True, dt)
+        E.ln_backward(dy, x, mm, dres, dx_ref, dm_ref.view(-1)[32:] if use_m else None, npix, HW, C, ldm, 1e-5, True, dt)
+        close(dx, dx_ref, dt, "ln bwd dx")
+        if use_m:
+            close(dm, dm_ref, dt, "ln bwd dm", tol=1e-4 if dt == F32 else 1e-2)
+    # biased variant switch
+    y = torch.empty_like(x)
+    y_ref = torch.empty_like(x)
+    ops.ln_forward(x, None, y, npix, HW, C, 0, 1e-5, False, dt)
+    E.ln_forward(x, None, y_ref, npix, HW, C, 0, 1e-5, False, dt)
+    close(y, y_ref, dt, "ln fwd biased")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_pointwise_family(dt):
+    d = dev()
+    rows, C, lda = 1000, 128, 192
+    a = rnd((rows, lda), dt, 1)
+    out = torch.zeros(C + 8, device=d)
+    out_ref = out.clone()
+    ops.colsum(a, out, rows, C, lda, dt)
+    E.colsum(a, out_ref, rows, C, lda, dt)
+    close(out, out_ref, dt, "colsum", tol=1e-4 if dt == F32 else 1e-3)
+    n = 4096 * 8
+    x = rnd((n,), dt, 2, scale=3.0)
+    dy = rnd((n,), dt, 3)
+    y, y_ref = torch.empty_like(x), torch.empty_like(x)
+    ops.silu(x, y, n, dt)
+    E.silu(x, y_ref, n, dt)
+    close(y, y_ref, dt, "silu")
+    ops.silu_backward(x, dy, y, n, dt)
+    E.silu_backward(x, dy, y_ref, n, dt)
+    close(y, y_ref, dt, "silu bwd")
+    B, H, W, Cc = 2, 8, 8, 64
+    g = rnd((B * 2 * H * 2 * W, Cc), dt, 4)
+    p, p_ref = torch.empty((B * H * W, Cc), dtype=TD[dt], device=d), torch.empty((B * H * W, Cc), dtype=TD[dt], device=d)
+    ops.sumpool2(g, p, B, H, W, Cc, dt)
+    E.sumpool2(g, p_ref, B, H, W, Cc, dt)
+    close(p, p_ref, dt, "sumpool2")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_layout_noise_loss(dt):
+    d = dev()
+    B, C, H, W, ldc = 3, 52, 16, 16, 64
+    x = rnd((B, C, H, W), F32, 1)
+    eps = rnd((B, C, H, W), F32, 2)
+    t = torch.rand(B, generator=torch.Generator().manual_seed(3)).to(d)
+    ms, ms_ref = torch.empty(B, 2, device=d), torch.empty(B, 2, device=d)
+    ops.mu_sigma(t, ms, B, 1e-3)
+    E.mu_sigma(t, ms_ref, B, 1e-3)
+    close(ms, ms_ref, F32, "mu_sigma", tol=1e-6)
+    for e in (None, eps):
+        y = torch.full((B * H * W, ldc), 5.0, dtype=TD[dt], device=d)
+        y_ref = y.clone()
+        ops.nchw_to_nhwc(x, e, ms if e is not None else None, y, B, C, H * W, ldc, dt)
+        E.nchw_to_nhwc(x, e, ms if e is not None else None, y_ref, B, C, H * W, ldc, dt)
+        close(y, y_ref, dt, "nchw_to_nhwc")
+        assert y[:, C:].abs().max().item() == 0.0
+    back, back_ref = torch.empty_like(x), torch.empty_like(x)
+    ops.nhwc_to_nchw(y, back, B, C, H * W, ldc, dt)
+    E.nhwc_to_nchw(y_ref, back_ref, B, C, H * W, ldc, dt)
+    close(back, back_ref, dt, "nhwc_to_nchw")
+    dy, dy_ref = torch.empty_like(y), torch.empty_like(y)
+    ls, ls_ref = torch.zeros(1, device=d), torch.zeros(1, device=d)
+    ops.mse_loss_grad(y, eps, dy, ls, B, C, H * W, ldc, 0.37, dt)
+    E.mse_loss_grad(y, eps, dy_ref, ls_ref, B, C, H * W, ldc, 0.37, dt)
+    close(dy, dy_ref, dt, "mse dy")
+    close(ls, ls_ref, F32, "mse loss", tol=1e-4)
+    assert dy[:, C:].abs().max().item() == 0.0
+
+
+def test_time_embedding_cast_transpose_adamw():
+    d = dev()
+    t = torch.tensor([0.0, 0.25, 0.5, 1.0], device=d)
+    o, o_ref = torch.empty(4, 32, device=d), torch.empty(4, 32, device=d)
+    ops.timestep_embedding(t, o, 4, 32)
+    E.timestep_embedding(t, o_ref, 4, 32)
+    close(o, o_ref, F32, "timestep_embedding", tol=1e-6)
+    assert abs(o[2, 0].item() - 0.87758255) < 1e-6 and abs(o[2, 16].item() - 0.47942555) < 1e-6  # SURVEY a1 KAT
+    src = rnd((10000,), F32, 1)
+    for dt in (F32, BF16):
+        dst, dst_ref = torch.empty(10000, dtype=TD[dt], device=d), torch.empty(10000, dtype=TD[dt], device=d)
+        ops.cast_f32(src, dst, 10000, dt)
+        E.cast_f32(src, dst_ref, 10000, dt)
+        assert torch.equal(dst, dst_ref)
+        R, NT, K, ldk, ldr = 52, 9, 100, 128, 64
+        w = rnd((R * NT * ldk,), F32, 2)
+        for flip in (0, 1):
+            out = torch.zeros(K * NT * ldr, dtype=TD[dt], device=d)
+            out_ref = out.clone()
+            ops.weight_transpose(w, out, R, NT, K, ldk, ldr, flip, dt)
+            E.weight_transpose(w, out_ref, R, NT, K, ldk, ldr, flip, dt)
+            assert torch.equal(out, out_ref)
+    n = 5000
+    bufs = [rnd((n,), F32, s) for s in (1, 2, 3)]
+    p, g_, ema = bufs
+    m = torch.zeros(n, device=d)
+    v = torch.zeros(n, device=d)
+    sh = torch.empty(n, dtype=torch.bfloat16, device=d)
+    ref = [b.clone() for b in (p, g_, m, v, ema)]
+    sh_ref = sh.clone()
+    for step in (1, 2, 3):
+        ops.adamw_ema(p, g_, m, v, ema, sh, n, 1e-3, 0.9, 0.999, 1e-8, 1e-3, step, 0.9999, 0.5)
+        E.adamw_ema(ref[0], ref[1], ref[2], ref[3], ref[4], sh_ref, n, 1e-3, 0.9, 0.999, 1e-8, 1e-3, step, 0.9999, 0.5)
+    close(p, ref[0], F32, "adamw p", tol=1e-6)
+    close(ema, ref[4], F32, "ema", tol=1e-6)
+    close(sh, sh_ref, BF16, "shadow", tol=1e-2)
+    # against torch.optim.AdamW itself (train.py:176-181)
+    q = torch.nn.Parameter(bufs[0].clone())
+    opt = torch.optim.AdamW([q], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    p2, m2, v2 = q.detach().clone(), torch.zeros(n, device=d), torch.zeros(n, device=d)
+    for step in (1, 2):
+        gr = rnd((n,), F32, 10 + step)
+        q.grad = gr.clone()
+        opt.step()
+        ops.adamw_ema(p2, gr, m2, v2, None, None, n, 1e-3, 0.9, 0.999, 1e-8, 1e-3, step, 0.0, 1.0)
+    close(p2, q.detach(), F32, "adamw vs torch.optim.AdamW", tol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 64, 512), (3, 16, 64), (1, 256, 128), (2, 4, 64)])
+def test_attention(shape, dt):
+    B, T, C = shape
+    d = dev()
+    qkv = rnd((B * T, 3 * C), dt, 1, scale=1.5)
+    o, o_ref = torch.empty((B * T, C), dtype=TD[dt], device=d), torch.empty((B * T, C), dtype=TD[dt], device=d)
+    lse, lse_ref = torch.empty(B * T, device=d), torch.empty(B * T, device=d)
+    ops.attention_forward(qkv, o, lse, B, T, C, dt)
+    E.attention_forward(qkv, o_ref, lse_ref, B, T, C, dt)
+    close(o, o_ref, dt, "attention fwd")
+    close(lse, lse_ref, F32, "attention lse", tol=1e-4)
+    do = rnd((B * T, C), dt, 2)
+    dq, dq_ref = torch.empty_like(qkv), torch.empty_like(qkv)
+    delta = torch.empty(B * T, device=d)
+    ops.attention_backward(qkv, o_ref, do, lse_ref, delta, dq, B, T, C, dt)
+    E.attention_backward(qkv, o_ref, do, lse_ref, delta, dq_ref, B, T, C, dt)
+    close(dq, dq_ref, dt, "attention bwd")

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the HIP GEMM kernels at the default network's layer shapes (random data).
+    python tools/bench_kernels.py [--batch 32]
+Prints one line per (kernel, shape): ms, TFLOP/s."""
+import argparse
+import math
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from climate2weather_amd import ops
+
+p = argparse.ArgumentParser()
+p.add_argument("--batch", type=int, default=32)
+p.add_argument("--iters", type=int, default=10)
+p.add_argument("--dtypes", default="bf16,fp32")
+a = p.parse_args()
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+SHAPES = [  # (mode, H, Cin, Cout)
+    (ops.CONV_S1, 128, 128, 128), (ops.CONV_S1, 64, 128, 128), (ops.CONV_S1, 32, 256, 256), (ops.CONV_S1, 16, 384, 384),
+    (ops.CONV_S1, 8, 512, 512), (ops.CONV_S2, 128, 128, 128), (ops.CONV_UP, 64, 128, 128), (ops.CONV_S1, 128, 64, 128),
+]
+for dname in a.dtypes.split(","):
+    dt = ops.DTYPE_BF16 if dname == "bf16" else ops.DTYPE_F32
+    T = ops.TORCH_DTYPE[dt]
+    B = a.batch if dt == ops.DTYPE_BF16 else max(1, a.batch // 8)
+    for mode, H, Cin, Cout in SHAPES:
+        Ho = H // 2 if mode == ops.CONV_S2 else (H * 2 if mode == ops.CONV_UP else H)
+        g = dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=Ho, Wout=Ho, Cout=Cout, ldy=Cout, wrows=Cout, mode=mode)
+        x = torch.randn(B * H * H, Cin, device=dev).to(T)
+        w = (torch.randn(Cout, 9, Cin, device=dev) / math.sqrt(9 * Cin)).to(T)
+        bias = torch.randn(Cout, device=dev)
+        y = torch.empty(B * Ho * Ho, Cout, device=dev, dtype=T)
+        dw = torch.zeros(Cout * 9 * Cin, device=dev)
+        flops = 2.0 * B * Ho * Ho * Cout * 9 * Cin
+        ms = timeit(lambda: ops.conv(x, w, bias, y, g, dt, act=ops.ACT_SILU), a.iters)
+        print(f"conv   {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt), a.iters)
+        print(f"wgrad  {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    # memory-bound kernels
+    npix, C = B * 128 * 128, 128
+    x = torch.randn(npix, C, device=dev).to(T)
+    y = torch.empty_like(x)
+    m = torch.randn(B, C, device=dev)
+    ms = timeit(lambda: ops.ln_forward(x, m, y, npix, 128 * 128, C, C, 1e-5, True, dt), a.iters)
+    print(f"ln_fwd {dname} {npix}x{C}: {ms:8.3f} ms  {2 * x.numel() * x.element_size() / ms / 1e6:8.1f} GB/s", flush=True)
+    dx = torch.empty_like(x)
+    dm = torch.zeros(B, C, device=dev)
+    ms = timeit(lambda: ops.ln_backward(y, x, m, y, dx, dm, npix, 128 * 128, C, C, 1e-5, True, dt), a.iters)
+    print(f"ln_bwd {dname} {npix}x{C}: {ms:8.3f} ms  {4 * x.numel() * x.element_size() / ms / 1e6:8.1f} GB/s", flush=True)
