@@ -50,8 +50,16 @@ _PROTOS = {
     "c2w_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_adamw_ema": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
                       c_float, c_int, c_float, c_float, c_void_p],
+    "c2w_ema_update": [c_void_p, c_void_p, c_longlong, c_float, c_void_p],
     "c2w_attention_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_attention_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_window_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_window_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_sampler_predict": [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_void_p],
+    "c2w_sumsq": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "c2w_sampler_correct": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_void_p],
+    "c2w_guidance": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
+                     c_void_p],
 }
 
 _lib = None

@@ -71,45 +71,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // dx = dres + d/dx [ LN_C(x + m) ] . dy ;  dm[b] += sum_pixels of the LN part (the modulation gradient).
 // With s = sqrt(var + eps), xh = (x+m-mean)/s, den = C-1 (unbiased) or C:
 //   dxm = ( dy - mean(dy) - xh * sum(dy*xh)/den ) / s
+// grid = (chunks per image, images): every pixel of a block belongs to one image, so the modulation gradient is
+// reduced in registers -> LDS (ds_add_f32) -> ONE contiguous global atomic sweep per block.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ m,
                                                      const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dm,
-                                                     long long npix, int HW, int C, int ldm, float eps, float inv_den, int pix_per_block) {
+                                                     int HW, int C, int ldm, float eps, float inv_den, int pix_per_block) {
     constexpr int P = Elem<T>::PER16;
+    __shared__ float red[16 * LN_MAXV * 8];
     const int sub = threadIdx.x >> 4, j = threadIdx.x & 15;
     const int nv = (C + 16 * P - 1) / (16 * P);
+    const long long b = blockIdx.y;
+    if (dm != nullptr) {
+        for (int c = threadIdx.x; c < C; c += 256) red[c] = 0.f;
+        __syncthreads();
+    }
     float am[LN_MAXV][P];
 #pragma unroll
     for (int v = 0; v < LN_MAXV; ++v)
 #pragma unroll
         for (int e = 0; e < P; ++e) am[v][e] = 0.f;
-    long long cur_b = -1;
-    auto flush = [&]() {
-        if (dm == nullptr || cur_b < 0) return;
-        float* dr = dm + (size_t)(ldm ? cur_b : 0) * ldm;
-#pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
-            const int c = (v * 16 + j) * P;
-            if (v < nv && c < C) {
-#pragma unroll
-                for (int e = 0; e < P; ++e) {
-                    atomicAdd(dr + c + e, am[v][e]);
-                    am[v][e] = 0.f;
-                }
-            }
-        }
-    };
-    const long long p0 = (long long)blockIdx.x * pix_per_block;
-    const long long p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
-    for (long long pix = p0 + sub; pix < p1; pix += 16) {
-        const long long b = pix / HW;
-        if (b != cur_b) {
-            flush();
-            cur_b = b;
-        }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = (p0 + pix_per_block < HW) ? p0 + pix_per_block : HW;
+    const float* mr = m ? m + (size_t)(ldm ? b : 0) * ldm : nullptr;
+    for (int pp = p0 + sub; pp < p1; pp += 16) {
+        const long long pix = b * HW + pp;
         const T* xr = x + pix * C;
         const T* gr = dy + pix * C;
-        const float* mr = m ? m + (size_t)(ldm ? b : 0) * ldm : nullptr;
         float f[LN_MAXV][P], g[LN_MAXV][P];
         float s = 0.f, sg = 0.f;
 #pragma unroll
@@ -175,7 +163,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
-    flush();
+    if (dm != nullptr) {
+#pragma unroll
+        for (int v = 0; v < LN_MAXV; ++v) {
+            const int c = (v * 16 + j) * P;
+            if (v < nv && c < C) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) atomicAdd(&red[c + e], am[v][e]);
+            }
+        }
+        __syncthreads();
+        float* dr = dm + (size_t)(ldm ? b : 0) * ldm;
+        for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dr + c, red[c]);
+    }
 }
 
 // out[c] += sum over rows of a[row][c]   (bias gradients)
@@ -398,6 +398,12 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
     }
 }
 
+// src/thor/ema.py:23-27 over a flat buffer
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long long n, float rate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        ema[i] = rate * ema[i] + (1.f - rate) * p[i];
+}
+
 inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -428,10 +434,11 @@ extern "C" int c2w_ln_backward(const void* dy, const void* x, const float* m, co
                                int C, int ldm, float eps, int unbiased, int dtype, void* stream) {
     if (!dy || !x || !dx || !vec_ok(dtype, C) || C > 16 * LN_MAXV * (dtype == C2W_DTYPE_F32 ? 4 : 8) || C < 2) return C2W_ERR_BAD_SHAPE;
     const float inv_den = 1.0f / (float)(unbiased ? C - 1 : C);
-    const int ppb = 256;
-    const int grid = (int)((npix + ppb - 1) / ppb);
-    DISPATCH_T(dtype, (ln_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)x, m, (const T*)dres, (T*)dx, dm, npix,
-                                                                                 HW, C, ldm, eps, inv_den, ppb)));
+    if (HW <= 0 || npix % HW != 0) return C2W_ERR_BAD_SHAPE;
+    const int ppb = HW < 512 ? HW : 512;
+    dim3 grid((HW + ppb - 1) / ppb, (unsigned)(npix / HW));
+    DISPATCH_T(dtype, (ln_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)x, m, (const T*)dres, (T*)dx, dm, HW, C,
+                                                                                 ldm, eps, inv_den, ppb)));
     return (int)hipGetLastError();
 }
 
@@ -522,6 +529,12 @@ extern "C" int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     adamw_ema_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps,
                                                                    weight_decay, bc1, bc2_sqrt, ema_rate, grad_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_ema_update(float* ema, const float* p, long long n, float rate, void* stream) {
+    if (!ema || !p) return C2W_ERR_BAD_ARG;
+    ema_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(ema, p, n, rate);
     return (int)hipGetLastError();
 }
 

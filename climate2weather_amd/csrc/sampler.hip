@@ -1,0 +1,187 @@
+// Device-resident pieces of the diffusion sampler (src/thor/pipelines.py:41-97) and of the sliding-window score
+// function (src/thor/score.py:68-93,111-185).  The reference keeps the trajectory on the host and ships every
+// window batch over PCIe each step; here the whole state x[L][F][H][W] (fp32) lives in HBM and these streaming
+// kernels gather windows straight into the network's NHWC input, scatter the kept frames back, apply the
+// predictor / corrector updates and the Gaussian-likelihood guidance term.
+#include "common.h"
+#include "c2w_hip.h"
+
+namespace {
+
+inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
+
+// unfold (src/thor/score.py:68-74) fused with NCHW->NHWC + cast: window j = frames i0+j .. i0+j+w-1, channel = tau*F + c.
+// In memory a window's (w*F, H, W) tensor is just the contiguous run of frames starting at frame i0+j.
+template <typename T>
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ x, T* __restrict__ y, int nw, int CW, int HW,
+                                                            long long frame_stride, int i0, int ldc) {
+    constexpr int P = Elem<T>::PER16;
+    const int nvec = ldc / P;
+    const long long total = (long long)nw * HW * nvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const long long r = i / HW;
+        const int vec = (int)(r % nvec);
+        const int j = (int)(r / nvec);
+        const float* src = x + (long long)(i0 + j) * frame_stride;
+        float f[P];
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            const int c = vec * P + e;
+            f[e] = (c < CW) ? src[(long long)c * HW + pix] : 0.f;
+        }
+        *(u32x4_t*)(y + ((size_t)j * HW + pix) * ldc + vec * P) = pack16<T>(f);
+    }
+}
+
+// fold (src/thor/score.py:76-88 / _window_score :111-141): keep the centre frame of every window, the leading k frames of
+// the first window and the trailing k frames of the last one.
+template <typename T>
+__global__ __launch_bounds__(256) void window_scatter_kernel(const T* __restrict__ y, float* __restrict__ eps, int nw, int F, int HW, int k,
+                                                             int i0, int nwin_total, int ldc) {
+    const int w = 2 * k + 1;
+    const long long total = (long long)nw * w * F * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        long long r = i / HW;
+        const int c = (int)(r % F);
+        r /= F;
+        const int tau = (int)(r % w);
+        const int j = (int)(r / w);
+        const int gi = i0 + j;
+        const bool keep = tau == k || (gi == 0 && tau < k) || (gi == nwin_total - 1 && tau > k);
+        if (keep) eps[((long long)(gi + tau) * F + c) * HW + pix] = Elem<T>::ld(y + ((size_t)j * HW + pix) * ldc + tau * F + c);
+    }
+}
+
+// predictor (src/thor/pipelines.py:41-46):  x <- mu' (x - sigma eps)/mu + sigma' eps  =  a x + b eps ; NaN/Inf raises `flag`
+__global__ __launch_bounds__(256) void predict_kernel(float* __restrict__ x, const float* __restrict__ eps, int* __restrict__ flag, long long n,
+                                                      float a, float b) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = a * x[i] + b * eps[i];
+        x[i] = v;
+        bad |= !(fabsf(v) <= 3.0e38f);
+    }
+    if (flag != nullptr && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ v, float* __restrict__ out, long long n) {
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += v[i] * v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// corrector (src/thor/pipelines.py:81-88): delta = tau / mean(eps^2) ; x <- x - (delta eps + sqrt(2 delta) z) sigma'
+__global__ __launch_bounds__(256) void correct_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z,
+                                                      const float* __restrict__ sumsq, int* __restrict__ flag, long long n, float tau,
+                                                      float sigma_next) {
+    const float delta = tau / (sumsq[0] / (float)n);
+    const float sd = sqrtf(2.f * delta);
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i] - (delta * eps[i] + sd * z[i]) * sigma_next;
+        x[i] = v;
+        bad |= !(fabsf(v) <= 3.0e38f);
+    }
+    if (flag != nullptr && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// Gaussian-likelihood guidance with the reference's measurement operator A = AvgPool2d(s) o x[::t_step]
+// (exp/downscaling.py:129-132) and exact_grad=False (src/thor/score.py:28-57, all shipped configs):
+//   x0 = (x - sigma eps)/mu ; err = y - A(x0) ; var = std_c^2 + gamma (sigma/mu)^2
+//   eps <- eps - sigma * (1/mu) * A^T(err/var)          (A^T spreads err/(var s^2) over the s x s cell)
+// one wave per (observed frame, channel, pooled cell)
+__global__ __launch_bounds__(256) void guidance_kernel(const float* __restrict__ x, float* __restrict__ eps, const float* __restrict__ yobs,
+                                                       const float* __restrict__ stdv, int nobs, int F, int H, int W, int s, int t_step,
+                                                       float mu, float sigma, float gamma) {
+    const int lane = threadIdx.x & 63;
+    const int PH = H / s, PW = W / s;
+    const long long ncell = (long long)nobs * F * PH * PW;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= ncell) return;
+    const int pw = (int)(wave % PW);
+    long long r = wave / PW;
+    const int ph = (int)(r % PH);
+    r /= PH;
+    const int c = (int)(r % F);
+    const int o = (int)(r / F);
+    const long long base = (((long long)o * t_step) * F + c) * H * W;
+    float acc = 0.f;
+    for (int q = lane; q < s * s; q += 64) {
+        const long long idx = base + (long long)(ph * s + q / s) * W + pw * s + q % s;
+        acc += (x[idx] - sigma * eps[idx]) / mu;
+    }
+    const float mean = wave_sum(acc) / (float)(s * s);
+    const float sd = stdv[c];
+    const float ratio = sigma / mu;
+    const float var = sd * sd + gamma * ratio * ratio;
+    const float err = yobs[(((long long)o * F + c) * PH + ph) * PW + pw] - mean;
+    const float corr = sigma * (err / var) / (mu * (float)(s * s));
+    for (int q = lane; q < s * s; q += 64) {
+        const long long idx = base + (long long)(ph * s + q / s) * W + pw * s + q % s;
+        eps[idx] -= corr;
+    }
+}
+
+}  // namespace
+
+extern "C" int c2w_window_gather(const float* x, void* y, int nw, int F, int HW, int k, int i0, int ldc, int dtype, void* stream) {
+    const int CW = (2 * k + 1) * F;
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    if (!x || !y || nw <= 0 || ldc < CW || ldc % P) return C2W_ERR_BAD_SHAPE;
+    const long long total = (long long)nw * HW * (ldc / P);
+    if (dtype == C2W_DTYPE_F32)
+        window_gather_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (float*)y, nw, CW, HW, (long long)F * HW, i0, ldc);
+    else if (dtype == C2W_DTYPE_BF16)
+        window_gather_kernel<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, nw, CW, HW, (long long)F * HW, i0, ldc);
+    else
+        return C2W_ERR_BAD_ARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_window_scatter(const void* y, float* eps, int nw, int F, int HW, int k, int i0, int nwin_total, int ldc, int dtype,
+                                  void* stream) {
+    if (!y || !eps || nw <= 0 || ldc < (2 * k + 1) * F) return C2W_ERR_BAD_SHAPE;
+    const long long total = (long long)nw * (2 * k + 1) * F * HW;
+    if (dtype == C2W_DTYPE_F32)
+        window_scatter_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const float*)y, eps, nw, F, HW, k, i0, nwin_total, ldc);
+    else if (dtype == C2W_DTYPE_BF16)
+        window_scatter_kernel<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const bf16_t*)y, eps, nw, F, HW, k, i0, nwin_total, ldc);
+    else
+        return C2W_ERR_BAD_ARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_sampler_predict(float* x, const float* eps, int* nan_flag, long long n, float a, float b, void* stream) {
+    if (!x || !eps) return C2W_ERR_BAD_ARG;
+    predict_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(x, eps, nan_flag, n, a, b);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_sumsq(const float* v, float* out, long long n, void* stream) {
+    if (!v || !out) return C2W_ERR_BAD_ARG;
+    sumsq_kernel<<<grid_for(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(v, out, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_sampler_correct(float* x, const float* eps, const float* z, const float* sumsq, int* nan_flag, long long n, float tau,
+                                   float sigma_next, void* stream) {
+    if (!x || !eps || !z || !sumsq) return C2W_ERR_BAD_ARG;
+    correct_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(x, eps, z, sumsq, nan_flag, n, tau, sigma_next);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_guidance(const float* x, float* eps, const float* yobs, const float* stdv, int nobs, int F, int H, int W, int s_step,
+                            int t_step, float mu, float sigma, float gamma, void* stream) {
+    if (!x || !eps || !yobs || !stdv || nobs <= 0 || s_step <= 0 || H % s_step || W % s_step || t_step <= 0) return C2W_ERR_BAD_SHAPE;
+    const long long ncell = (long long)nobs * F * (H / s_step) * (W / s_step);
+    const long long blocks = (ncell + 3) / 4;
+    guidance_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma);
+    return (int)hipGetLastError();
+}

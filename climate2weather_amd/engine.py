@@ -63,7 +63,13 @@ class Layout:
         self.convs: Dict[str, ConvRec] = {}
         self.views: Dict[str, Tuple[int, Tuple[int, ...], Tuple[int, ...]]] = {}  # param name -> (offset, shape, strides)
         off = 0
-        # 1) modulation projections, back to back in execution order:  Wp_all [sumC][E], bp_all [sumC]
+        self._off = 0
+        # Flat order = reverse of the order in which backward finalises gradients (time MLP last, output conv first), so
+        # the finished part of the gradient buffer is always a growing suffix -> bucketed all-reduce can chase it.
+        self._add("map_layer0", self.E, self.noise_features, 1, lin=True)
+        self._add("map_layer1", self.E, self.E, 1, lin=True)
+        off = self._off
+        # modulation projections, back to back in execution order:  Wp_all [sumC][E], bp_all [sumC]
         blocks: List[BlockSpec] = []
         for lv in self.levels:
             blocks += [b for b in lv.descent if b.kind == "res"]
@@ -86,23 +92,8 @@ class Layout:
         off = _round_up(off, ALIGN)
         self.convs["proj"] = ConvRec("proj", self.sum_c, self.E, self.E, 1, self.proj_w_off, self.proj_b_off, lin=True, dg_ld=self.sum_c)
 
-        def add(name: str, rows: int, cin: int, taps: int, kstride: Optional[int] = None, lin=False, dg_ld=None, flip=False, ndim=4):
-            nonlocal off
-            ks = kstride or cin
-            rec = ConvRec(name, rows, cin, ks, taps, lin=lin, dg_ld=dg_ld if dg_ld is not None else rows, flip=flip)
-            rec.w_off = off
-            if taps == 9:
-                self.views[name + ".weight"] = (off, (rows, cin, 3, 3), (9 * ks, 1, 3 * ks, ks))
-            elif ndim == 3:
-                self.views[name + ".weight"] = (off, (rows, cin, 1), (ks, 1, 1))
-            else:
-                self.views[name + ".weight"] = (off, (rows, cin), (ks, 1))
-            off = _round_up(off + rows * taps * ks, ALIGN)
-            rec.b_off = off
-            self.views[name + ".bias"] = (off, (rows,), (1,))
-            off = _round_up(off + rows, ALIGN)
-            self.convs[name] = rec
-            return rec
+        self._off = off
+        add = self._add
 
         L = len(self.levels)
         for i, lv in enumerate(self.levels):
@@ -120,9 +111,7 @@ class Layout:
                 add("unet." + lv.tail_key, self.levels[i - 1].channels, lv.channels, 9, flip=True)
             else:
                 add("unet." + lv.tail_key, self.out_channels, lv.channels, 9, dg_ld=self.cout_pad, flip=True)
-        add("map_layer0", self.E, self.noise_features, 1, lin=True)
-        add("map_layer1", self.E, self.E, 1, lin=True)
-        self.numel = off
+        self.numel = self._off
         # dgrad operand buffers: [cin][taps][dg_ld]
         dg = 0
         dgl = 0
@@ -137,6 +126,24 @@ class Layout:
                 rec.dg_off = dg
                 dg += size
         self.dg_numel, self.dg_lin_numel = dg, dgl
+
+    def _add(self, name: str, rows: int, cin: int, taps: int, kstride: Optional[int] = None, lin=False, dg_ld=None, flip=False, ndim=4):
+        off = self._off
+        ks = kstride or cin
+        rec = ConvRec(name, rows, cin, ks, taps, lin=lin, dg_ld=dg_ld if dg_ld is not None else rows, flip=flip)
+        rec.w_off = off
+        if taps == 9:
+            self.views[name + ".weight"] = (off, (rows, cin, 3, 3), (9 * ks, 1, 3 * ks, ks))
+        elif ndim == 3:
+            self.views[name + ".weight"] = (off, (rows, cin, 1), (ks, 1, 1))
+        else:
+            self.views[name + ".weight"] = (off, (rows, cin), (ks, 1))
+        off = _round_up(off + rows * taps * ks, ALIGN)
+        rec.b_off = off
+        self.views[name + ".bias"] = (off, (rows,), (1,))
+        self._off = _round_up(off + rows, ALIGN)
+        self.convs[name] = rec
+        return rec
 
     @staticmethod
     def _add_block(add, b: BlockSpec):
@@ -156,6 +163,11 @@ class Tape:
         self.steps: List[Callable] = []
         self.gskip: Dict[int, torch.Tensor] = {}
         self.meta: dict = {}
+        self.progress: Optional[Callable[[int], None]] = None  # called with the lowest flat offset whose gradient is final
+
+    def done(self, off: int) -> None:
+        if self.progress is not None:
+            self.progress(off)
 
 
 class Engine:
@@ -284,6 +296,7 @@ class Engine:
             def bw(gy: torch.Tensor) -> Optional[torch.Tensor]:
                 ops.colsum(gy, self._gb(rec), rows, rec.rows, rec.rows, DTYPE_F32)
                 ops.conv_wgrad(x, gy, self._gw(rec), g, DTYPE_F32)
+                tape.done(rec.w_off)
                 if not need_dx:
                     return None
                 dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
@@ -295,14 +308,18 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, dt: int, tape: Optional[Tape] = None, noise: Optional[Tuple] = None,
-                want_dx: bool = False, nhwc_out: bool = False):
+                want_dx: bool = False, nhwc_out: bool = False, x_nhwc: Optional[torch.Tensor] = None, shape=None):
         """eps_pred = ScoreUNet(x, t).  x: (B,C,H,W) fp32 on the GPU; t: numel 1 or B.
         noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion.
         With ``tape`` every op records its backward closure (training / exact guidance)."""
         lay = self.layout
         T = TORCH_DTYPE[dt]
-        dev = x.device
-        B, C, H, W = x.shape
+        if x_nhwc is not None:  # rows already in the network's input layout (the sampler's fused window gather)
+            B, C, H, W = shape
+            dev = x_nhwc.device
+        else:
+            B, C, H, W = x.shape
+            dev = x.device
         L = len(lay.levels)
         if C != lay.in_channels:
             raise ValueError(f"expected {lay.in_channels} channels, got {C}")
@@ -313,7 +330,8 @@ class Engine:
             if lv.channels % ck:
                 raise ValueError(f"hidden_channels must be multiples of {ck} for this compute dtype")
         train = tape is not None
-        x = x.contiguous().float()
+        if x_nhwc is None:
+            x = x.contiguous().float()
         tt = t.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
         Bt = tt.numel()
         if Bt not in (1, B):
@@ -333,8 +351,11 @@ class Engine:
             dm_all = None
 
         # ---- network input -> NHWC
-        x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
-        ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
+        if x_nhwc is not None:
+            x0 = x_nhwc
+        else:
+            x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
+            ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
 
         def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None):
             rec = lay.convs[name]
@@ -372,6 +393,7 @@ class Engine:
                     da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=a1)
                     ops.colsum(da1, self._gb(r1), npix, Cc, Cc, dt)
                     ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt)
+                    tape.done(r1.w_off)
                     dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                     dx = torch.empty_like(dh0)
                     ops.ln_backward(dh0, xin, m, gy, dx, dm_all.view(-1)[b.mod_offset:], npix, Hc * Wc, Cc, ldm, LN_EPS,
@@ -408,6 +430,7 @@ class Engine:
                     ops.attention_backward(qkv, o, do, lse, delta, dqkv, B, Tn, Cc, dt)
                     ops.colsum(dqkv, self._gb(rq), npix, 3 * Cc, 3 * Cc, dt)
                     ops.conv_wgrad(hl, dqkv, self._gw(rq), gq, dt)
+                    tape.done(rq.w_off)
                     dhl = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(dqkv, self._wT(rq, dt), None, dhl, self._geom(npix, 1, 1, 3 * Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
                     dx = torch.empty_like(dhl)
@@ -424,6 +447,7 @@ class Engine:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
                 ops.colsum(gy, self._gb(rec), B * H * W, rec.rows, rec.rows, dt)
                 ops.conv_wgrad(x0, gy, self._gw(rec), g, dt)
+                tape.done(rec.w_off)
                 if not want_dx:
                     return None
                 return dgrad(rec, gy, H, W, H, W, CONV_S1, lay.cin_pad)
@@ -439,6 +463,7 @@ class Engine:
                     def bw_head(gy, xin=xin, g=g_h, rec=r_h, Hp=Hp, Wp=Wp, Hc=Hc, Wc=Wc, lvl=i - 1):
                         ops.colsum(gy, self._gb(rec), B * Hc * Wc, rec.rows, rec.rows, dt)
                         ops.conv_wgrad(xin, gy, self._gw(rec), g, dt)
+                        tape.done(rec.w_off)
                         # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
                         return dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
                     tape.steps.append(bw_head)
@@ -465,6 +490,7 @@ class Engine:
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient
                         ops.colsum(gy, self._gb(rec), B * Hu * Wu, rec.rows, rec.rows, dt)
                         ops.conv_wgrad(hl, gy, self._gw(rec), g, dt)
+                        tape.done(rec.w_off)
                         gu = dgrad(rec, gy, Hu, Wu, Hu, Wu, CONV_S1, Cc)  # gradient w.r.t. the upsampled map
                         gl = torch.empty((B * Hl * Wl, Cc), dtype=T, device=dev)
                         ops.sumpool2(gu, gl, B, Hl, Wl, Cc, dt)
@@ -481,6 +507,7 @@ class Engine:
                         gw = dict(g)
                         gw["Cout"] = rec.rows
                         ops.conv_wgrad(xin, gy, self._gw(rec), gw, dt)
+                        tape.done(rec.w_off)
                         return dgrad(rec, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                     tape.steps.append(bw_tail0)
         if train:
@@ -506,6 +533,7 @@ class Engine:
             ops.silu_backward(z, gh, gz, z.numel(), DTYPE_F32)
             ops.colsum(gz, self._gb(rec), rows, rec.rows, rec.rows, DTYPE_F32)
             ops.conv_wgrad(x, gz, self._gw(rec), g, DTYPE_F32)
+            tape.done(rec.w_off)
             if not need_dx:
                 return None
             dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)

@@ -108,6 +108,10 @@ def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, s
                                     ema_rate, grad_scale, _stream()), "c2w_adamw_ema")
 
 
+def ema_update(ema, p, n, rate):
+    check(_lib.load().c2w_ema_update(_p(ema), _p(p), n, rate, _stream()), "c2w_ema_update")
+
+
 def attention_forward(qkv, o, lse, B, T, C, dtype):
     check(_lib.load().c2w_attention_forward(_p(qkv), _p(o), _p(lse), B, T, C, dtype, _stream()), "c2w_attention_forward")
 
@@ -115,3 +119,29 @@ def attention_forward(qkv, o, lse, B, T, C, dtype):
 def attention_backward(qkv, o, d_o, lse, delta_ws, dqkv, B, T, C, dtype):
     check(_lib.load().c2w_attention_backward(_p(qkv), _p(o), _p(d_o), _p(lse), _p(delta_ws), _p(dqkv), B, T, C, dtype, _stream()),
           "c2w_attention_backward")
+
+
+def window_gather(x, y, nw, F, HW, k, i0, ldc, dtype):
+    check(_lib.load().c2w_window_gather(_p(x), _p(y), nw, F, HW, k, i0, ldc, dtype, _stream()), "c2w_window_gather")
+
+
+def window_scatter(y, eps, nw, F, HW, k, i0, nwin_total, ldc, dtype):
+    check(_lib.load().c2w_window_scatter(_p(y), _p(eps), nw, F, HW, k, i0, nwin_total, ldc, dtype, _stream()), "c2w_window_scatter")
+
+
+def sampler_predict(x, eps, nan_flag, n, a, b):
+    check(_lib.load().c2w_sampler_predict(_p(x), _p(eps), _p(nan_flag), n, a, b, _stream()), "c2w_sampler_predict")
+
+
+def sumsq(v, out, n):
+    check(_lib.load().c2w_sumsq(_p(v), _p(out), n, _stream()), "c2w_sumsq")
+
+
+def sampler_correct(x, eps, z, sumsq_buf, nan_flag, n, tau, sigma_next):
+    check(_lib.load().c2w_sampler_correct(_p(x), _p(eps), _p(z), _p(sumsq_buf), _p(nan_flag), n, tau, sigma_next, _stream()),
+          "c2w_sampler_correct")
+
+
+def guidance(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma):
+    check(_lib.load().c2w_guidance(_p(x), _p(eps), _p(yobs), _p(stdv), nobs, F, H, W, s_step, t_step, mu, sigma, gamma, _stream()),
+          "c2w_guidance")

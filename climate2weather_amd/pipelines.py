@@ -1,0 +1,125 @@
+"""Drop-in for ``thor.pipelines.SDAPipeline`` (src/thor/pipelines.py:8-97): VP-cosine noise process, epsilon-MSE
+loss and the predictor(-corrector) sampler.
+
+``pipeline_kwargs.class_name`` (train.py:184) can point here.  Same methods and signatures.  The sampler keeps
+the trajectory on the GPU and uses the fused HIP update kernels (csrc/sampler.hip) whenever the score function is
+one of ``climate2weather_amd.score_fn``'s; with any other callable it runs the same update rule with torch ops on
+whatever device the state lives on.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class SDAPipeline:
+    def __init__(self, eta: float = 1e-3):
+        self.eta = eta  # numerical-stability floor of the schedule (src/thor/pipelines.py:9-11)
+
+    # ---- schedule (src/thor/pipelines.py:13-20)
+    def alpha(self, t):
+        return torch.cos(math.acos(math.sqrt(self.eta)) * t) ** 2
+
+    def mu(self, t):
+        return self.alpha(t)
+
+    def sigma(self, t):
+        return (1 - self.alpha(t) ** 2 + self.eta**2).sqrt()
+
+    def _mu_sigma_f(self, t: float):
+        a = math.cos(math.acos(math.sqrt(self.eta)) * t) ** 2
+        return a, math.sqrt(1 - a * a + self.eta**2)
+
+    # ---- training side (src/thor/pipelines.py:22-35)
+    def forward(self, x, t):
+        eps = torch.randn_like(x)
+        return self.mu(t) * x + self.sigma(t) * eps, eps
+
+    def loss(self, net, x, forcing=None):
+        t = torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device)
+        xt, eps = self.forward(x, t)
+        eps_pred = net(xt, t, forcing=forcing)
+        return (eps_pred - eps) ** 2
+
+    def pred_eps(self, score_fn, x, t):
+        return score_fn(x, t)
+
+    # ---- sampling side (src/thor/pipelines.py:41-97)
+    def _sample_step(self, score_fn, x, t, dt, proc_x0=None):
+        eps_pred = self.pred_eps(score_fn, x, t)
+        pred_x0 = (x - self.sigma(t) * eps_pred) / self.mu(t)
+        if proc_x0 is not None:
+            pred_x0 = proc_x0(pred_x0)
+        return self.mu(t - dt) * pred_x0 + self.sigma(t - dt) * eps_pred
+
+    def sample(self, score_fn, noise, steps: int = 64, corrections: int = 0, tau: float = 1.0, proc_x0=None, device=None,
+               show_progressbar: bool = True, z_draws=None):
+        """Same contract as the reference.  ``device=None`` follows the reference's default (CPU-resident state) unless the
+        score function is device-resident, in which case the state stays on its GPU.  ``z_draws`` (extension, tests):
+        iterable of corrector normals to use instead of drawing them."""
+        fused = getattr(score_fn, "device_resident", False) and proc_x0 is None
+        if device is None:
+            device = score_fn.device if fused else torch.device("cpu")
+        device = torch.device(device)
+        fused = fused and device.type == "cuda"
+        shape = noise.shape
+        x = noise.to(device=device).clone() if fused else noise.to(device=device)
+        time_steps = torch.linspace(1, 0, steps + 1).to(dtype=x.dtype, device=device)
+        dt = 1 / steps
+        start = time.time()
+        zs = iter(z_draws) if z_draws is not None else None
+        z = torch.empty_like(x) if corrections > 0 else None
+        nan_flag = torch.zeros(1, dtype=torch.int32, device=device) if fused else None
+        sumsq = torch.zeros(1, dtype=torch.float32, device=device) if fused and corrections > 0 else None
+        ts_host = torch.linspace(1, 0, steps + 1).tolist()
+        iterator = range(steps)
+        if show_progressbar:
+            try:
+                from tqdm.auto import tqdm
+                iterator = tqdm(iterator, desc="Sampling")
+            except Exception:  # pragma: no cover
+                pass
+        with torch.no_grad():
+            for i in iterator:
+                t = time_steps[i]
+                if fused:
+                    tf = ts_host[i]
+                    t = torch.tensor(tf, dtype=torch.float32)  # host scalar: no device->host sync per step
+                    x = x.float().contiguous()
+                    eps = score_fn(x, t)
+                    mu_t, sg_t = self._mu_sigma_f(tf)
+                    mu_n, sg_n = self._mu_sigma_f(tf - dt)
+                    n = x.numel()
+                    ops.sampler_predict(x, eps, nan_flag, n, mu_n / mu_t, sg_n - mu_n * sg_t / mu_t)
+                    for _ in range(corrections):
+                        if zs is not None:
+                            z.copy_(next(zs))
+                        else:
+                            z.normal_()
+                        eps = score_fn(x, t - dt)
+                        sumsq.zero_()
+                        ops.sumsq(eps, sumsq, n)
+                        ops.sampler_correct(x, eps, z, sumsq, nan_flag, n, tau, sg_n)
+                else:
+                    x = self._sample_step(score_fn, x, t, dt, proc_x0=proc_x0)
+                    for _ in range(corrections):
+                        if zs is not None:
+                            z.copy_(next(zs))
+                        else:
+                            z.normal_()
+                        eps = score_fn(x, t - dt)
+                        delta = tau / eps.square().mean(dim=tuple(range(-len(shape), 0)), keepdim=True)
+                        x = x - (delta * eps + torch.sqrt(2 * delta) * z) * self.sigma(t - dt)
+                        del eps
+                    if torch.isnan(x).any():
+                        raise ValueError("NaN detected in sample")
+        if fused and int(nan_flag.item()) != 0:  # one host sync per trajectory instead of one per step
+            raise ValueError("NaN detected in sample")
+        total = time.time() - start
+        print(f"Total sampling time: {total:.2f} s  = {total / 60:.3f} min = {total / 3600:.4f} h")
+        return x.reshape(shape)

@@ -1,0 +1,192 @@
+"""The training step of the reference (training_loop.py:369-391) on the MI355X engine.
+
+    zero_grad -> [accumulation rounds: loss = pipeline.loss(net, data).mean(); backward] -> lr -> AdamW -> EMA
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL on ROCm).  What differs from the reference below
+the API:
+  * noise process, network forward, loss, and the whole backward are the engine's HIP sequences (no autograd graph);
+  * gradients live in ONE flat fp32 buffer laid out in reverse finalisation order; while backward is still running,
+    finished buckets of it are all-reduced over xGMI on RCCL's stream (replaces Lightning Fabric's DDP wrapper,
+    training_loop.py:116,375-378) -- a sum; the 1/world_size mean is folded into the optimizer kernel;
+  * AdamW (train.py:176-181) + EMA (src/thor/ema.py:23-27) + the bf16 weight shadow refresh are one fused kernel.
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .engine import Tape
+from .ops import DTYPE_BF16, DTYPE_F32, TORCH_DTYPE
+from .pipelines import SDAPipeline
+
+
+class Trainer:
+    def __init__(self, net, pipeline: Optional[SDAPipeline] = None, *, lr: float = 1e-4, lr_fn: Optional[Callable[[int], float]] = None,
+                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-3, ema_rates: Sequence[float] = (0.9999,),
+                 precision: str = "bf16", batch_size: Optional[int] = None, loss_scaling: float = 1.0,
+                 process_group=None, bucket_mb: float = 48.0):
+        self.net = net
+        self.pipeline = pipeline or SDAPipeline()
+        self.lr, self.lr_fn = lr, lr_fn
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.ema_rates = list(ema_rates)
+        self.dt = DTYPE_BF16 if precision == "bf16" else DTYPE_F32
+        self.loss_scaling = loss_scaling
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.batch_size = batch_size  # global batch (items per optimizer step); None -> B_gpu * world
+        self.cur_ndata = 0
+        self.step_count = 0
+        eng = net._get_engine()
+        self.eng = eng
+        eng.ensure_grad_buffer(net, bind=True)
+        n = eng.layout.numel
+        dev = eng.flat.device
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ema_flats = [eng.flat.clone() for _ in self.ema_rates]
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self.world > 1:  # same initial weights everywhere (DDP's initial broadcast)
+            dist.broadcast(eng.flat, src=0, group=self.pg)
+            eng.weights_changed()
+            for e in self.ema_flats:
+                e.copy_(eng.flat)
+        # all-reduce buckets over the flat gradient buffer, last bucket = first finalised
+        per = max(int(bucket_mb * (1 << 20) // 4), 1)
+        self.buckets: List[tuple] = []
+        end = n
+        while end > 0:
+            start = max(0, end - per)
+            self.buckets.append((start, end))
+            end = start
+        self._works: list = []
+        self._next_bucket = 0
+
+    # ------------------------------------------------------------------ gradient all-reduce, overlapped with backward
+    def _on_progress(self, off: int) -> None:
+        while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off:
+            s, e = self.buckets[self._next_bucket]
+            self._works.append(dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._next_bucket += 1
+
+    def _finish_allreduce(self) -> None:
+        self._on_progress(0)
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        self._next_bucket = 0
+
+    # ------------------------------------------------------------------ one optimizer step
+    def step(self, batches, t: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``batches``: one (B,C,H,W) fp32 GPU tensor, or a list of them = gradient-accumulation rounds
+        (training_loop.py:373-378: gradients of the rounds are summed, only the last round synchronises).
+        ``t`` (B,) and ``eps`` (B,C,H,W) may be injected (tests); otherwise drawn as src/thor/pipelines.py:29-31 does.
+        Returns the last round's loss (device scalar, like the value the reference logs)."""
+        if isinstance(batches, torch.Tensor):
+            batches = [batches]
+        eng = self.eng
+        eng.flat_grad.zero_()
+        loss = None
+        for r, x in enumerate(batches):
+            last = r == len(batches) - 1
+            loss = self._forward_backward(x, t if last or t is None else None, eps if last or eps is None else None,
+                                          sync=last and self.world > 1)
+        if self.world > 1:
+            self._finish_allreduce()
+        lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
+        self.step_count += 1
+        n = eng.layout.numel
+        shadow = eng.shadow if self.dt == DTYPE_BF16 else None
+        if self.dt == DTYPE_BF16 and shadow is None:
+            eng._w(next(iter(r for r in eng.layout.convs.values() if not r.lin)), DTYPE_BF16)
+            shadow = eng.shadow
+        ops.adamw_ema(eng.flat, eng.flat_grad, self.m, self.v, self.ema_flats[0] if self.ema_flats else None, shadow, n, float(lr),
+                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                      float(self.ema_rates[0]) if self.ema_rates else 0.0, 1.0 / self.world)
+        for rate, e in zip(self.ema_rates[1:], self.ema_flats[1:]):
+            ops.ema_update(e, eng.flat, n, float(rate))
+        eng.weights_changed(shadow_fresh=shadow is not None)
+        B = sum(b.shape[0] for b in batches)
+        self.cur_ndata += self.batch_size if self.batch_size is not None else B * self.world
+        return loss
+
+    def _forward_backward(self, x, t, eps, sync: bool) -> torch.Tensor:
+        eng, lay = self.eng, self.eng.layout
+        B, C, H, W = x.shape
+        dev = x.device
+        if t is None:
+            t = torch.rand(B, dtype=torch.float32, device=dev)
+        if eps is None:
+            eps = torch.randn_like(x)
+        t = t.reshape(-1).to(dev).float().contiguous()
+        eps = eps.contiguous()
+        musig = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        ops.mu_sigma(t, musig, B, self.pipeline.eta)
+        tape = Tape()
+        if sync:
+            tape.progress = self._on_progress
+        y = eng.forward(x, t, self.dt, tape=tape, noise=(eps, musig), nhwc_out=True)
+        dy = torch.empty_like(y)
+        self.loss_sum.zero_()
+        n = B * C * H * W
+        ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, 2.0 * self.loss_scaling / n, self.dt)
+        eng.backward(tape, dy)
+        return self.loss_sum[0] * (self.loss_scaling / n)
+
+    # ------------------------------------------------------------------ EMA access / state
+    def ema_state_dicts(self):
+        """[(rate, state_dict)] with the reference's key names (snapshot export, training_loop.py:250-265)."""
+        out = []
+        for rate, flat in zip(self.ema_rates, self.ema_flats):
+            sd = {}
+            for name, (off, shape, strides) in self.eng.layout.views.items():
+                sd[name] = torch.as_strided(flat, shape, strides, off).clone()
+            out.append((rate, {k: sd[k] for k in self.net.state_dict().keys()}))
+        return out
+
+    def state_dict(self):
+        """Same content as the reference's training-state checkpoint (src/thor/checkpoint.py:13-35): progress, network,
+        optimizer moments, EMA."""
+        return dict(state=dict(cur_ndata=self.cur_ndata, step_count=self.step_count), net=self.net.state_dict(),
+                    optimizer=dict(m=self.m, v=self.v, step=self.step_count),
+                    ema=dict(rates=self.ema_rates, flats=self.ema_flats), pipeline=dict(eta=self.pipeline.eta))
+
+    def load_state_dict(self, sd):
+        self.net.load_state_dict(sd["net"])
+        self.eng = self.net._get_engine()
+        self.eng.weights_changed()
+        self.m.copy_(sd["optimizer"]["m"])
+        self.v.copy_(sd["optimizer"]["v"])
+        self.step_count = int(sd["optimizer"]["step"])
+        self.cur_ndata = int(sd["state"]["cur_ndata"])
+        for e, s in zip(self.ema_flats, sd["ema"]["flats"]):
+            e.copy_(s)
+
+
+CKPT_RE = re.compile(r"training-state-(\d+).ckpt")
+
+
+def save_checkpoint(trainer: Trainer, run_dir: str) -> str:
+    """``training-state-{kdata:07d}.ckpt`` as training_loop.py:353-363 names it."""
+    path = os.path.join(run_dir, f"training-state-{trainer.cur_ndata // 1000:07d}.ckpt")
+    torch.save(trainer.state_dict(), path)
+    return path
+
+
+def load_latest_checkpoint(trainer: Trainer, run_dir: str) -> Optional[str]:
+    """src/thor/checkpoint.py:61-79: pick the highest-numbered training-state file."""
+    best = None
+    for f in os.listdir(run_dir) if os.path.isdir(run_dir) else []:
+        m = CKPT_RE.fullmatch(f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None
+    path = os.path.join(run_dir, best[1])
+    trainer.load_state_dict(torch.load(path, map_location=trainer.eng.flat.device, weights_only=False))
+    return path

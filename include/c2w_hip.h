@@ -103,11 +103,33 @@ int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void
                   float beta1, float beta2, float eps, float weight_decay, int step, float ema_rate, float grad_scale,
                   void* stream);
 
+/* p_ema = rate * p_ema + (1 - rate) * p over a flat buffer (src/thor/ema.py:23-27) */
+int c2w_ema_update(float* ema, const float* p, long long n, float rate, void* stream);
+
 /* QKVAttention, one head (model/nn.py:62-85).  qkv: [B][T][3C] (q|k|v), o: [B][T][C], lse: [B][T] fp32 (may be NULL
  * for inference).  backward recomputes probabilities from lse; delta_ws is a [B][T] fp32 scratch. */
 int c2w_attention_forward(const void* qkv, void* o, float* lse, int B, int T, int C, int dtype, void* stream);
 int c2w_attention_backward(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
                            int B, int T, int C, int dtype, void* stream);
+
+/* ---- device-resident sampler (replaces the CPU-resident state + per-batch PCIe round trips of
+ * src/thor/score.py:156-185 and the elementwise updates of src/thor/pipelines.py:41-91) ---- */
+/* unfold, src/thor/score.py:68-74: windows i0..i0+nw-1 of x[L][F][HW] (fp32) -> NHWC rows [nw*HW][ldc], channel = tau*F + c */
+int c2w_window_gather(const float* x, void* y, int nw, int F, int HW, int k, int i0, int ldc, int dtype, void* stream);
+/* fold, src/thor/score.py:76-88: centre frame of every window (+ leading k of window 0, trailing k of the last) -> eps[L][F][HW] */
+int c2w_window_scatter(const void* y, float* eps, int nw, int F, int HW, int k, int i0, int nwin_total, int ldc,
+                       int dtype, void* stream);
+/* predictor, src/thor/pipelines.py:41-46: x = a*x + b*eps with a = mu'/mu, b = sigma' - mu' sigma/mu; non-finite -> *nan_flag |= 1 */
+int c2w_sampler_predict(float* x, const float* eps, int* nan_flag, long long n, float a, float b, void* stream);
+/* out[0] += sum v^2 */
+int c2w_sumsq(const float* v, float* out, long long n, void* stream);
+/* corrector, src/thor/pipelines.py:81-88: delta = tau/(sumsq[0]/n); x -= (delta eps + sqrt(2 delta) z) sigma_next */
+int c2w_sampler_correct(float* x, const float* eps, const float* z, const float* sumsq, int* nan_flag, long long n,
+                        float tau, float sigma_next, void* stream);
+/* likelihood guidance for A = AvgPool2d(s_step) o x[::t_step] (exp/downscaling.py:129-132) with exact_grad=False
+ * (src/thor/score.py:24-57): eps -= sigma/mu * A^T((y - A((x - sigma eps)/mu)) / (std_c^2 + gamma (sigma/mu)^2)), in place */
+int c2w_guidance(const float* x, float* eps, const float* yobs, const float* stdv, int nobs, int F, int H, int W,
+                 int s_step, int t_step, float mu, float sigma, float gamma, void* stream);
 
 /* library identity: returns the gfx target string the kernels were compiled for ("gfx950") */
 const char* c2w_target(void);

@@ -1,0 +1,35 @@
+"""Worker for the world_size-2 gloo test of the gradient all-reduce path (CPU, HIP launchers replaced by tests/emu_ops)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_mb: float):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import emu_ops
+    from climate2weather_amd import ops as c2w_ops
+    for name in emu_ops.ALL:
+        if hasattr(c2w_ops, name):
+            setattr(c2w_ops, name, getattr(emu_ops, name))
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+
+    g = np.load(os.path.join(golden_dir, "tiny_net.npz"))
+    torch.manual_seed(3 + 100 * rank)  # different initial weights per rank: the trainer must broadcast rank 0's
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    tr = Trainer(net, lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=bucket_mb)
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    sl = slice(rank, rank + 1)  # global batch 2 -> one item per rank
+    loss = tr.step(x[sl].contiguous(), t=t[sl].reshape(-1), eps=eps[sl].contiguous())
+    torch.save(dict(loss=float(loss), sd={k: v.clone() for k, v in net.state_dict().items()}, nb=len(tr.buckets)),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

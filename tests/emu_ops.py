@@ -206,6 +206,10 @@ def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, s
         shadow.reshape(-1)[:n] = P.to(torch.bfloat16)
 
 
+def ema_update(ema, p, n, rate):
+    ema.reshape(-1)[:n].mul_(rate).add_(p.reshape(-1)[:n], alpha=1 - rate)
+
+
 def _attn(qkv, B, T, C):
     q, k, v = _rows(qkv, B * T, 3 * C).view(B, T, 3 * C).split(C, dim=-1)
     s = torch.einsum("btc,bsc->bts", q, k) / math.sqrt(C)
@@ -227,6 +231,57 @@ def attention_backward(qkv, o, d_o, lse, delta_ws, dqkv, B, T, C, dtype):
         oo, _ = _attn(q, B, T, C)
         (g,) = torch.autograd.grad(oo, q, _rows(d_o, B * T, C).float().view(B, T, C))
     _rows(dqkv, B * T, 3 * C)[:] = g.to(TD[dtype])
+
+
+def window_gather(x, y, nw, F, HW, k, i0, ldc, dtype):
+    w = 2 * k + 1
+    X = x.reshape(-1)
+    Y = _rows(y, nw * HW, ldc)
+    Y[:] = 0
+    for j in range(nw):
+        win = X[(i0 + j) * F * HW: (i0 + j + w) * F * HW].view(w * F, HW)
+        Y[j * HW:(j + 1) * HW, : w * F] = win.t().to(TD[dtype])
+
+
+def window_scatter(y, eps, nw, F, HW, k, i0, nwin_total, ldc, dtype):
+    w = 2 * k + 1
+    Y = _rows(y, nw * HW, ldc).float().view(nw, HW, ldc)
+    Ev = eps.reshape(-1)
+    for j in range(nw):
+        gi = i0 + j
+        for tau in range(w):
+            if tau == k or (gi == 0 and tau < k) or (gi == nwin_total - 1 and tau > k):
+                Ev[(gi + tau) * F * HW:(gi + tau + 1) * F * HW] = Y[j, :, tau * F:(tau + 1) * F].t().reshape(-1)
+
+
+def sampler_predict(x, eps, nan_flag, n, a, b):
+    X = x.reshape(-1)[:n]
+    X.mul_(a).add_(eps.reshape(-1)[:n], alpha=b)
+    if nan_flag is not None and not torch.isfinite(X).all():
+        nan_flag.reshape(-1)[0] |= 1
+
+
+def sumsq(v, out, n):
+    out.reshape(-1)[0] += v.reshape(-1)[:n].float().square().sum()
+
+
+def sampler_correct(x, eps, z, sumsq_buf, nan_flag, n, tau, sigma_next):
+    delta = tau / (sumsq_buf.reshape(-1)[0] / n)
+    X = x.reshape(-1)[:n]
+    X.sub_((delta * eps.reshape(-1)[:n] + torch.sqrt(2 * delta) * z.reshape(-1)[:n]) * sigma_next)
+    if nan_flag is not None and not torch.isfinite(X).all():
+        nan_flag.reshape(-1)[0] |= 1
+
+
+def guidance(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma):
+    L = x.numel() // (F * H * W)
+    X = x.reshape(-1)[: L * F * H * W].view(L, F, H, W)
+    Ev = eps.reshape(-1)[: L * F * H * W].view(L, F, H, W)
+    x0 = (X[::t_step][:nobs] - sigma * Ev[::t_step][:nobs]) / mu
+    err = yobs.reshape(nobs, F, H // s_step, W // s_step) - torch.nn.functional.avg_pool2d(x0, s_step)
+    var = stdv.reshape(1, F, 1, 1) ** 2 + gamma * (sigma / mu) ** 2
+    g = (err / var).repeat_interleave(s_step, 2).repeat_interleave(s_step, 3) / (s_step * s_step)
+    Ev[::t_step][:nobs] -= sigma * g / mu
 
 
 ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("F",)]
