@@ -178,26 +178,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-// out[c] += sum over rows of a[row][c]   (bias gradients)
+// out[c] += sum over rows of a[row][c]   (bias gradients).  Consecutive threads read consecutive 16-B vectors of a row
+// (coalesced); row groups are combined through LDS and each block issues one contiguous atomic sweep.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, float* __restrict__ out, long long rows, int C, int lda,
                                                      int rows_per_block) {
     constexpr int P = Elem<T>::PER16;
-    const int nvec = C / P;  // 16-B vectors per row
+    __shared__ float red[256 * P];
+    const int vbase = blockIdx.y * 256;              // this block's slice of the row: up to 256 vectors of 16 B
+    const int nvec = (C / P - vbase) < 256 ? (C / P - vbase) : 256;
+    a += (size_t)vbase * P;
+    out += (size_t)vbase * P;
+    C = nvec * P;
+    const int ngrp = 256 / nvec;
+    const int vec = threadIdx.x % nvec, grp = threadIdx.x / nvec;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
-    for (int vec = threadIdx.x; vec < nvec; vec += blockDim.x) {
-        float acc[P];
+    float acc[P];
 #pragma unroll
-        for (int e = 0; e < P; ++e) acc[e] = 0.f;
-        for (long long r = r0; r < r1; ++r) {
+    for (int e = 0; e < P; ++e) acc[e] = 0.f;
+    if (grp < ngrp) {
+        for (long long r = r0 + grp; r < r1; r += ngrp) {
             float f[P];
             unpack16<T>(*(const u32x4_t*)(a + r * lda + vec * P), f);
 #pragma unroll
             for (int e = 0; e < P; ++e) acc[e] += f[e];
         }
 #pragma unroll
-        for (int e = 0; e < P; ++e) atomicAdd(out + vec * P + e, acc[e]);
+        for (int e = 0; e < P; ++e) red[(grp * nvec + vec) * P + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < ngrp; ++g) s += red[g * C + c];
+        atomicAdd(out + c, s);
     }
 }
 
@@ -444,8 +458,9 @@ extern "C" int c2w_ln_backward(const void* dy, const void* x, const float* m, co
 
 extern "C" int c2w_colsum(const void* a, float* out, long long rows, int C, int lda, int dtype, void* stream) {
     if (!a || !out || !vec_ok(dtype, C) || !vec_ok(dtype, lda)) return C2W_ERR_BAD_SHAPE;
-    const int rpb = 128;
-    const int grid = (int)((rows + rpb - 1) / rpb);
+    const int rpb = 2048;
+    const int nvec_total = C / (dtype == C2W_DTYPE_F32 ? 4 : 8);
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((nvec_total + 255) / 256));
     DISPATCH_T(dtype, (colsum_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)a, out, rows, C, lda, rpb)));
     return (int)hipGetLastError();
 }

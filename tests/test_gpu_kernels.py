@@ -155,6 +155,13 @@ def test_pointwise_family(dt):
     ops.colsum(a, out, rows, C, lda, dt)
     E.colsum(a, out_ref, rows, C, lda, dt)
     close(out, out_ref, dt, "colsum", tol=1e-4 if dt == F32 else 1e-3)
+    for rows2, C2 in ((5, 8448), (3000, 384), (70000, 64)):  # wide rows (modulation bias), odd vector counts, many blocks
+        a2 = rnd((rows2, C2), dt, 7)
+        o2 = torch.zeros(C2, device=d)
+        o2_ref = o2.clone()
+        ops.colsum(a2, o2, rows2, C2, C2, dt)
+        E.colsum(a2, o2_ref, rows2, C2, C2, dt)
+        close(o2, o2_ref, dt, f"colsum {rows2}x{C2}", tol=1e-4 if dt == F32 else 2e-3)
     n = 4096 * 8
     x = rnd((n,), dt, 2, scale=3.0)
     dy = rnd((n,), dt, 3)
