@@ -27,6 +27,7 @@ constexpr int BN = 128;       // output channels per block tile
 constexpr int NTHREADS = 512;
 constexpr int PBYTES = BM * 128;  // one pixel-tile stage  (32 KiB)
 constexpr int WBYTES = BN * 128;  // one weight-tile stage (16 KiB)
+constexpr int NSLOT = 3;          // ring depth (3 x 48 KiB = 144 KiB of the CU's 160 KiB LDS)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -48,8 +49,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
     constexpr int CK = 128 / ESZ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // 3-slot ring of (pixel tile, weight tile) stages: loads run two stages ahead of the MFMAs
     char* const Pbuf = smem;
-    char* const Wbuf = smem + 2 * PBYTES;
+    char* const Wbuf = smem + NSLOT * PBYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,12 +144,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     issue(0, 0);
+    if (NS > 1) issue(1, 1);
+    int slot = 0;
     for (int s = 0; s < NS; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage s landed for every wave; every wave is done reading ring slot (s+1)&1
-        if (s + 1 < NS) issue(s + 1, (s + 1) & 1);
-        const char* const Pb = Pbuf + (s & 1) * PBYTES;
-        const char* const Wb = Wbuf + (s & 1) * WBYTES;
+        // each wave issues 6 LDS-DMA loads per stage: all but the youngest 6 retired <=> stage s has landed
+        if (s + 1 < NS) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // stage s landed for every wave; every wave is done reading slot (s+2)%3 (= stage s-1)
+        if (s + 2 < NS) issue(s + 2, slot >= 1 ? slot - 1 : NSLOT - 1);
+        const char* const Pb = Pbuf + slot * PBYTES;
+        const char* const Wb = Wbuf + slot * WBYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4_t a[4], b[4];
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
 #pragma unroll
                 for (int n = 0; n < 4; ++n) Mma<T>::run(a[m], b[n], acc[m][n]);
         }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
 
     // ---- epilogue: bias/activation in registers -> LDS tile [pixel][channel] -> coalesced 16-B NHWC stores
@@ -263,7 +273,7 @@ int launch_mode(const C2wConvArgs& a, int naive, hipStream_t st) {
         return (int)hipGetLastError();
     }
     constexpr int ESZ = sizeof(T);
-    constexpr int lds = (2 * PBYTES + 2 * WBYTES) > BM * (BN * ESZ + 16) ? (2 * PBYTES + 2 * WBYTES) : BM * (BN * ESZ + 16);
+    constexpr int lds = NSLOT * (PBYTES + WBYTES) > BM * (BN * ESZ + 16) ? NSLOT * (PBYTES + WBYTES) : BM * (BN * ESZ + 16);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -20,6 +20,7 @@ constexpr int KT = 64;  // pixels per stage
 constexpr int NTHREADS = 512;
 constexpr int ABYTES = KT * 256;  // dY stage  (16 KiB)
 constexpr int BBYTES = KT * 512;  // X stage   (32 KiB)
+constexpr int NSLOT = 3;          // stage ring depth: loads run two stages ahead of the MFMAs
 
 struct WgradArgs {
     const void* dy;  // [npix][ldy]
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
     constexpr int NTL = MT;                 // and along N (one column block per wave)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Abuf = smem;
-    char* const Bbuf = smem + 2 * ABYTES;
+    char* const Bbuf = smem + NSLOT * ABYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,11 +162,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
     }
 
     if (kt0 < kt1) issue(kt0, 0);
+    if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+    int buf = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
+        // 6 LDS-DMA loads per wave per stage: all but the youngest 6 retired <=> this stage has landed
+        if (kt + 1 < kt1) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < kt1) issue(kt + 2, buf >= 1 ? buf - 1 : NSLOT - 1);
         const char* const Ab = Abuf + buf * ABYTES;
         const char* const Bb = Bbuf + buf * BBYTES;
         if constexpr (ESZ == 2) {
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
                     for (int n = 0; n < NTL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
             }
         }
+        buf = buf + 1 == NSLOT ? 0 : buf + 1;
     }
 
     // ---- epilogue: tile -> LDS [co][column] fp32 -> atomics, one (co, column block) row per wave instruction
@@ -265,7 +273,7 @@ int launch(const C2wConvArgs& a, float* dw, hipStream_t st) {
     p.nsplit = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
     p.div_hw = make_div((uint32_t)(a.Hout * a.Wout));
     p.div_w = make_div((uint32_t)a.Wout);
-    constexpr int lds_main = 2 * ABYTES + 2 * BBYTES;
+    constexpr int lds_main = NSLOT * (ABYTES + BBYTES);
     constexpr int lds_epi = COT * (4 * CIB + 4) * 4;
     constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
     static bool attr_set = false;
