@@ -13,6 +13,8 @@ p = argparse.ArgumentParser()
 p.add_argument("--batch", type=int, default=32)
 p.add_argument("--iters", type=int, default=10)
 p.add_argument("--dtypes", default="bf16,fp32")
+p.add_argument("--only", type=int, default=-1, help="run only SHAPES[i]")
+p.add_argument("--kind", default="conv,wgrad,ln")
 a = p.parse_args()
 dev = torch.device("cuda:0")
 
@@ -38,7 +40,9 @@ for dname in a.dtypes.split(","):
     dt = ops.DTYPE_BF16 if dname == "bf16" else ops.DTYPE_F32
     T = ops.TORCH_DTYPE[dt]
     B = a.batch if dt == ops.DTYPE_BF16 else max(1, a.batch // 8)
-    for mode, H, Cin, Cout in SHAPES:
+    for si, (mode, H, Cin, Cout) in enumerate(SHAPES):
+        if a.only >= 0 and si != a.only:
+            continue
         Ho = H // 2 if mode == ops.CONV_S2 else (H * 2 if mode == ops.CONV_UP else H)
         g = dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=Ho, Wout=Ho, Cout=Cout, ldy=Cout, wrows=Cout, mode=mode)
         x = torch.randn(B * H * H, Cin, device=dev).to(T)
@@ -47,10 +51,14 @@ for dname in a.dtypes.split(","):
         y = torch.empty(B * Ho * Ho, Cout, device=dev, dtype=T)
         dw = torch.zeros(Cout * 9 * Cin, device=dev)
         flops = 2.0 * B * Ho * Ho * Cout * 9 * Cin
-        ms = timeit(lambda: ops.conv(x, w, bias, y, g, dt, act=ops.ACT_SILU), a.iters)
-        print(f"conv   {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
-        ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt), a.iters)
-        print(f"wgrad  {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        if "conv" in a.kind:
+          ms = timeit(lambda: ops.conv(x, w, bias, y, g, dt, act=ops.ACT_SILU), a.iters)
+          print(f"conv   {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        if "wgrad" in a.kind:
+          ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt), a.iters)
+          print(f"wgrad  {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    if "ln" not in a.kind:
+        continue
     # memory-bound kernels
     npix, C = B * 128 * 128, 128
     x = torch.randn(npix, C, device=dev).to(T)
