@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libc2w_hip.so")
+LIB_PATH = os.environ.get("C2W_LIB") or os.path.join(HERE, "libc2w_hip.so")  # C2W_LIB: diagnostic builds only
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
@@ -33,7 +33,7 @@ class ConvArgs(Structure):
 # name -> argtypes (every function returns int status except c2w_target)
 _PROTOS = {
     "c2w_conv_forward": [POINTER(ConvArgs), c_int, c_int, c_void_p],
-    "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_int, c_void_p],
+    "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_void_p],
     "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,
                         c_int, c_void_p],

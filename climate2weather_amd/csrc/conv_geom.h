@@ -32,3 +32,7 @@ struct FastDiv {
     uint32_t magic, shift;
 };
 __device__ __forceinline__ int fast_div(int n, FastDiv d) { return d.magic ? (int)(__umulhi((uint32_t)n, d.magic) >> d.shift) : n; }
+
+// halo-patch kernel for 3x3 stride-1 convolutions on 16x16-tileable images (conv_patch.hip)
+bool c2w_conv_patch_eligible(const C2wConvArgs& a);
+int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st);

@@ -1,0 +1,306 @@
+// Halo-patch implicit GEMM for the 3x3 stride-1 convolutions (the 60 res-block convs and their input gradients:
+// 98.8 of the 116 GFLOP forward, model/nn.py:155,157) on gfx950.
+//
+// Why a second kernel: PMC on the gather kernel (profiles/r01_pmc_conv_gather_b32.md) shows ~290 non-MFMA
+// instructions per 32 MFMAs per wave -- per-tap gather address arithmetic and scalar loop overhead -- so the wave's
+// in-order issue stream, not the matrix pipe / LDS / HBM, set the time.  Here
+//   * a block owns a 16x16 output tile of one image and stages the (16+2)x(16+2) input halo patch ONCE per K-chunk
+//     (128 B of channels per pixel); all 9 taps read it from LDS -> each input pixel is fetched once, not 9 times;
+//   * the 9 taps are unrolled: the patch row pitch is 24 pixels (a multiple of 8), so the XOR swizzle of a fragment
+//     read depends only on (lane, kw) and every LDS address is  register + immediate  -- no per-stage VALU;
+//   * per stage (one tap of one chunk) a wave issues 2 weight pieces + at most 1 patch piece of LDS-DMA
+//     (patch of the NEXT chunk trickles in during taps 0..6), counted vmcnt, one raw s_barrier;
+//   * weights ring: 3 slots of [128 co][128 B]; slot = tap % 3 is a compile-time constant.
+// Same MFMA tiling as conv_igemm.hip: 256 px x 128 co per block, 8 waves x (4x4) 16x16 tiles, A = weights, B = pixels.
+#include "conv_geom.h"
+
+namespace {
+
+constexpr int NTHREADS = 512;
+constexpr int PW = 24;                    // patch row pitch in pixels (18 used)
+constexpr int PROW = PW * 128;            // bytes per patch row
+constexpr int NPIECE = 18 * 3;            // 1 KiB LDS-DMA pieces (8 pixels each) per patch
+constexpr int PBYTES = NPIECE * 1024;     // 55,296
+constexpr int WBYTES = 128 * 128;         // one tap's weight tile: 128 co x 128 B
+constexpr int WBASE = 2 * PBYTES;         // weight ring behind the two patch slots
+constexpr int LDS_MAIN = WBASE + 3 * WBYTES;  // 159,744 B of the CU's 163,840
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), c, 0, 0, 0);
+    }
+};
+
+template <int N> struct IC { static constexpr int value = N; };
+
+#ifndef C2W_EXP
+#define C2W_EXP 0  // diagnostic timing builds only: 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA in the loop, 8 no barrier
+#endif
+template <typename T>
+__device__ __forceinline__ void mma_x(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    if constexpr (C2W_EXP & 1) {
+        asm volatile("" ::"v"(a), "v"(b));
+    } else {
+        Mma<T>::run(a, b, c);
+    }
+}
+__device__ __forceinline__ u32x4_t lds_x(const char* p, const u32x4_t& keep) {
+    if constexpr (C2W_EXP & 2) {
+        return keep;
+    } else {
+        return *(const u32x4_t*)p;
+    }
+}
+
+__device__ __forceinline__ void wait_vm(int n) {  // wave-uniform n in {0,2,3}
+    if (n == 3) {
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else if (n == 2) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wConvArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int CK = 128 / ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int nN = (p.Cout + 127) / 128;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hin, W = p.Win;
+    const int tw = W >> 4, tpi = (H >> 4) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 4, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    // ---- patch pieces of this wave: round r -> piece r*8 + wid (pieces past the end repeat the last one)
+    uint32_t pvo[7];
+    int pdst[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        int pc = r * 8 + wid;
+        pc = pc < NPIECE ? pc : NPIECE - 1;
+        const int pr = pc / 3, pg = pc - pr * 3;
+        const int px = pg * 8 + (lane >> 3);
+        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+        const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+        pdst[r] = pc * 1024;
+    }
+    uint32_t wvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+    auto issue_w = [&](int chunk, int tap, int wslot) {
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rw, smem + WBASE + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
+    };
+
+    // ---- fragment read offsets: register part (the rest is an immediate)
+    uint32_t offA[2][4], preB[2][3][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = wm * 64 + m * 16 + li;
+            offA[ks][m] = (uint32_t)(WBASE + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int px = li + kw;
+                preB[ks][kw][n] = (uint32_t)(((wn * 4 + n) * PW + px) * 128 + (((ks * 4 + lg) ^ (px & 7)) << 4));
+            }
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * 9;
+
+    // prologue: patch of chunk 0, weights of stages 0 and 1
+#pragma unroll
+    for (int r = 0; r < 7; ++r) glds16(rx, smem + pdst[r], pvo[r], 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    int np = 2;  // LDS-DMA pieces this wave issued in the previous stage (still allowed in flight)
+    u32x4_t da[4] = {}, db[4] = {};  // second-half fragments of the previous stage (deferred MFMAs)
+
+    auto stage = [&](auto PARc, auto TAPc, int c) {
+        constexpr int PAR = decltype(PARc)::value, TAP = decltype(TAPc)::value;
+        constexpr int KH = TAP / 3, KW = TAP % 3, WS = TAP % 3;
+        const int s = c * 9 + TAP;
+        wait_vm(np);
+        if constexpr (!(C2W_EXP & 8)) __builtin_amdgcn_s_barrier();
+        np = 0;
+        if (!(C2W_EXP & 4) && s + 2 < NS) {
+            constexpr int T2 = (TAP + 2) % 9;
+            issue_w(TAP + 2 >= 9 ? c + 1 : c, T2, (TAP + 2) % 3);
+            np = 2;
+        }
+        if (!(C2W_EXP & 4) && TAP < 7 && c + 1 < nchunk) {
+            glds16(rx, smem + (PAR ^ 1) * PBYTES + pdst[TAP < 7 ? TAP : 0], pvo[TAP < 7 ? TAP : 0], (uint32_t)(c + 1) * 128u);
+            np += 1;
+        }
+        // software pipeline across the barrier: the second K-half of every stage is multiplied AFTER the next stage's
+        // barrier, from registers, while that stage's first fragments are still on their way from LDS.
+        u32x4_t a0[4], b0[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = lds_x(smem + offA[0][m] + WS * WBYTES, da[m]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b0[n] = lds_x(smem + preB[0][KW][n] + KH * PROW + PAR * PBYTES, db[n]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_x<T>(da[m], db[n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = lds_x(smem + offA[1][m] + WS * WBYTES, a0[m]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) db[n] = lds_x(smem + preB[1][KW][n] + KH * PROW + PAR * PBYTES, b0[n]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma_x<T>(a0[m], b0[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before any wave may refill their slot
+    };
+    auto chunk9 = [&](auto PARc, int c) {
+        stage(PARc, IC<0>{}, c); stage(PARc, IC<1>{}, c); stage(PARc, IC<2>{}, c);
+        stage(PARc, IC<3>{}, c); stage(PARc, IC<4>{}, c); stage(PARc, IC<5>{}, c);
+        stage(PARc, IC<6>{}, c); stage(PARc, IC<7>{}, c); stage(PARc, IC<8>{}, c);
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk9(IC<0>{}, c);
+        if (c + 1 < nchunk) chunk9(IC<1>{}, c + 1);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) mma_x<T>(da[m], db[n], acc[m][n]);
+
+    // ---- epilogue (as conv_igemm.hip): bias/activation in registers -> LDS [pixel][channel] -> 16-B NHWC stores
+    constexpr int OS = 128 * ESZ + 16;
+    __syncthreads();
+    char* const O = smem;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int col = wm * 64 + m * 16 + lg * 4;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (p.bias != nullptr && co0 + col + r < p.wrows) ? p.bias[co0 + col + r] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = wn * 64 + n * 16 + li;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[m][n][r] + bv[r];
+                if (p.act == C2W_ACT_SILU) v[r] = silu_f(v[r]);
+            }
+            if constexpr (ESZ == 4) {
+                *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int SEGS = 128 * ESZ / 16;
+    constexpr int PER16 = 16 / ESZ;
+    for (int seg = tid; seg < 256 * SEGS; seg += NTHREADS) {
+        const int row = seg / SEGS, cs = seg - row * SEGS;
+        const int c = co0 + cs * PER16;
+        if (c < p.Cout) {
+            const size_t Q = ((size_t)b * H + oh0 + (row >> 4)) * W + ow0 + (row & 15);
+            u32x4_t v = *(const u32x4_t*)(O + row * OS + cs * 16);
+            const size_t off = (Q * p.ldy + c) * ESZ;
+            if (p.mul != nullptr || p.res != nullptr) {
+                float f[PER16];
+                unpack16<T>(v, f);
+                if (p.mul != nullptr) {
+                    float g[PER16];
+                    unpack16<T>(*(const u32x4_t*)((const char*)p.mul + off), g);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) f[e] *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(g[e]) : g[e];
+                }
+                if (p.res != nullptr) {
+                    float g[PER16];
+                    unpack16<T>(*(const u32x4_t*)((const char*)p.res + off), g);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) f[e] += g[e];
+                }
+                v = pack16<T>(f);
+            }
+            *(u32x4_t*)((char*)p.y + off) = v;
+        }
+    }
+}
+
+template <typename T>
+int launch(const C2wConvArgs& a, hipStream_t st) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int lds_epi = 256 * (128 * ESZ + 16);
+    constexpr int lds = LDS_MAIN > lds_epi ? LDS_MAIN : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_s1_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int nM = a.B * (a.Hin >> 4) * (a.Win >> 4), nN = (a.Cout + 127) / 128;
+    conv_patch_s1_kernel<T><<<nM * nN, NTHREADS, lds, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool c2w_conv_patch_eligible(const C2wConvArgs& a) {
+    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 15) == 0 && (a.Win & 15) == 0 &&
+           (long long)a.B * (a.Hin >> 4) * (a.Win >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
+}
+
+int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {
+    if (dtype == C2W_DTYPE_F32) return launch<float>(a, st);
+    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, st);
+    return C2W_ERR_BAD_ARG;
+}

@@ -26,6 +26,7 @@ struct WgradArgs {
     const void* dy;  // [npix][ldy]
     const void* x;   // [B][Hin][Win][Cin]
     float* dw;       // [Cout][NT][Cin] fp32, accumulated
+    float* db;       // [Cout] fp32 bias gradient (column sums of dY), accumulated; may be null
     int B, Hin, Win, Cin, Hout, Wout, Cout, ldy;
     int nsplit, ktiles_per_split;
     FastDiv div_hw, div_w;
@@ -131,6 +132,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int n = 0; n < NTL; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient = dY^T . 1: the wave that owns column block 0 of column tile 0 multiplies its dY fragments by ones
+    const bool do_bias = p.db != nullptr && tn == 0 && wn == 0;
+    f32x4_t accb[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) accb[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
     // ---- fragment read offsets
     uint32_t offA[MT][2], offB[NTL][2];  // bf16: [tile][h]; fp32: [tile][0] holds the (row-independent) part
     if constexpr (ESZ == 2) {
@@ -197,6 +204,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NTL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                if (do_bias) {
+                    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -211,6 +223,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NTL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.0f, accb[m], 0, 0, 0);
+                }
             }
         }
         buf = buf + 1 == NSLOT ? 0 : buf + 1;
@@ -231,6 +247,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
         }
     __syncthreads();
     if (kt0 >= kt1) return;
+    if (do_bias && li == 0) {  // every column of accb holds the same sums; lane (li=0, lg) owns rows 4*lg .. 4*lg+3
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (COT / 2) + m * 16 + lg * 4 + r;
+                if (co < p.Cout) atomicAdd(p.db + co, accb[m][r]);
+            }
+    }
     for (int idx = tid; idx < COT * NCOL; idx += NTHREADS) {
         const int row = idx / NCOL, col = idx - row * NCOL;
         const int cb = col / CIB, cil = col - cb * CIB;
@@ -255,12 +280,12 @@ FastDiv make_div(uint32_t d) {
 }
 
 template <typename T, int MODE>
-int launch(const C2wConvArgs& a, float* dw, hipStream_t st) {
+int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
     constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
     WgradArgs p;
-    p.dy = a.y; p.x = a.x; p.dw = dw;
+    p.dy = a.y; p.x = a.x; p.dw = dw; p.db = db;
     p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Cin = a.Cin; p.Hout = a.Hout; p.Wout = a.Wout; p.Cout = a.Cout; p.ldy = a.ldy;
     const long long npix = (long long)a.B * a.Hout * a.Wout;
     const int nkt = (int)((npix + KT - 1) / KT);
@@ -286,12 +311,12 @@ int launch(const C2wConvArgs& a, float* dw, hipStream_t st) {
 }
 
 template <typename T>
-int launch_dtype(const C2wConvArgs& a, float* dw, hipStream_t st) {
+int launch_dtype(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     switch (a.mode) {
-        case C2W_CONV_1X1: return launch<T, C2W_CONV_1X1>(a, dw, st);
-        case C2W_CONV_S1: return launch<T, C2W_CONV_S1>(a, dw, st);
-        case C2W_CONV_S2: return launch<T, C2W_CONV_S2>(a, dw, st);
-        case C2W_CONV_UP: return launch<T, C2W_CONV_UP>(a, dw, st);
+        case C2W_CONV_1X1: return launch<T, C2W_CONV_1X1>(a, dw, db, st);
+        case C2W_CONV_S1: return launch<T, C2W_CONV_S1>(a, dw, db, st);
+        case C2W_CONV_S2: return launch<T, C2W_CONV_S2>(a, dw, db, st);
+        case C2W_CONV_UP: return launch<T, C2W_CONV_UP>(a, dw, db, st);
     }
     return C2W_ERR_BAD_ARG;
 }
@@ -299,8 +324,9 @@ int launch_dtype(const C2wConvArgs& a, float* dw, hipStream_t st) {
 }  // namespace
 
 // Geometry is passed with the forward call's argument block: x = the forward input, y = dY (gradient w.r.t. the forward
-// output, [B*Hout*Wout][ldy]); w/bias/res/mul/act are ignored.  dw is [Cout][taps][Cin] fp32 and is accumulated into.
-extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, int dtype, void* stream) {
+// output, [B*Hout*Wout][ldy]); w/bias/res/mul/act are ignored.  dw is [Cout][taps][Cin] fp32 and is accumulated into;
+// dbias (optional) receives the bias gradient sum_q dY[q][co] from the same pass over dY.
+extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, int dtype, void* stream) {
     if (a == nullptr || a->x == nullptr || a->y == nullptr || dw == nullptr) return C2W_ERR_BAD_ARG;
     const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
     if (a->Cin <= 0 || a->Cin % (128 / esz) != 0) return C2W_ERR_BAD_SHAPE;
@@ -308,7 +334,7 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, int dtype, void* 
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
     if ((long long)a->B * a->Hout * a->Wout >= (1ll << 31)) return C2W_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, st);
-    if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, st);
+    if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, dbias, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, dbias, st);
     return C2W_ERR_BAD_ARG;
 }

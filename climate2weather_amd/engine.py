@@ -294,8 +294,7 @@ class Engine:
         ops.conv(x, self._w(rec, DTYPE_F32), self._b(rec), y, g, DTYPE_F32, act=act)
         if tape is not None:
             def bw(gy: torch.Tensor) -> Optional[torch.Tensor]:
-                ops.colsum(gy, self._gb(rec), rows, rec.rows, rec.rows, DTYPE_F32)
-                ops.conv_wgrad(x, gy, self._gw(rec), g, DTYPE_F32)
+                ops.conv_wgrad(x, gy, self._gw(rec), g, DTYPE_F32, dbias=self._gb(rec))
                 tape.done(rec.w_off)
                 if not need_dx:
                     return None
@@ -388,11 +387,9 @@ class Engine:
             out, g2, r2 = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin)
             if train:
                 def bw(gy):
-                    ops.colsum(gy, self._gb(r2), npix, Cc, Cc, dt)
-                    ops.conv_wgrad(h1, gy, self._gw(r2), g2, dt)
+                    ops.conv_wgrad(h1, gy, self._gw(r2), g2, dt, dbias=self._gb(r2))
                     da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=a1)
-                    ops.colsum(da1, self._gb(r1), npix, Cc, Cc, dt)
-                    ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt)
+                    ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt, dbias=self._gb(r1))
                     tape.done(r1.w_off)
                     dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                     dx = torch.empty_like(dh0)
@@ -421,15 +418,13 @@ class Engine:
             ops.conv(o, self._w(rp, dt), self._b(rp), out, gp, dt, res=xin)
             if train:
                 def bw(gy):
-                    ops.colsum(gy, self._gb(rp), npix, Cc, Cc, dt)
-                    ops.conv_wgrad(o, gy, self._gw(rp), gp, dt)
+                    ops.conv_wgrad(o, gy, self._gw(rp), gp, dt, dbias=self._gb(rp))
                     do = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(gy, self._wT(rp, dt), None, do, self._geom(npix, 1, 1, Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
                     dqkv = torch.empty_like(qkv)
                     delta = torch.empty((npix,), dtype=torch.float32, device=dev)
                     ops.attention_backward(qkv, o, do, lse, delta, dqkv, B, Tn, Cc, dt)
-                    ops.colsum(dqkv, self._gb(rq), npix, 3 * Cc, 3 * Cc, dt)
-                    ops.conv_wgrad(hl, dqkv, self._gw(rq), gq, dt)
+                    ops.conv_wgrad(hl, dqkv, self._gw(rq), gq, dt, dbias=self._gb(rq))
                     tape.done(rq.w_off)
                     dhl = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(dqkv, self._wT(rq, dt), None, dhl, self._geom(npix, 1, 1, 3 * Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
@@ -445,8 +440,7 @@ class Engine:
         cur, g_h0, r_h0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1)
         if train:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
-                ops.colsum(gy, self._gb(rec), B * H * W, rec.rows, rec.rows, dt)
-                ops.conv_wgrad(x0, gy, self._gw(rec), g, dt)
+                ops.conv_wgrad(x0, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
                 tape.done(rec.w_off)
                 if not want_dx:
                     return None
@@ -461,8 +455,7 @@ class Engine:
                 cur, g_h, r_h = conv3("unet." + lv.head_key, xin, Hp, Wp, Hc, Wc, CONV_S2)
                 if train:
                     def bw_head(gy, xin=xin, g=g_h, rec=r_h, Hp=Hp, Wp=Wp, Hc=Hc, Wc=Wc, lvl=i - 1):
-                        ops.colsum(gy, self._gb(rec), B * Hc * Wc, rec.rows, rec.rows, dt)
-                        ops.conv_wgrad(xin, gy, self._gw(rec), g, dt)
+                        ops.conv_wgrad(xin, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
                         tape.done(rec.w_off)
                         # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
                         return dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
@@ -488,8 +481,7 @@ class Engine:
                 if train:
                     def bw_tail(gy, xin=xin, hl=hl, g=g_t, rec=r_t, Hl=Hl, Wl=Wl, Hu=Hc, Wu=Wc, Cc=Cc, lvl=i - 1):
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient
-                        ops.colsum(gy, self._gb(rec), B * Hu * Wu, rec.rows, rec.rows, dt)
-                        ops.conv_wgrad(hl, gy, self._gw(rec), g, dt)
+                        ops.conv_wgrad(hl, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
                         tape.done(rec.w_off)
                         gu = dgrad(rec, gy, Hu, Wu, Hu, Wu, CONV_S1, Cc)  # gradient w.r.t. the upsampled map
                         gl = torch.empty((B * Hl * Wl, Cc), dtype=T, device=dev)
@@ -503,10 +495,9 @@ class Engine:
                 cur, g_t, r_t = conv3("unet." + lv.tail_key, xin, Hc, Wc, Hc, Wc, CONV_S1, ldy=lay.cout_pad, cout=lay.cout_pad)
                 if train:
                     def bw_tail0(gy, xin=xin, g=g_t, rec=r_t, Hc=Hc, Wc=Wc, Cc=lv.channels):
-                        ops.colsum(gy, self._gb(rec), B * Hc * Wc, lay.cout_pad, lay.cout_pad, dt)
                         gw = dict(g)
                         gw["Cout"] = rec.rows
-                        ops.conv_wgrad(xin, gy, self._gw(rec), gw, dt)
+                        ops.conv_wgrad(xin, gy, self._gw(rec), gw, dt, dbias=self._gb(rec))
                         tape.done(rec.w_off)
                         return dgrad(rec, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                     tape.steps.append(bw_tail0)
@@ -531,8 +522,7 @@ class Engine:
         def bw(gh: torch.Tensor) -> Optional[torch.Tensor]:
             gz = torch.empty_like(z)
             ops.silu_backward(z, gh, gz, z.numel(), DTYPE_F32)
-            ops.colsum(gz, self._gb(rec), rows, rec.rows, rec.rows, DTYPE_F32)
-            ops.conv_wgrad(x, gz, self._gw(rec), g, DTYPE_F32)
+            ops.conv_wgrad(x, gz, self._gw(rec), g, DTYPE_F32, dbias=self._gb(rec))
             tape.done(rec.w_off)
             if not need_dx:
                 return None

@@ -37,16 +37,17 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode) -> ConvArgs:
                     g["Cout"], g["ldy"], g["wrows"], g["mode"], act, mulmode)
 
 
-def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive: bool = False):
+def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode)."""
     a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode)
-    check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")
+    check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
-def conv_wgrad(x, dy, dw, g: dict, dtype: int):
+def conv_wgrad(x, dy, dw, g: dict, dtype: int, dbias=None):
+    """c2w_conv_wgrad: dw += dY^T . gather(x); dbias (optional) += column sums of dY."""
     a = _conv_args(x, None, None, None, None, dy, g, 0, 0)
     a.w = None
-    check(_lib.load().c2w_conv_wgrad(ctypes.byref(a), _p(dw), dtype, _stream()), "c2w_conv_wgrad")
+    check(_lib.load().c2w_conv_wgrad(ctypes.byref(a), _p(dw), _p(dbias), dtype, _stream()), "c2w_conv_wgrad")
 
 
 def ln_forward(x, m, y, npix, HW, C, ldm, eps, unbiased, dtype):

@@ -53,15 +53,17 @@ typedef struct C2wConvArgs {
     int32_t mulmode; /* C2W_MUL_* */
 } C2wConvArgs;
 
-/* naive != 0 runs a one-thread-per-output direct convolution with identical semantics
- * (debug cross-check of the MFMA kernel; never used by the product path). */
+/* naive == 0: product path (halo-patch MFMA kernel for 3x3 stride-1 on 16x16-tileable images, general gather MFMA
+ * kernel otherwise); naive == 2: force the gather MFMA kernel; naive == 1: one-thread-per-output direct convolution
+ * with identical semantics (debug cross-check only). */
 int c2w_conv_forward(const C2wConvArgs* args, int dtype, int naive, void* stream);
 
 /* dW[co][tap][ci] (fp32) += sum_q dY[q][co] * x[src(q,tap)][ci]  -- weight gradient of the same geometry.
  * Pass the forward call's block with y := dY; w/bias/res/mul/act are ignored.  Split-K over pixels across
  * workgroups, combined with fp32 atomics: zero dw (or leave the value to accumulate onto) beforehand.
- * Replaces autograd's weight backward of every Conv2d/Conv1d/Linear cited above. */
-int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, int dtype, void* stream);
+ * dbias (may be NULL): [Cout] fp32, += sum_q dY[q][co] (the bias gradient, from the same pass over dY).
+ * Replaces autograd's weight/bias backward of every Conv2d/Conv1d/Linear cited above. */
+int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, float* dbias, int dtype, void* stream);
 
 /* y = LN_C(x + m[b]): parameter-free channel LayerNorm (zuko.nn.LayerNorm at model/nn.py:44,154,183) fused with
  * the time-modulation add of model/nn.py:28.  x,y: [npix][C]; m: fp32 rows of C (row b = pixel / HW, stride ldm;

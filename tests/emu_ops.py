@@ -73,7 +73,7 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
     _rows(y, npix, ldy)[:, :Cout] = out.to(T)
 
 
-def conv_wgrad(x, dy, dw, g, dtype):
+def conv_wgrad(x, dy, dw, g, dtype, dbias=None):
     B, Hin, Win, Cin, Hout, Wout, Cout, ldy = (g[k] for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ldy"))
     taps = 1 if g["mode"] == CONV_1X1 else 9
     X = _rows(x, B * Hin * Win, Cin).view(B, Hin, Win, Cin).float().permute(0, 3, 1, 2)
@@ -83,6 +83,8 @@ def conv_wgrad(x, dy, dw, g, dtype):
         gy = _rows(dy, B * Hout * Wout, ldy)[:, :Cout].float().view(B, Hout, Wout, Cout).permute(0, 3, 1, 2)
         (gw,) = torch.autograd.grad(out, Wt, gy)
     dw.reshape(-1)[: Cout * taps * Cin] += gw.reshape(-1)
+    if dbias is not None:
+        dbias.reshape(-1)[:Cout] += _rows(dy, B * Hout * Wout, ldy)[:, :Cout].float().sum(0)
 
 
 def _ln(xm, unbiased, eps):

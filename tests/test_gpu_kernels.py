@@ -45,6 +45,8 @@ CONV_CASES = [
     (ops.CONV_S1, 3, 8, 8, 128, 192, 192, 192),     # ragged pixel tile (192 px), two channel tiles, second partial
     (ops.CONV_S1, 1, 32, 32, 128, 64, 52, 64),      # output conv: 52 real rows, padded output rows stay zero
     (ops.CONV_S1, 2, 4, 4, 64, 64, 64, 64),         # tiny spatial (plumbing config depth)
+    (ops.CONV_S1, 2, 32, 48, 128, 128, 128, 128),   # halo-patch kernel: 2x3 tiles per image, 2 K-chunks (bf16) / 4 (fp32)
+    (ops.CONV_S1, 1, 16, 32, 192, 320, 320, 320),   # halo-patch kernel: odd chunk count, 3 channel tiles (last partial)
     (ops.CONV_S2, 2, 16, 16, 64, 128, 128, 128),
     (ops.CONV_S2, 1, 32, 32, 128, 256, 256, 256),
     (ops.CONV_UP, 2, 8, 8, 128, 64, 64, 64),
@@ -65,7 +67,7 @@ def _out_hw(mode, Hin, Win):
 
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("naive", [False, True])
+@pytest.mark.parametrize("naive", [0, 1, 2])
 def test_conv_forward(case, dt, naive):
     mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
     taps = 1 if mode == ops.CONV_1X1 else 9
@@ -99,10 +101,14 @@ def test_conv_wgrad(case, dt):
     dy = rnd((B * Hout * Wout, ldy), dt, 2)
     dw = torch.zeros(Cw * taps * Cin + 64, dtype=torch.float32, device=dev())
     dw_ref = dw.clone()
-    ops.conv_wgrad(x, dy, dw, g, dt)
-    E.conv_wgrad(x, dy, dw_ref, g, dt)
+    db = torch.zeros(Cw + 8, dtype=torch.float32, device=dev())
+    db_ref = db.clone()
+    ops.conv_wgrad(x, dy, dw, g, dt, dbias=db)
+    E.conv_wgrad(x, dy, dw_ref, g, dt, dbias=db_ref)
     torch.cuda.synchronize()
     close(dw, dw_ref, dt, f"wgrad mode={mode}", tol=1e-4 if dt == F32 else 1e-2)
+    close(db, db_ref, dt, f"wgrad bias mode={mode}", tol=1e-4 if dt == F32 else 1e-2)
+    assert db[Cw:].abs().max().item() == 0.0
     assert dw[-64:].abs().max().item() == 0.0  # nothing written past the tensor
     # accumulation semantics: a second call adds
     ops.conv_wgrad(x, dy, dw, g, dt)
