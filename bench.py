@@ -162,7 +162,7 @@ def main():
         roof = None
         if k_ms:
             ach = flops_launch / (k_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="conv_igemm_kernel<bf16,S1> 128->128 @%dx%d (res-block conv fwd + dgrad)" % (a.size, a.size),
+            roof = dict(bound="mfma", kernel="conv_patch_s1_kernel<bf16> 128->128 @%dx%d (res-block conv fwd + dgrad)" % (a.size, a.size),
                         achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                         traffic=None, launches_timed=k_n, avg_launch_ms=round(k_ms, 4), flops_per_launch=flops_launch)
         out = dict(metric="UNet denoise steps/sec (train fwd+bwd+allreduce+AdamW+EMA windows/s)", value=round(value, 2), unit="windows/s",

@@ -36,3 +36,7 @@ __device__ __forceinline__ int fast_div(int n, FastDiv d) { return d.magic ? (in
 // halo-patch kernel for 3x3 stride-1 convolutions on 16x16-tileable images (conv_patch.hip)
 bool c2w_conv_patch_eligible(const C2wConvArgs& a);
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st);
+
+// halo-patch weight-gradient kernel for the same convolutions (wgrad_patch.hip)
+bool c2w_wgrad_patch_eligible(const C2wConvArgs& a);
+int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st);

@@ -18,6 +18,8 @@
 // The element type only changes how a 16-byte fragment is fed to the matrix core:
 //   bf16 : 1 x v_mfma_f32_16x16x32_bf16     (8 k-values per lane)
 //   fp32 : 4 x v_mfma_f32_16x16x4_f32       (4 k-values per lane, exact fp32 fma chain)
+#include <cstdlib>
+
 #include "conv_geom.h"
 
 namespace {
@@ -307,7 +309,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
     if (a->Hout >= 65536 || a->Wout >= 65536) return C2W_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (naive == 0 && c2w_conv_patch_eligible(*a)) return c2w_conv_patch_s1(*a, dtype, st);
+    if (naive == 0 && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_s1(*a, dtype, st);
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, naive, st);

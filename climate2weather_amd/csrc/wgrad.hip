@@ -12,6 +12,8 @@
 // x 64 pixels per stage; 8 waves = 2 (M) x 4 (N: one column block each).  Split-K over pixel ranges across
 // workgroups; partial tiles are combined with fp32 global atomics issued as 256-B contiguous wave instructions
 // (tile staged through LDS first).  dW must be zero-initialised (or hold the value to accumulate onto).
+#include <cstdlib>
+
 #include "conv_geom.h"
 
 namespace {
@@ -334,6 +336,7 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, int
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
     if ((long long)a->B * a->Hout * a->Wout >= (1ll << 31)) return C2W_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch(*a, dw, dbias, dtype, st);
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, dbias, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, dbias, st);
     return C2W_ERR_BAD_ARG;

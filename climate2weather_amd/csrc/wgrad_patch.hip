@@ -1,0 +1,260 @@
+// Halo-patch weight-gradient GEMM for the 3x3 stride-1 convolutions on gfx950:
+//     dW[co][tap][ci] += sum_q dY[q][co] * X[q shifted by tap][ci]         (+ dbias[co] += sum_q dY[q][co])
+//
+// The general wgrad kernel (wgrad.hip) gathers X once per tap and spends most of its issue slots on per-stage
+// gather arithmetic.  Here one workgroup owns (256 B of output channels) x (128 B of input channels) x ALL 9 taps:
+//   * K tile = an 8x16 block of output pixels of one image.  Per K tile it stages dY[128 px][256 B] and ONE
+//     (8+2)x(16+2) input halo patch [10][24 px pitch][128 B]; the 9 taps are 9 shifted views of that patch, so each
+//     input pixel is loaded once (not 9 times) and dY once -- 3.7x fewer bytes per FLOP than the gather kernel;
+//   * both operands are K(pixel)-strided in memory: they are staged as they lie in HBM (direct-to-LDS 16-B loads,
+//     zero padding via out-of-range buffer offsets) and transposed on the way into the matrix core
+//     (bf16: ds_read_b64_tr_b16; fp32: one dword per lane).  Source-side XOR swizzles keep the transposed reads
+//     conflict free (dY rows: chunk ^= (row&3)<<2 | (row>>2)&3; patch rows: chunk ^= ((pix>>1)&1)<<1 | ((pix>>3)&1)<<2);
+//   * taps unrolled, every LDS address = register + immediate; one barrier per K tile (144 MFMAs per wave in bf16);
+//   * 36 accumulator tiles per wave (bf16: 4 co-tiles x 1 ci-tile x 9 taps); split-K over pixel ranges across
+//     workgroups, partial sums combined with fp32 atomics issued as full 256-B rows (staged through LDS per tap);
+//   * the bias gradient rides along as one extra MFMA per co-tile against a vector of ones.
+#include "conv_geom.h"
+
+namespace {
+
+constexpr int NTHREADS = 512;
+constexpr int KPX = 128;                 // pixels per K tile (8 rows x 16 cols)
+constexpr int ABYTES = KPX * 256;        // dY tile
+constexpr int PPITCH = 24;               // patch row pitch (pixels); 18 used
+constexpr int NPIECE = 10 * 3;           // 1 KiB pieces per patch
+constexpr int PBYTES = NPIECE * 1024;    // 30,720
+constexpr int SLOT = ABYTES + PBYTES;    // 63,488
+constexpr int LDS_BYTES = 2 * SLOT;      // 126,976
+
+struct WpArgs {
+    const void* dy;
+    const void* x;
+    float* dw;
+    float* db;
+    int B, H, W, Cin, Cout, ldy;
+    int ktiles, ktiles_per_split;
+};
+
+__device__ __forceinline__ uint32_t swzA(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
+__device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2)); }
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr bool BF = ESZ == 2;
+    constexpr int COT = 256 / ESZ;       // output channels per workgroup tile
+    constexpr int CIB = 128 / ESZ;       // input channels per workgroup tile
+    constexpr int MTW = BF ? 4 : 1;      // 16-wide co tiles per wave (x 1 ci tile x 9 taps)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int mt0 = BF ? (wid & 1) * 4 : (wid >> 1);  // first co tile of this wave
+    const int nt = BF ? (wid >> 1) : (wid & 1);       // its ci tile
+
+    const int ncib = p.Cin / CIB;
+    const int tilesM = (p.Cout + COT - 1) / COT;
+    const int tilesMN = tilesM * ncib;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int split = L / tilesMN, mn = L - split * tilesMN;
+    const int tm = mn / ncib, cb = mn - tm * ncib;
+    const int co0 = tm * COT, ci0 = cb * CIB;
+    const int H = p.H, W = p.W;
+    const int tw = W >> 4, tpi = (H >> 3) * tw;
+    const int t0 = split * p.ktiles_per_split;
+    const int t1 = (t0 + p.ktiles_per_split < p.ktiles) ? t0 + p.ktiles_per_split : p.ktiles;
+
+    // ---- dY staging slots (tile-relative): 128 rows x 16 chunks = 4 rounds
+    uint32_t avo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = tid + NTHREADS * i, row = s >> 4, pc = s & 15;
+        const uint32_t lc = (uint32_t)pc ^ swzA(row);
+        const int c = co0 + (int)lc * (16 / ESZ);
+        avo[i] = (c < p.Cout) ? (uint32_t)((((row >> 4) * W + (row & 15)) * p.ldy + c) * ESZ) : C2W_OOB;
+    }
+    // ---- patch pieces of this wave (4 rounds; pieces past the end repeat the last one)
+    int ppr[4], ppx[4], pdst[4];
+    uint32_t plc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int pc = r * 8 + wid;
+        pc = pc < NPIECE ? pc : NPIECE - 1;
+        const int pr = pc / 3, pg = pc - pr * 3;
+        const int px = pg * 8 + (lane >> 3);
+        ppr[r] = pr;
+        ppx[r] = px;
+        pdst[r] = pc * 1024;
+        plc[r] = (uint32_t)(((lane & 7) ^ swzP(pr * PPITCH + px)) << 4) + (uint32_t)ci0 * ESZ;
+    }
+    const size_t ximg = (size_t)H * W * p.Cin * ESZ;
+    const size_t yimg = (size_t)H * W * p.ldy * ESZ;
+
+    auto issue = [&](int t, int slot) {
+        const int b = t / tpi, tt = t - b * tpi;
+        const int ty = tt / tw, tx = tt - ty * tw;
+        const int oh0 = ty << 3, ow0 = tx << 4;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.dy + (size_t)b * yimg, (uint32_t)yimg);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg);
+        char* const base = smem + slot * SLOT;
+        const uint32_t aso = (uint32_t)((oh0 * W + ow0) * p.ldy) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(ra, base + wid * 1024 + i * 8192, avo[i], aso);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ih = oh0 - 1 + ppr[r], iw = ow0 - 1 + ppx[r];
+            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && ppx[r] < 18;
+            const uint32_t voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + plc[r] : C2W_OOB;
+            glds16(rx, base + ABYTES + pdst[r], voff, 0);
+        }
+    };
+
+    f32x4_t acc[9][MTW];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[t][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db != nullptr && cb == 0 && nt == 0;
+    f32x4_t accb[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) accb[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment read offsets (register part; K step and slot are added as immediates / one add per tile)
+    uint32_t offA[MTW][2], offB[9][2];
+    if constexpr (BF) {
+        const int qq = li >> 2, pp = li & 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 8 * lg + qq + 4 * h;  // + 32*ks
+            const uint32_t f = swzA(row);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+                offA[m][h] = (uint32_t)(row * 256 + (((((mt0 + m) * 2 + (pp >> 1)) ^ f) & 15) << 4) + 8 * (pp & 1));
+            const int r = lg >> 1, c = 8 * (lg & 1) + qq + 4 * h;  // pixel (r + 2*ks, c) of the K tile
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pix = (r + t / 3) * PPITCH + c + t % 3;
+                offB[t][h] = (uint32_t)(ABYTES + pix * 128 + (((uint32_t)(nt * 2 + (pp >> 1)) ^ swzP(pix)) << 4) + 8 * (pp & 1));
+            }
+        }
+    }
+
+    if (t0 < t1) issue(t0, 0);
+    int slot = 0;
+    for (int t = t0; t < t1; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading the other slot
+        if (t + 1 < t1) issue(t + 1, slot ^ 1);
+        const char* const S = smem + slot * SLOT;
+        if constexpr (BF) {
+            typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+            auto tr8 = [&](uint32_t o0, uint32_t o1) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o0));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o1));
+                return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8_t a[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) a[m] = tr8(offA[m][0] + ks * 32 * 256, offA[m][1] + ks * 32 * 256);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const bf16x8_t bfr = tr8(offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bfr, acc[tp][m], 0, 0, 0);
+                }
+                if (do_bias) {
+                    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int kk = 0; kk < 32; ++kk) {  // 4 pixels per MFMA: lane (i, g) feeds pixel 4*kk + g
+                const int row = kk * 4 + lg;
+                const float a = *(const float*)(S + row * 256 + ((((uint32_t)(mt0 * 4 + (li >> 2))) ^ swzA(row)) << 4) + (li & 3) * 4);
+                const int r = kk >> 2, c = 4 * (kk & 3) + lg;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int pix = (r + tp / 3) * PPITCH + c + tp % 3;
+                    const float bv = *(const float*)(S + ABYTES + pix * 128 + ((((uint32_t)(nt * 4 + (li >> 2))) ^ swzP(pix)) << 4) + (li & 3) * 4);
+                    acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[tp][0], 0, 0, 0);
+                }
+                if (do_bias) accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb[0], 0, 0, 0);
+            }
+        }
+        slot ^= 1;
+    }
+
+    // ---- epilogue: per tap, tile -> LDS [co][ci] fp32 -> atomics as whole (co, tap) rows of CIB floats
+    if (t0 >= t1) return;
+    if (do_bias && li == 0) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (mt0 + m) * 16 + lg * 4 + r;
+                if (co < p.Cout) atomicAdd(p.db + co, accb[m][r]);
+            }
+    }
+    constexpr int OS = CIB + 4;
+    float* const O = (float*)smem;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) O[((mt0 + m) * 16 + lg * 4 + r) * OS + nt * 16 + li] = acc[tp][m][r];
+        __syncthreads();
+        for (int idx = tid; idx < COT * CIB; idx += NTHREADS) {
+            const int row = idx / CIB, col = idx - row * CIB;
+            const int co = co0 + row;
+            if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * 9 + tp) * p.Cin + ci0 + col, O[row * OS + col]);
+        }
+    }
+}
+
+template <typename T>
+int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    WpArgs p;
+    p.dy = a.y; p.x = a.x; p.dw = dw; p.db = db;
+    p.B = a.B; p.H = a.Hin; p.W = a.Win; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
+    p.ktiles = a.B * (a.Hin >> 3) * (a.Win >> 4);
+    const int tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
+    int nsplit = (256 + tilesMN - 1) / tilesMN;  // one resident workgroup per CU, one round: every extra workgroup costs 295 KB of atomics
+    if (nsplit > p.ktiles) nsplit = p.ktiles;
+    if (nsplit < 1) nsplit = 1;
+    p.ktiles_per_split = (p.ktiles + nsplit - 1) / nsplit;
+    nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    wgrad_patch_kernel<T><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
+    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && (a.Win & 15) == 0;
+}
+
+int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st) {
+    if (dtype == C2W_DTYPE_F32) return launch<float>(a, dw, db, st);
+    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, dw, db, st);
+    return C2W_ERR_BAD_ARG;
+}

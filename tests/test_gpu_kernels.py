@@ -90,9 +90,14 @@ def test_conv_forward(case, dt, naive):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("force_gather", [False, True])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] != ops.CONV_TS2])
-def test_conv_wgrad(case, dt):
+def test_conv_wgrad(case, dt, force_gather, monkeypatch):
     mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
+    if force_gather:
+        if mode != ops.CONV_S1:
+            pytest.skip("only 3x3 stride-1 has two kernels")
+        monkeypatch.setenv("C2W_FORCE_GATHER", "1")  # the general kernel on shapes the halo-patch kernel would take
     taps = 1 if mode == ops.CONV_1X1 else 9
     Hout, Wout = _out_hw(mode, Hin, Win)
     Cw = wrows  # gradient rows = real output channels
