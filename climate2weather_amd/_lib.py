@@ -23,7 +23,7 @@ class C2wError(RuntimeError):
 
 class ConvArgs(Structure):
     _fields_ = [
-        ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("mul", c_void_p), ("y", c_void_p),
+        ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("mul", c_void_p), ("y", c_void_p), ("y2", c_void_p),
         ("B", c_int32), ("Hin", c_int32), ("Win", c_int32), ("Cin", c_int32),
         ("Hout", c_int32), ("Wout", c_int32), ("Cout", c_int32), ("ldy", c_int32),
         ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),

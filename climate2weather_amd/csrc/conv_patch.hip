@@ -273,6 +273,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wCon
                 v = pack16<T>(f);
             }
             *(u32x4_t*)((char*)p.y + off) = v;
+            if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
+                float f2[PER16];
+                unpack16<T>(v, f2);
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) f2[e] = silu_f(f2[e]);
+                *(u32x4_t*)((char*)p.y2 + off) = pack16<T>(f2);
+            }
         }
     }
 }

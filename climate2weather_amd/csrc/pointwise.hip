@@ -17,19 +17,19 @@ __device__ __forceinline__ float sub16_sum(float v) {  // sum over the 16 lanes 
 // ------------------------------------------------------------------------------------------------
 // y = LN_C(x + m[b])   zuko.nn.LayerNorm as used at model/nn.py:44,154,183 fused with the broadcast add of
 // model/nn.py:28.  16 lanes per pixel, whole channel row in registers, two-pass mean/variance.
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ m, T* __restrict__ y,
                                                      long long npix, int HW, int C, int ldm, float eps, float inv_den) {
     constexpr int P = Elem<T>::PER16;
     const int sub = threadIdx.x >> 4, j = threadIdx.x & 15;
-    const int nv = (C + 16 * P - 1) / (16 * P);
+    constexpr int nv = NV;
     for (long long pix = (long long)blockIdx.x * 16 + sub; pix < npix; pix += (long long)gridDim.x * 16) {
         const T* xr = x + pix * C;
         const float* mr = m ? m + (size_t)(ldm ? (pix / HW) : 0) * ldm : nullptr;
-        float f[LN_MAXV][P];
+        float f[NV][P];
         float s = 0.f;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
                 unpack16<T>(*(const u32x4_t*)(xr + c), f[v]);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const float mean = sub16_sum(s) / (float)C;
         float q = 0.f;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
 #pragma unroll
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const float rs = 1.0f / sqrtf(sub16_sum(q) * inv_den + eps);
         T* yr = y + pix * C;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
 #pragma unroll
@@ -73,22 +73,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 //   dxm = ( dy - mean(dy) - xh * sum(dy*xh)/den ) / s
 // grid = (chunks per image, images): every pixel of a block belongs to one image, so the modulation gradient is
 // reduced in registers -> LDS (ds_add_f32) -> ONE contiguous global atomic sweep per block.
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ m,
                                                      const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dm,
                                                      int HW, int C, int ldm, float eps, float inv_den, int pix_per_block) {
     constexpr int P = Elem<T>::PER16;
     __shared__ float red[16 * LN_MAXV * 8];
     const int sub = threadIdx.x >> 4, j = threadIdx.x & 15;
-    const int nv = (C + 16 * P - 1) / (16 * P);
+    constexpr int nv = NV;
     const long long b = blockIdx.y;
     if (dm != nullptr) {
         for (int c = threadIdx.x; c < C; c += 256) red[c] = 0.f;
         __syncthreads();
     }
-    float am[LN_MAXV][P];
+    float am[NV][P];
 #pragma unroll
-    for (int v = 0; v < LN_MAXV; ++v)
+    for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int e = 0; e < P; ++e) am[v][e] = 0.f;
     const int p0 = blockIdx.x * pix_per_block;
@@ -98,10 +98,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const long long pix = b * HW + pp;
         const T* xr = x + pix * C;
         const T* gr = dy + pix * C;
-        float f[LN_MAXV][P], g[LN_MAXV][P];
+        float f[NV][P], g[NV][P];
         float s = 0.f, sg = 0.f;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
                 unpack16<T>(*(const u32x4_t*)(xr + c), f[v]);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const float gmean = sub16_sum(sg) / (float)C;
         float q = 0.f;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const float rs = 1.0f / sqrtf(sub16_sum(q) * inv_den + eps);
         float d = 0.f;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const float dot = sub16_sum(d) * inv_den;
         T* dxr = dx + pix * C;
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
                 float o[P];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     if (dm != nullptr) {
 #pragma unroll
-        for (int v = 0; v < LN_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 16 + j) * P;
             if (v < nv && c < C) {
 #pragma unroll
@@ -439,8 +439,12 @@ extern "C" int c2w_ln_forward(const void* x, const float* m, void* y, long long 
                               int dtype, void* stream) {
     if (!x || !y || !vec_ok(dtype, C) || C > 16 * LN_MAXV * (dtype == C2W_DTYPE_F32 ? 4 : 8) || C < 2) return C2W_ERR_BAD_SHAPE;
     const float inv_den = 1.0f / (float)(unbiased ? C - 1 : C);
-    DISPATCH_T(dtype, (ln_fwd_kernel<T><<<grid_for(npix, 16, 16384), 256, 0, (hipStream_t)stream>>>((const T*)x, m, (T*)y, npix, HW, C, ldm,
-                                                                                                    eps, inv_den)));
+    const int nv = (C + 16 * (dtype == C2W_DTYPE_F32 ? 4 : 8) - 1) / (16 * (dtype == C2W_DTYPE_F32 ? 4 : 8));
+#define LN_FWD(NVV) DISPATCH_T(dtype, (ln_fwd_kernel<T, NVV><<<grid_for(npix, 16, 16384), 256, 0, (hipStream_t)stream>>>( \
+    (const T*)x, m, (T*)y, npix, HW, C, ldm, eps, inv_den)))
+    if (nv <= 1) LN_FWD(1); else if (nv == 2) LN_FWD(2); else if (nv == 3) LN_FWD(3); else if (nv == 4) LN_FWD(4);
+    else if (nv <= 6) LN_FWD(6); else LN_FWD(8);
+#undef LN_FWD
     return (int)hipGetLastError();
 }
 
@@ -451,8 +455,12 @@ extern "C" int c2w_ln_backward(const void* dy, const void* x, const float* m, co
     if (HW <= 0 || npix % HW != 0) return C2W_ERR_BAD_SHAPE;
     const int ppb = HW < 512 ? HW : 512;
     dim3 grid((HW + ppb - 1) / ppb, (unsigned)(npix / HW));
-    DISPATCH_T(dtype, (ln_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)x, m, (const T*)dres, (T*)dx, dm, HW, C,
-                                                                                 ldm, eps, inv_den, ppb)));
+    const int nv = (C + 16 * (dtype == C2W_DTYPE_F32 ? 4 : 8) - 1) / (16 * (dtype == C2W_DTYPE_F32 ? 4 : 8));
+#define LN_BWD(NVV) DISPATCH_T(dtype, (ln_bwd_kernel<T, NVV><<<grid, 256, 0, (hipStream_t)stream>>>( \
+    (const T*)dy, (const T*)x, m, (const T*)dres, (T*)dx, dm, HW, C, ldm, eps, inv_den, ppb)))
+    if (nv <= 1) LN_BWD(1); else if (nv == 2) LN_BWD(2); else if (nv == 3) LN_BWD(3); else if (nv == 4) LN_BWD(4);
+    else if (nv <= 6) LN_BWD(6); else LN_BWD(8);
+#undef LN_BWD
     return (int)hipGetLastError();
 }
 

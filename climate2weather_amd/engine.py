@@ -356,12 +356,12 @@ class Engine:
             x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
             ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
 
-        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None):
+        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None):
             rec = lay.convs[name]
             ldy_ = ldy or rec.rows
             y = torch.empty((B * Ho * Wo, ldy_), dtype=T, device=dev)
             g = self._geom(B, Hi, Wi, rec.kstride, Ho, Wo, cout or rec.rows, ldy_, rec.rows, mode)
-            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res)
+            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2)
             return y, g, rec
 
         def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None):
@@ -378,11 +378,10 @@ class Engine:
             m = m_all.view(-1)[b.mod_offset:]
             h0 = torch.empty((npix, Cc), dtype=T, device=dev)
             ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
-            a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE if train else ACT_SILU)
-            if train:
-                h1 = torch.empty_like(a1)
-                ops.silu(a1, h1, a1.numel(), dt)
-            else:
+            # training keeps the pre-activation (for silu') and the activation: both come out of the conv's epilogue
+            h1 = torch.empty((npix, Cc), dtype=T, device=dev) if train else None
+            a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE if train else ACT_SILU, y2=h1)
+            if not train:
                 h1 = a1
             out, g2, r2 = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin)
             if train:

@@ -32,14 +32,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _conv_args(x, w, bias, res, mul, y, g, act, mulmode) -> ConvArgs:
-    return ConvArgs(_p(x), _p(w), _p(bias), _p(res), _p(mul), _p(y), g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"],
+def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None) -> ConvArgs:
+    return ConvArgs(_p(x), _p(w), _p(bias), _p(res), _p(mul), _p(y), _p(y2), g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"],
                     g["Cout"], g["ldy"], g["wrows"], g["mode"], act, mulmode)
 
 
-def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False):
+def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode)."""
-    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode)
+    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2)
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 

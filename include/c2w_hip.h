@@ -45,6 +45,7 @@ typedef struct C2wConvArgs {
     const void* res;   /* [B*Hout*Wout][ldy] added last, or NULL   (residual / skip: model/nn.py:28,238) */
     const void* mul;   /* [B*Hout*Wout][ldy] or NULL: y *= mul (C2W_MUL_PLAIN) or y *= silu'(mul) (C2W_MUL_DSILU) */
     void* y;           /* [B*Hout*Wout][ldy] */
+    void* y2;          /* optional second output [B*Hout*Wout][ldy]: silu(y) (training keeps the pre-activation too) */
     int32_t B, Hin, Win, Cin;
     int32_t Hout, Wout, Cout, ldy;
     int32_t wrows;

@@ -48,7 +48,7 @@ def _conv_core(X, Wt, g):
     raise ValueError(mode)
 
 
-def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False):
+def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None):
     B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows = (g[k] for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ldy", "wrows"))
     taps = 1 if g["mode"] == CONV_1X1 else 9
     T = TD[dtype]
@@ -71,6 +71,8 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
     if res is not None:
         out = out + _rows(res, npix, ldy)[:, :Cout].float()
     _rows(y, npix, ldy)[:, :Cout] = out.to(T)
+    if y2 is not None:
+        _rows(y2, npix, ldy)[:, :Cout] = F.silu(out.to(T).float()).to(T)
 
 
 def conv_wgrad(x, dy, dw, g, dtype, dbias=None):

@@ -78,15 +78,19 @@ def test_conv_forward(case, dt, naive):
     bias = rnd((wrows,), F32, 3)
     res = rnd((B * Hout * Wout, ldy), dt, 4)
     mul = rnd((B * Hout * Wout, ldy), dt, 5)
-    for variant in range(4):
-        kw = [dict(), dict(act=ops.ACT_SILU), dict(res=res), dict(mul=mul, mulmode=ops.MUL_DSILU, res=res)][variant]
+    for variant in range(5):
+        kw = [dict(), dict(act=ops.ACT_SILU), dict(res=res), dict(mul=mul, mulmode=ops.MUL_DSILU, res=res), dict()][variant]
         b = None if variant == 3 else bias
         y = torch.full((B * Hout * Wout, ldy), 7.0, dtype=TD[dt], device=dev())
         y_ref = y.clone()
-        ops.conv(x, w, b, y, g, dt, naive=naive, **kw)
-        E.conv(x, w, b, y_ref, g, dt, **kw)
+        y2 = torch.full_like(y, 3.0) if variant == 4 else None  # dual output: pre-activation + silu
+        y2_ref = y2.clone() if variant == 4 else None
+        ops.conv(x, w, b, y, g, dt, naive=naive, y2=y2, **kw)
+        E.conv(x, w, b, y_ref, g, dt, y2=y2_ref, **kw)
         torch.cuda.synchronize()
         close(y, y_ref, dt, f"conv mode={mode} variant={variant} naive={naive}")
+        if variant == 4:
+            close(y2, y2_ref, dt, f"conv second output mode={mode} naive={naive}")
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
