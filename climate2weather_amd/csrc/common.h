@@ -65,9 +65,14 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float a) { return a / (1.0f + __expf(-a)); }
+// SiLU and its derivative on the fast transcendental path (v_exp_f32 + v_rcp_f32, ~1 ulp each): the epilogues evaluate
+// them 64x per thread per tile, where an IEEE division (v_div_scale/fmas/fixup) costs more than the rest of the epilogue.
+__device__ __forceinline__ float sigmoid_f(float a) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * a));
+}
+__device__ __forceinline__ float silu_f(float a) { return a * sigmoid_f(a); }
 __device__ __forceinline__ float dsilu_f(float a) {
-    float s = 1.0f / (1.0f + __expf(-a));
+    const float s = sigmoid_f(a);
     return s * (1.0f + a * (1.0f - s));
 }
 

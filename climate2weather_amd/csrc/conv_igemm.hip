@@ -20,7 +20,7 @@
 //   fp32 : 4 x v_mfma_f32_16x16x4_f32       (4 k-values per lane, exact fp32 fma chain)
 #include <cstdlib>
 
-#include "conv_geom.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -145,6 +145,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    float bv[4][4];  // bias: fetched now, used in the epilogue
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
     issue(0, 0);
     if (NS > 1) issue(1, 1);
     int slot = 0;
@@ -174,69 +176,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
 
-    // ---- epilogue: bias/activation in registers -> LDS tile [pixel][channel] -> coalesced 16-B NHWC stores
+    // ---- epilogue (conv_epilogue.h): bias/activation in registers -> LDS tile [pixel][channel] -> 16-B NHWC stores
     constexpr int OS = BN * ESZ + 16;  // padded row stride
+    EpiStore<T, BM, NTHREADS> est;
+    est.prefetch(p, tid, co0, [&](int row) -> long long {
+        const int Q = tm * BM + row;
+        return Q < npix ? (long long)Q : -1;
+    });
     __syncthreads();
     char* const O = smem;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int col = wm * 64 + m * 16 + lg * 4;
-        float bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (p.bias != nullptr && co0 + col + r < p.wrows) ? p.bias[co0 + col + r] : 0.f;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int row = wn * 64 + n * 16 + li;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[m][n][r] + bv[r];
-                if (p.act == C2W_ACT_SILU) v[r] = silu_f(v[r]);
-            }
-            if constexpr (ESZ == 4) {
-                *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
-            } else {
-                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            }
-        }
-    }
+    epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
     __syncthreads();
-    constexpr int SEGS = BN * ESZ / 16;
-    constexpr int PER16 = 16 / ESZ;
-    for (int seg = tid; seg < BM * SEGS; seg += NTHREADS) {
-        const int row = seg / SEGS, cs = seg - row * SEGS;
-        const int Q = tm * BM + row;
-        const int c = co0 + cs * PER16;
-        if (Q < npix && c < p.Cout) {
-            u32x4_t v = *(const u32x4_t*)(O + row * OS + cs * 16);
-            const size_t off = ((size_t)Q * p.ldy + c) * ESZ;
-            if (p.mul != nullptr || p.res != nullptr) {
-                float f[PER16];
-                unpack16<T>(v, f);
-                if (p.mul != nullptr) {
-                    float g[PER16];
-                    unpack16<T>(*(const u32x4_t*)((const char*)p.mul + off), g);
-#pragma unroll
-                    for (int e = 0; e < PER16; ++e) f[e] *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(g[e]) : g[e];
-                }
-                if (p.res != nullptr) {
-                    float g[PER16];
-                    unpack16<T>(*(const u32x4_t*)((const char*)p.res + off), g);
-#pragma unroll
-                    for (int e = 0; e < PER16; ++e) f[e] += g[e];
-                }
-                v = pack16<T>(f);
-            }
-            *(u32x4_t*)((char*)p.y + off) = v;
-            if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
-                float f2[PER16];
-                unpack16<T>(v, f2);
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) f2[e] = silu_f(f2[e]);
-                *(u32x4_t*)((char*)p.y2 + off) = pack16<T>(f2);
-            }
-        }
-    }
+    est.finish(p, O, OS, tid);
 }
 
 // ---- slow, obviously-correct direct convolution with the same argument block (debug / cross-check only)

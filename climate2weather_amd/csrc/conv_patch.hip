@@ -12,7 +12,7 @@
 //     (patch of the NEXT chunk trickles in during taps 0..6), counted vmcnt, one raw s_barrier;
 //   * weights ring: 3 slots of [128 co][128 B]; slot = tap % 3 is a compile-time constant.
 // Same MFMA tiling as conv_igemm.hip: 256 px x 128 co per block, 8 waves x (4x4) 16x16 tiles, A = weights, B = pixels.
-#include "conv_geom.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -154,6 +154,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wCon
     const int nchunk = p.Cin / CK;
     const int NS = nchunk * 9;
 
+    float bv[4][4];  // bias: fetched now, used in the epilogue (its latency hides under the main loop)
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+
     // prologue: patch of chunk 0, weights of stages 0 and 1
 #pragma unroll
     for (int r = 0; r < 7; ++r) glds16(rx, smem + pdst[r], pvo[r], 0);
@@ -219,69 +222,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wCon
 #pragma unroll
         for (int n = 0; n < 4; ++n) mma_x<T>(da[m], db[n], acc[m][n]);
 
-    // ---- epilogue (as conv_igemm.hip): bias/activation in registers -> LDS [pixel][channel] -> 16-B NHWC stores
+    // ---- epilogue (conv_epilogue.h): bias/activation in registers -> LDS [pixel][channel] -> 16-B NHWC stores
     constexpr int OS = 128 * ESZ + 16;
+    EpiStore<T, 256, NTHREADS> est;
+    est.prefetch(p, tid, co0, [&](int row) -> long long {
+        return ((long long)b * H + oh0 + (row >> 4)) * W + ow0 + (row & 15);
+    });
     __syncthreads();
     char* const O = smem;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int col = wm * 64 + m * 16 + lg * 4;
-        float bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (p.bias != nullptr && co0 + col + r < p.wrows) ? p.bias[co0 + col + r] : 0.f;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int row = wn * 64 + n * 16 + li;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[m][n][r] + bv[r];
-                if (p.act == C2W_ACT_SILU) v[r] = silu_f(v[r]);
-            }
-            if constexpr (ESZ == 4) {
-                *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
-            } else {
-                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            }
-        }
-    }
+    epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
     __syncthreads();
-    constexpr int SEGS = 128 * ESZ / 16;
-    constexpr int PER16 = 16 / ESZ;
-    for (int seg = tid; seg < 256 * SEGS; seg += NTHREADS) {
-        const int row = seg / SEGS, cs = seg - row * SEGS;
-        const int c = co0 + cs * PER16;
-        if (c < p.Cout) {
-            const size_t Q = ((size_t)b * H + oh0 + (row >> 4)) * W + ow0 + (row & 15);
-            u32x4_t v = *(const u32x4_t*)(O + row * OS + cs * 16);
-            const size_t off = (Q * p.ldy + c) * ESZ;
-            if (p.mul != nullptr || p.res != nullptr) {
-                float f[PER16];
-                unpack16<T>(v, f);
-                if (p.mul != nullptr) {
-                    float g[PER16];
-                    unpack16<T>(*(const u32x4_t*)((const char*)p.mul + off), g);
-#pragma unroll
-                    for (int e = 0; e < PER16; ++e) f[e] *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(g[e]) : g[e];
-                }
-                if (p.res != nullptr) {
-                    float g[PER16];
-                    unpack16<T>(*(const u32x4_t*)((const char*)p.res + off), g);
-#pragma unroll
-                    for (int e = 0; e < PER16; ++e) f[e] += g[e];
-                }
-                v = pack16<T>(f);
-            }
-            *(u32x4_t*)((char*)p.y + off) = v;
-            if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
-                float f2[PER16];
-                unpack16<T>(v, f2);
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) f2[e] = silu_f(f2[e]);
-                *(u32x4_t*)((char*)p.y2 + off) = pack16<T>(f2);
-            }
-        }
-    }
+    est.finish(p, O, OS, tid);
 }
 
 template <typename T>

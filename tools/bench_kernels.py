@@ -15,6 +15,7 @@ p.add_argument("--iters", type=int, default=10)
 p.add_argument("--dtypes", default="bf16,fp32")
 p.add_argument("--only", type=int, default=-1, help="run only SHAPES[i]")
 p.add_argument("--kind", default="conv,wgrad,ln")
+p.add_argument("--act", type=int, default=1)
 a = p.parse_args()
 dev = torch.device("cuda:0")
 
@@ -52,7 +53,7 @@ for dname in a.dtypes.split(","):
         dw = torch.zeros(Cout * 9 * Cin, device=dev)
         flops = 2.0 * B * Ho * Ho * Cout * 9 * Cin
         if "conv" in a.kind:
-          ms = timeit(lambda: ops.conv(x, w, bias, y, g, dt, act=ops.ACT_SILU), a.iters)
+          ms = timeit(lambda: ops.conv(x, w, bias, y, g, dt, act=a.act), a.iters)
           print(f"conv   {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
         if "wgrad" in a.kind:
           ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt), a.iters)
