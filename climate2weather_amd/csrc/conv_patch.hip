@@ -12,6 +12,8 @@
 //     (patch of the NEXT chunk trickles in during taps 0..6), counted vmcnt, one raw s_barrier;
 //   * weights ring: 3 slots of [128 co][128 B]; slot = tap % 3 is a compile-time constant.
 // Same MFMA tiling as conv_igemm.hip: 256 px x 128 co per block, 8 waves x (4x4) 16x16 tiles, A = weights, B = pixels.
+#include <cstdlib>
+
 #include "conv_epilogue.h"
 
 namespace {
@@ -42,7 +44,13 @@ template <> struct Mma<float> {
 template <int N> struct IC { static constexpr int value = N; };
 
 #ifndef C2W_EXP
-#define C2W_EXP 0  // diagnostic timing builds only: 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA in the loop, 8 no barrier
+#define C2W_EXP 0  // diagnostic timing builds only: 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA in the loop, 8 no barrier,
+#endif             // 16 cycle stamps (s_memtime) to the buffer registered with c2w_debug_set (tools/stamp_conv_patch.py)
+#if C2W_EXP & 16
+__device__ unsigned long long* c2w_dbg = nullptr;
+#define C2W_STAMP(var) var = __builtin_amdgcn_s_memtime()
+#else
+#define C2W_STAMP(var) (void)0
 #endif
 template <typename T>
 __device__ __forceinline__ void mma_x(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
@@ -235,6 +243,195 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wCon
     est.finish(p, O, OS, tid);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant.  Cycle stamps (profiles/r01_stamps_conv_patch.md) show a 256-pixel tile spending 40-48 %
+// of its cycles in its prologue / epilogue (plus the gap between workgroups), and the 156-KiB kernel above admits one
+// workgroup per CU, so nothing runs meanwhile.  This variant is the same pipeline on HALF the tile -- 8x16 output pixels,
+// 4 waves (2 over channels x 2 over pixels, each still a 64x64 MFMA sub-tile) -- with one patch buffer and the 3-slot
+// weight ring: 30,720 + 49,152 = 79,872 B, so TWO workgroups share a CU (8 waves, 2 per SIMD, independent barriers):
+// one's prologue, chunk-boundary patch load and epilogue overlap the other's MFMAs.
+constexpr int H_NTHR = 256;
+constexpr int H_NPIECE = 10 * 3;              // (8+2) patch rows x 3 pieces
+constexpr int H_PBYTES = H_NPIECE * 1024;     // 30,720
+constexpr int H_LDS = H_PBYTES + 3 * WBYTES;  // 79,872
+
+__device__ __forceinline__ void wait_vm4(int n) {  // wave-uniform n in {0, 4}
+    if (n == 4) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wConvArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int CK = 128 / ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [patch | W0 | W1 | W2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int nN = (p.Cout + 127) / 128;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hin, W = p.Win;
+    const int tw = W >> 4, tpi = (H >> 3) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 3, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    // patch pieces: 30 pieces over 4 waves = 8 rounds (pieces past the end repeat the last one)
+    uint32_t pvo[8];
+    int pdst[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int pc = r * 4 + wid;
+        pc = pc < H_NPIECE ? pc : H_NPIECE - 1;
+        const int pr = pc / 3, pg = pc - pr * 3;
+        const int px = pg * 8 + (lane >> 3);
+        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+        const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+        pdst[r] = pc * 1024;
+    }
+    uint32_t wvo[4];  // weight tile: 128 rows x 8 chunks = 4 rounds of 256 threads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+    auto issue_w = [&](int chunk, int tap, int wslot) {
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rw, smem + H_PBYTES + wslot * WBYTES + wid * 1024 + i * 4096, wvo[i], so);
+    };
+    auto issue_patch = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) glds16(rx, smem + pdst[r], pvo[r], (uint32_t)chunk * 128u);
+    };
+
+    uint32_t offA[2][4], preB[2][3][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = wm * 64 + m * 16 + li;
+            offA[ks][m] = (uint32_t)(H_PBYTES + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int px = li + kw;
+                preB[ks][kw][n] = (uint32_t)(((wn * 4 + n) * PW + px) * 128 + (((ks * 4 + lg) ^ (px & 7)) << 4));
+            }
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * 9;
+
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    C2W_STAMP(st0);
+    issue_patch(0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    float bv[4][4];
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    int np = 4;  // LDS-DMA pieces of the previous stage that may still be in flight
+    u32x4_t da[4] = {}, db[4] = {};
+
+    auto stage = [&](auto TAPc, int c) {
+        constexpr int TAP = decltype(TAPc)::value;
+        constexpr int KH = TAP / 3, KW = TAP % 3, WS = TAP % 3, T2 = (TAP + 2) % 9;
+        const int s = c * 9 + TAP;
+        wait_vm4(np);
+        __builtin_amdgcn_s_barrier();
+        if (s == 0) C2W_STAMP(st1);
+        if (TAP == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+            issue_patch(c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        np = 0;
+        if (s + 2 < NS) {
+            issue_w(TAP + 2 >= 9 ? c + 1 : c, T2, (TAP + 2) % 3);
+            np = 4;
+        }
+        u32x4_t a0[4], b0[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA[0][m] + WS * WBYTES);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b0[n] = *(const u32x4_t*)(smem + preB[0][KW][n] + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + offA[1][m] + WS * WBYTES);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) db[n] = *(const u32x4_t*)(smem + preB[1][KW][n] + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        stage(IC<0>{}, c); stage(IC<1>{}, c); stage(IC<2>{}, c); stage(IC<3>{}, c); stage(IC<4>{}, c);
+        stage(IC<5>{}, c); stage(IC<6>{}, c); stage(IC<7>{}, c); stage(IC<8>{}, c);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+
+    constexpr int OS = 128 * ESZ + 16;
+    C2W_STAMP(st2);
+    EpiStore<T, 128, H_NTHR> est;
+    est.prefetch(p, tid, co0, [&](int row) -> long long {
+        return ((long long)b * H + oh0 + (row >> 4)) * W + ow0 + (row & 15);
+    });
+    __syncthreads();
+    char* const O = smem;
+    epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
+    __syncthreads();
+    C2W_STAMP(st3);
+    est.finish(p, O, OS, tid);
+    C2W_STAMP(st4);
+#if C2W_EXP & 16
+    if (tid == 0 && c2w_dbg != nullptr) {
+        unsigned long long* d = c2w_dbg + (size_t)L * 5;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4;
+    }
+#endif
+}
+
 template <typename T>
 int launch(const C2wConvArgs& a, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
@@ -245,7 +442,20 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_s1_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    const int nM = a.B * (a.Hin >> 4) * (a.Win >> 4), nN = (a.Cout + 127) / 128;
+    const int nN = (a.Cout + 127) / 128;
+    if (getenv("C2W_CONV_FULL") == nullptr) {  // two half-tile workgroups per CU
+        static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
+        static bool attr_h = false;
+        if (!attr_h) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            attr_h = true;
+        }
+        const int nMh = a.B * (a.Hin >> 3) * (a.Win >> 4);
+        const int lds_h = getenv("C2W_HALF_ONE_PER_CU") ? 100 * 1024 : H_LDS;  // diagnostic: forbid co-residency
+        conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, lds_h, st>>>(a);
+        return (int)hipGetLastError();
+    }
+    const int nM = a.B * (a.Hin >> 4) * (a.Win >> 4);
     conv_patch_s1_kernel<T><<<nM * nN, NTHREADS, lds, st>>>(a);
     return (int)hipGetLastError();
 }
@@ -262,3 +472,7 @@ int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {
     if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, st);
     return C2W_ERR_BAD_ARG;
 }
+
+#if C2W_EXP & 16
+extern "C" int c2w_debug_set(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(c2w_dbg), &ptr, sizeof(void*)); }
+#endif

@@ -11,7 +11,7 @@ g = dict(B=B, Hin=H, Win=H, Cin=C, Hout=H, Wout=H, Cout=C, ldy=C, wrows=C, mode=
 x = torch.randn(B*H*H, C, device=dev).to(T); w = (torch.randn(C, 9, C, device=dev)/math.sqrt(9*C)).to(T)
 bias = torch.randn(C, device=dev); y = torch.empty(B*H*H, C, device=dev, dtype=T)
 res = torch.randn(B*H*H, C, device=dev).to(T)
-ntile = B*(H//16)**2
+ntile = B*(H//16)**2 * (1 if os.environ.get('C2W_CONV_FULL') else 2)
 dbg = torch.zeros(ntile*5, dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.c2w_debug_set.argtypes = [ctypes.c_void_p]
