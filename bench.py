@@ -98,9 +98,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("C2W_FORCE_DIST"):  # C2W_FORCE_DIST: exercise the RCCL path with a single rank
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -162,7 +164,7 @@ def main():
         roof = None
         if k_ms:
             ach = flops_launch / (k_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="conv_patch_s1_kernel<bf16> 128->128 @%dx%d (res-block conv fwd + dgrad)" % (a.size, a.size),
+            roof = dict(bound="mfma", kernel="conv_patch_half_kernel<bf16> 128->128 @%dx%d (res-block conv fwd + dgrad)" % (a.size, a.size),
                         achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                         traffic=None, launches_timed=k_n, avg_launch_ms=round(k_ms, 4), flops_per_launch=flops_launch)
         out = dict(metric="UNet denoise steps/sec (train fwd+bwd+allreduce+AdamW+EMA windows/s)", value=round(value, 2), unit="windows/s",
@@ -200,7 +202,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

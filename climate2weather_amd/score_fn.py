@@ -74,8 +74,11 @@ class AbstractScoreFunction:
             with torch.set_grad_enabled(exact_grad):
                 eps_pred = self.noise_process.pred_eps(self.score_fn, x, t)
             x0_pred = (x - sigma * eps_pred) / mu
-            err = y - A(x0_pred)
-            var = std**2 + gamma * (sigma / mu) ** 2
+            # the observation follows the state: the reference keeps both on the host, the device-resident sampler in HBM
+            yy = y.to(x.device) if isinstance(y, torch.Tensor) else y
+            sd = std.to(x.device) if isinstance(std, torch.Tensor) else std
+            err = yy - A(x0_pred)
+            var = sd**2 + gamma * (sigma / mu) ** 2
             return -(err**2 / var).sum() / 2, (eps_pred, sigma)
 
         self.likelihood = log_p

@@ -39,6 +39,7 @@ class Trainer:
         self.loss_scaling = loss_scaling
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.sync_grads = self.world > 1 or (bool(os.environ.get("C2W_FORCE_DIST")) and dist.is_initialized())
         self.batch_size = batch_size  # global batch (items per optimizer step); None -> B_gpu * world
         self.cur_ndata = 0
         self.step_count = 0
@@ -51,7 +52,7 @@ class Trainer:
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ema_flats = [eng.flat.clone() for _ in self.ema_rates]
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-        if self.world > 1:  # same initial weights everywhere (DDP's initial broadcast)
+        if self.sync_grads:  # same initial weights everywhere (DDP's initial broadcast)
             dist.broadcast(eng.flat, src=0, group=self.pg)
             eng.weights_changed()
             for e in self.ema_flats:
@@ -95,8 +96,8 @@ class Trainer:
         for r, x in enumerate(batches):
             last = r == len(batches) - 1
             loss = self._forward_backward(x, t if last or t is None else None, eps if last or eps is None else None,
-                                          sync=last and self.world > 1)
-        if self.world > 1:
+                                          sync=last and self.sync_grads)
+        if self.sync_grads:
             self._finish_allreduce()
         lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
         self.step_count += 1

@@ -1,0 +1,242 @@
+"""GPU parity of the host-level paths that sit around the network: the training step (training_loop.py:369-391), the
+sliding-window score functions and the predictor/corrector sampler (src/thor/score.py, src/thor/pipelines.py), and the
+sampler's fused HIP update kernels (csrc/sampler.hip), against the golden vectors of the imported reference and the
+CPU oracle.  fp32 mode, tolerances as stated per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import emu_ops
+from climate2weather_amd import ops
+from climate2weather_amd.ops import DTYPE_BF16, DTYPE_F32
+from climate2weather_amd.pipelines import SDAPipeline
+from climate2weather_amd.score import ScoreUNet
+from climate2weather_amd.score_fn import BatchedScoreFunction, DefaultScoreFunction, PoolStrideOperator
+from climate2weather_amd.training import Trainer
+from oracle import diffusion as od
+from oracle import host as oh
+from oracle import unet as ou
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3,
+            padding_mode="zeros")
+DEFAULT = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3,
+               padding_mode="zeros", attention_levels=[4])
+TD = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
+
+
+def _golden(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name), allow_pickle=False).items()}
+
+
+def _tiny(seed=3):
+    torch.manual_seed(seed)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).cuda()
+    net.precision = "fp32"
+    return net
+
+
+def _assert_adam_close(v, ref, grad, lr, name):
+    big = grad.abs() > 1e-5  # see tests/test_host_emulated.py: g/(|g|+eps) is ill-conditioned where |g| ~ eps
+    assert torch.allclose(v[big], ref[big], atol=3e-6), name
+    assert (v - ref).abs().max().item() <= 2.0 * lr, name
+
+
+# ------------------------------------------------------------------------------------------------ training step (a13)
+def test_training_step_fp32_vs_golden(golden_dir):
+    g = _golden(golden_dir, "tiny_net.npz")
+    net = _tiny()
+    tr = Trainer(net, lr=1e-3, precision="fp32", ema_rates=[0.9, 0.999])
+    x, t, eps = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "eps"))
+    loss = tr.step(x, t=t.reshape(-1), eps=eps)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-4)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    for k in [str(n) for n in g["param_order"]]:
+        p, gr = torch.from_numpy(g["sd." + k]), torch.from_numpy(g["grad." + k])
+        exp = oh.adamw_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3)[0]
+        _assert_adam_close(sd[k], exp, gr, 1e-3, k)
+    for rate, esd in tr.ema_state_dicts():
+        for k, v in esd.items():
+            ref = oh.ema_update(torch.from_numpy(g["sd." + k]), sd[k], rate)
+            assert torch.allclose(v.cpu(), ref, atol=1e-6), k
+
+
+def test_config0_ten_training_steps_follow_the_oracle():
+    """BASELINE.json configs[0]: default net, 1 variable x window 13 = 13 channels, 32x32, batch 2, 10 optimizer steps.
+    The HIP trainer and the CPU oracle (autograd + oracle.host.adamw_step) start from the same weights and see the same
+    (x, t, eps) every step; fp32; per-step losses agree to 1e-3 relative (ten steps of accumulated fp32 reordering),
+    and the weights after step 10 (each moved ~10 * lr = 1e-3) to 1e-4 max / 5e-6 mean absolute -- Adam's g/(sqrt(v)+eps)
+    turns gradient noise on near-zero gradients into O(lr) differences, hence the two-level bound."""
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=13, spatial=2, activation=torch.nn.SiLU, **DEFAULT)
+    ref = ou.OracleScoreUNet(net.state_dict(), DEFAULT["hidden_blocks"], DEFAULT["attention_levels"])
+    net = net.cuda()
+    net.precision = "fp32"
+    lr, steps = 1e-4, 10
+    tr = Trainer(net, lr=lr, precision="fp32", ema_rates=[0.9999])
+    m = [torch.zeros_like(p) for p in ref.params]
+    v = [torch.zeros_like(p) for p in ref.params]
+    gen = torch.Generator().manual_seed(7)
+    for s in range(1, steps + 1):
+        x = torch.randn(2, 13, 32, 32, generator=gen) * 0.5 + 0.5
+        t = torch.rand(2, generator=gen)
+        eps = torch.randn(2, 13, 32, 32, generator=gen)
+        got = float(tr.step(x.cuda(), t=t.cuda(), eps=eps.cuda()))
+        for p in ref.parameters():
+            p.grad = None
+        loss = od.loss(ref, x, t.view(-1, 1, 1, 1), eps).mean()
+        loss.backward()
+        with torch.no_grad():
+            for i, p in enumerate(ref.params):
+                newp, m[i], v[i] = oh.adamw_step(p.detach(), p.grad, m[i], v[i], s, lr)
+                p.copy_(newp)
+        assert got == pytest.approx(loss.item(), rel=1e-3), s
+    sd = net.state_dict()
+    for n, p in ref.sd().items():
+        d = (sd[n].cpu() - p.detach()).abs()
+        assert d.max().item() <= 1e-4 and d.mean().item() <= 5e-6, (n, d.max().item(), d.mean().item())
+
+
+# ------------------------------------------------------------------------------------------------ sampler (a10 - a12)
+@pytest.mark.parametrize("name,corrections,cond,exact,op", [
+    ("uncond_c0", 0, False, False, None), ("uncond_c1", 1, False, False, None),
+    ("cond_c0", 0, True, False, "pool"), ("cond_c0", 0, True, False, "generic"), ("cond_c1_exact", 1, True, True, "pool")])
+@pytest.mark.parametrize("fused", [True, False])
+def test_sampler_trajectories_vs_golden(golden_dir, name, corrections, cond, exact, op, fused):
+    """Trajectory end points of the imported reference (tiny net, L=9, F=2, k=1, 32x32, 4 steps, recorded corrector draws).
+    fused=True: state stays in HBM, csrc/sampler.hip update kernels; fused=False: the reference's torch update rule with
+    the state on the host and window batches going through the HIP network."""
+    s = _golden(golden_dir, "sampler.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    dev = torch.device("cuda", 0)
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=dev, noise_process=pipe)
+    if cond:
+        A = PoolStrideOperator(8, 2) if op == "pool" else (lambda z: F.avg_pool2d(z[::2], 8))
+        sf.condition_on(A=A, y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=float(s["gamma"]),
+                        exact_grad=exact)
+    sf.device_resident = fused
+    zs = [torch.from_numpy(z) for z in s[name + ".z"]] if corrections else None
+    xs = pipe.sample(sf, torch.from_numpy(s[name + ".noise"]), steps=4, corrections=corrections, tau=0.5,
+                     device=dev if fused else torch.device("cpu"), show_progressbar=False, z_draws=zs)
+    ref = torch.from_numpy(s[name + ".x"])
+    assert (xs.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+
+
+def test_score_functions_vs_golden(golden_dir):
+    s = _golden(golden_dir, "sampler.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    x = torch.from_numpy(s["score_x"])
+    for sf in (DefaultScoreFunction(net, markov_order=1, noise_process=pipe),
+               BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cuda", 0), noise_process=pipe)):
+        with torch.no_grad():
+            y = sf(x.cuda(), torch.tensor(0.7))
+        assert torch.allclose(y.cpu(), torch.from_numpy(s["score_y"]), atol=2e-5)
+
+
+def test_nan_in_state_raises_on_the_device_path():
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cuda", 0), noise_process=pipe)
+    noise = torch.randn(5, 2, 16, 16)
+    noise[0, 0, 0, 0] = float("nan")
+    with pytest.raises(ValueError, match="NaN detected"):
+        pipe.sample(sf, noise, steps=2, show_progressbar=False)
+
+
+# ------------------------------------------------------------------------------------------------ csrc/sampler.hip kernels
+@pytest.mark.parametrize("dtype", [DTYPE_F32, DTYPE_BF16])
+@pytest.mark.parametrize("L,Fv,k,H,i0,nw", [(9, 2, 1, 16, 0, 7), (9, 2, 1, 16, 3, 4), (20, 4, 6, 32, 0, 8), (20, 4, 6, 32, 5, 3),
+                                            (14, 5, 6, 8, 0, 2), (3, 1, 1, 8, 0, 1)])
+def test_window_gather_scatter_vs_emulation(dtype, L, Fv, k, H, i0, nw):
+    """unfold (src/thor/score.py:122-133) straight into padded NHWC rows, and fold (:135-154) straight out of them."""
+    w = 2 * k + 1
+    HW = H * H
+    ldc = (w * Fv + 7) // 8 * 8
+    nwin = L - w + 1
+    gen = torch.Generator().manual_seed(L * 100 + i0)
+    x = torch.randn(L, Fv, H, H, generator=gen)
+    y_ref = torch.full((nw * HW, ldc), 7.0, dtype=TD[dtype])
+    emu_ops.window_gather(x, y_ref, nw, Fv, HW, k, i0, ldc, dtype)
+    y = torch.full((nw * HW, ldc), 7.0, dtype=TD[dtype], device="cuda")
+    ops.window_gather(x.cuda(), y, nw, Fv, HW, k, i0, ldc, dtype)
+    assert torch.equal(y.cpu(), y_ref)
+    net_out = torch.randn(nw * HW, ldc, generator=gen).to(TD[dtype])
+    e_ref = torch.full((L, Fv, H, H), -3.0)
+    emu_ops.window_scatter(net_out, e_ref, nw, Fv, HW, k, i0, nwin, ldc, dtype)
+    e = torch.full((L, Fv, H, H), -3.0, device="cuda")
+    ops.window_scatter(net_out.cuda(), e, nw, Fv, HW, k, i0, nwin, ldc, dtype)
+    assert torch.equal(e.cpu(), e_ref)
+
+
+def test_unfold_fold_round_trip_at_full_size():
+    """Size-independent property at the sampler's shipped shape (L=49, F=4, k=6, 128x128): scattering the gathered
+    windows back (fold o unfold) reproduces the trajectory exactly, whatever the window batching."""
+    L, Fv, k, H = 49, 4, 6, 128
+    w, HW = 2 * k + 1, H * H
+    ldc = (w * Fv + 7) // 8 * 8
+    nwin = L - w + 1
+    x = torch.randn(L, Fv, H, H, device="cuda")
+    out = torch.zeros_like(x)
+    for i0 in range(0, nwin, 16):
+        nw = min(16, nwin - i0)
+        y = torch.empty(nw * HW, ldc, device="cuda")
+        ops.window_gather(x, y, nw, Fv, HW, k, i0, ldc, DTYPE_F32)
+        ops.window_scatter(y, out, nw, Fv, HW, k, i0, nwin, ldc, DTYPE_F32)
+    assert torch.equal(out, x)
+
+
+@pytest.mark.parametrize("n", [1, 1000, 9 * 2 * 32 * 32, 49 * 4 * 128 * 128 + 3])
+def test_predict_correct_sumsq_vs_emulation(n):
+    gen = torch.Generator().manual_seed(n)
+    x, eps, z = (torch.randn(n, generator=gen) for _ in range(3))
+    a, b, tau, sg = 1.0123, -0.0456, 0.5, 0.8
+    xr = x.clone()
+    emu_ops.sampler_predict(xr, eps, None, n, a, b)
+    xg, flag = x.cuda(), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.sampler_predict(xg, eps.cuda(), flag, n, a, b)
+    assert torch.allclose(xg.cpu(), xr, rtol=1e-6, atol=1e-6) and int(flag) == 0
+    ss_ref = torch.zeros(1, dtype=torch.float64)
+    ss_ref += eps.double().square().sum()
+    ss = torch.zeros(1, device="cuda")
+    ops.sumsq(eps.cuda(), ss, n)
+    assert float(ss) == pytest.approx(float(ss_ref), rel=1e-5)
+    ssr = ss.cpu().clone()
+    emu_ops.sampler_correct(xr, eps, z, ssr, None, n, tau, sg)
+    ops.sampler_correct(xg, eps.cuda(), z.cuda(), ss, flag, n, tau, sg)
+    assert torch.allclose(xg.cpu(), xr, rtol=1e-5, atol=1e-5) and int(flag) == 0
+    # non-finite state raises the flag (src/thor/pipelines.py:90-91)
+    xg[n // 2] = float("inf")
+    ops.sampler_predict(xg, eps.cuda(), flag, n, a, b)
+    assert int(flag) != 0
+
+
+@pytest.mark.parametrize("L,Fv,H,s_step,t_step", [(9, 2, 32, 8, 2), (13, 4, 128, 16, 6), (12, 4, 64, 16, 6), (5, 1, 16, 4, 1)])
+def test_guidance_kernel_vs_emulation_and_autograd(L, Fv, H, s_step, t_step):
+    """exact_grad=False guidance (src/thor/score.py:24-42) for A = AvgPool2d(s) o [::t] (exp/downscaling.py:129-132):
+    eps <- eps - sigma * d/dx log p(y|x), closed form in one kernel; checked against the emulation and against
+    torch.autograd of the log-likelihood itself."""
+    gen = torch.Generator().manual_seed(L)
+    nobs = (L + t_step - 1) // t_step
+    x = torch.randn(L, Fv, H, H, generator=gen)
+    eps = torch.randn(L, Fv, H, H, generator=gen)
+    yobs = torch.randn(nobs, Fv, H // s_step, H // s_step, generator=gen)
+    std = torch.rand(Fv, generator=gen) * 0.5 + 0.2
+    mu, sigma, gamma = 0.6, 0.8, 1e-2
+    e_ref = eps.clone()
+    emu_ops.guidance(x, e_ref, yobs, std, nobs, Fv, H, H, s_step, t_step, mu, sigma, gamma)
+    e = eps.cuda()
+    ops.guidance(x.cuda(), e, yobs.cuda(), std.cuda(), nobs, Fv, H, H, s_step, t_step, mu, sigma, gamma)
+    assert torch.allclose(e.cpu(), e_ref, rtol=1e-5, atol=1e-5)
+    xa = x.clone().requires_grad_(True)
+    x0 = (xa - sigma * eps) / mu
+    err = yobs - F.avg_pool2d(x0[::t_step], s_step)
+    var = std.view(1, Fv, 1, 1) ** 2 + gamma * (sigma / mu) ** 2
+    logp = -(err ** 2 / var).sum() / 2
+    (J,) = torch.autograd.grad(logp, xa)
+    assert torch.allclose(e.cpu(), eps - sigma * J, rtol=1e-4, atol=1e-5)
