@@ -75,13 +75,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     const int HWo = p.Hout * p.Wout;
     const int npix = p.B * HWo;
 
+    // ---- TS2 (input gradient of the stride-2 conv): an output pixel (oh, ow) only receives taps with kh = oh + 1 (mod 2),
+    //      kw = ow + 1 (mod 2) -- 4, 2, 2 or 1 of the 9.  When the image is even-sized and a quarter of the pixels fills whole
+    //      tiles, tiles are formed per parity class (heaviest class first) and their K loop walks only the class's taps.
+    bool par = false;
+    int pa = 0, pw = 0, psh = 0;  // row / column parity of the tile's class, log2(number of taps)
+    const int Wh = p.Wout >> 1, HWq = HWo >> 2, nq = npix >> 2;
+    if constexpr (MODE == C2W_CONV_TS2) {
+        par = ((p.Hout | p.Wout) & 1) == 0 && nq % BM == 0;
+        if (par) {
+            const int cls = (tm * BM) / nq;
+            pa = cls < 2;
+            pw = (cls & 1) == 0;
+            psh = pa + pw;
+        }
+    }
     // ---- buffer descriptors (wave-uniform).  x: rebased at the tile's first image so offsets stay < 2^31.
-    const int b0 = (tm * BM) / HWo;
+    const int b0 = (MODE == C2W_CONV_TS2 && par) ? ((tm * BM) % nq) / HWq : (tm * BM) / HWo;
     const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
     size_t xrem = (size_t)(p.B - b0) * img_bytes;
     if (xrem > 0x7fffffffu) xrem = 0x7fffffffu;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b0 * img_bytes, (uint32_t)xrem);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * NT * p.Cin * ESZ));
+
+    // tile row -> output pixel (b, oh, ow); identity order unless the tile belongs to a parity class
+    auto row_pixel = [&](int Q, int& b, int& oh, int& ow) {
+        if (MODE == C2W_CONV_TS2 && par) {
+            const int qq = Q % nq;
+            b = qq / HWq;
+            const int rem = qq - b * HWq;
+            const int yh = rem / Wh;
+            oh = 2 * yh + pa;
+            ow = 2 * (rem - yh * Wh) + pw;
+        } else {
+            b = Q / HWo;
+            const int rem = Q - b * HWo;
+            oh = rem / p.Wout;
+            ow = rem - oh * p.Wout;
+        }
+    };
 
     // ---- per-thread staging slots: pixel tile = 256 rows x 8 slots(16 B) = 4 rounds; weight tile = 2 rounds
     int pb[4], pyx[4];
@@ -90,10 +122,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     for (int i = 0; i < 4; ++i) {
         const int q = (tid >> 3) + 64 * i;
         const int Q = tm * BM + q;
-        const int b = Q / HWo;
-        const int rem = Q - b * HWo;
-        const int oh = rem / p.Wout;
-        const int ow = rem - oh * p.Wout;
+        int b, oh, ow;
+        row_pixel(Q, b, oh, ow);
         pb[i] = (Q < npix) ? (b - b0) * p.Hin : -1;
         pyx[i] = (oh << 16) | ow;
         plc[i] = (uint32_t)(((tid & 7) ^ (q & 7)) << 4);
@@ -106,12 +136,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     }
 
     const int nchunk = p.Cin / CK;
-    const int NS = nchunk * NT;
+    const int NS = (MODE == C2W_CONV_TS2 && par) ? (nchunk << psh) : nchunk * NT;
 
     auto issue = [&](int s, int buf) {
-        const int chunk = s / NT;
-        const int tap = s - chunk * NT;
-        const int kh = tap / 3, kw = tap - kh * 3;
+        int chunk, kh, kw;
+        if (MODE == C2W_CONV_TS2 && par) {
+            chunk = s >> psh;
+            const int ti = s - (chunk << psh);  // (kh index, kw index) inside the class: kh in {0,2} if pa else {1}
+            kh = pa ? 2 * (ti >> pw) : 1;
+            kw = pw ? 2 * (ti & 1) : 1;
+        } else {
+            chunk = s / NT;
+            const int tap0 = s - chunk * NT;
+            kh = tap0 / 3;
+            kw = tap0 - kh * 3;
+        }
+        const int tap = kh * 3 + kw;
         char* const pdst = Pbuf + buf * PBYTES + wid * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -181,7 +221,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     EpiStore<T, BM, NTHREADS> est;
     est.prefetch(p, tid, co0, [&](int row) -> long long {
         const int Q = tm * BM + row;
-        return Q < npix ? (long long)Q : -1;
+        if (Q >= npix) return -1;
+        if (MODE == C2W_CONV_TS2 && par) {
+            int b, oh, ow;
+            row_pixel(Q, b, oh, ow);
+            return ((long long)b * p.Hout + oh) * p.Wout + ow;
+        }
+        return (long long)Q;
     });
     __syncthreads();
     char* const O = smem;

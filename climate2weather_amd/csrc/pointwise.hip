@@ -1,6 +1,7 @@
 // HBM-bound kernels around the convolutions: channel LayerNorm (+ time modulation) forward/backward,
 // layout changes at the NCHW fp32 boundary, noise process / loss, reductions, optimizer.
 // All are streaming kernels: 16-byte vector accesses, fp32 math, wave-level (16-lane sub-group) reductions.
+#include <algorithm>
 #include "common.h"
 #include "c2w_hip.h"
 
@@ -339,6 +340,111 @@ __global__ __launch_bounds__(256) void mse_loss_grad_kernel(const T* __restrict_
     if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
 }
 
+// ---- LDS-tiled layout kernels: one block = one image x 128 pixels.  Channel planes (NCHW fp32) are read as coalesced rows
+//      into an LDS tile [channel][pixel], NHWC rows leave as contiguous 16-B vectors (the whole 128-pixel x ldc span of
+//      the output is one contiguous byte range).  Replaces per-thread strided 16-B stores / 4-B gathers.
+constexpr int LT_PT = 128;  // pixels per tile
+constexpr int LT_LD = LT_PT + 1;
+
+// tile[c][px] = f(plane values) for c < ldc (zero beyond C / beyond HW)
+template <typename F>
+__device__ __forceinline__ void lt_load_planes(float* tile, int C, int ldc, int HW, int p0, size_t img_off, F&& f) {
+    const int tid = threadIdx.x;
+    if ((HW & 3) == 0) {  // 16-B loads: 32 lanes cover one channel row of the tile
+        const int q = tid & 31, cb = tid >> 5;
+        const bool in = p0 + 4 * q < HW;
+#pragma unroll 4
+        for (int c = cb; c < ldc; c += 8) {
+            f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (c < C && in) v = f(img_off + (size_t)c * HW + p0 + 4 * q);
+            float* d = tile + c * LT_LD + 4 * q;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+    } else {
+        const int px = tid & (LT_PT - 1), cb = tid >> 7;
+        const bool in = p0 + px < HW;
+#pragma unroll 4
+        for (int c = cb; c < ldc; c += 2) {
+            float v = 0.f;
+            if (c < C && in) v = f(img_off + (size_t)c * HW + p0 + px, 0);
+            tile[c * LT_LD + px] = v;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                                 const float* __restrict__ musig, T* __restrict__ y, int B, int C, int HW,
+                                                                 int ldc) {
+    constexpr int P = Elem<T>::PER16;
+    extern __shared__ float lt_tile[];
+    const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
+    for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
+        const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
+        float mu = 1.f, sg = 0.f;
+        if (eps) { mu = musig[2 * b]; sg = musig[2 * b + 1]; }
+        struct Ld {
+            const float *x, *eps; float mu, sg;
+            __device__ __forceinline__ f32x4_t operator()(size_t o) const {
+                f32x4_t v = *(const f32x4_t*)(x + o);
+                if (eps) { const f32x4_t e = *(const f32x4_t*)(eps + o); v = mu * v + sg * e; }
+                return v;
+            }
+            __device__ __forceinline__ float operator()(size_t o, int) const { return eps ? mu * x[o] + sg * eps[o] : x[o]; }
+        } ld{x, eps, mu, sg};
+        lt_load_planes(lt_tile, C, ldc, HW, p0, (size_t)b * C * HW, ld);
+        __syncthreads();
+        const int npx = min(LT_PT, HW - p0);
+        for (int i = threadIdx.x; i < npx * nvec; i += 256) {
+            const int px = i / nvec, v = i - px * nvec;
+            float f[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) f[e] = lt_tile[(v * P + e) * LT_LD + px];
+            *(u32x4_t*)(y + ((size_t)b * HW + p0) * ldc + (size_t)i * P) = pack16<T>(f);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mse_loss_grad_tiled_kernel(const T* __restrict__ y, const float* __restrict__ eps, T* __restrict__ dy,
+                                                                  float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale) {
+    constexpr int P = Elem<T>::PER16;
+    extern __shared__ float lt_tile[];
+    const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
+    float local = 0.f;
+    for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
+        const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
+        struct Ld {
+            const float* eps;
+            __device__ __forceinline__ f32x4_t operator()(size_t o) const { return *(const f32x4_t*)(eps + o); }
+            __device__ __forceinline__ float operator()(size_t o, int) const { return eps[o]; }
+        } ld{eps};
+        lt_load_planes(lt_tile, C, ldc, HW, p0, (size_t)b * C * HW, ld);
+        __syncthreads();
+        const int npx = min(LT_PT, HW - p0);
+        for (int i = threadIdx.x; i < npx * nvec; i += 256) {
+            const int px = i / nvec, v = i - px * nvec;
+            const size_t o = ((size_t)b * HW + p0) * ldc + (size_t)i * P;
+            float f[P];
+            unpack16<T>(*(const u32x4_t*)(y + o), f);
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                float d = 0.f;
+                if (v * P + e < C) {
+                    d = f[e] - lt_tile[(v * P + e) * LT_LD + px];
+                    local += d * d;
+                }
+                f[e] = d * gscale;
+            }
+            *(u32x4_t*)(dy + o) = pack16<T>(f);
+        }
+        __syncthreads();
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
+}
+
 // timestep_embedding (model/score.py:14-34): out[b] = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(max_period) i/half)
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim, float max_period) {
     const int half = dim / 2;
@@ -499,6 +605,12 @@ extern "C" int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* m
                                 void* stream) {
     if (!x || !y || !vec_ok(dtype, ldc) || ldc < C || (eps && !musig)) return C2W_ERR_BAD_SHAPE;
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (lds <= 64 * 1024) {
+        const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
+        DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T><<<nblk, 256, lds, (hipStream_t)stream>>>(x, eps, musig, (T*)y, B, C, HW, ldc)));
+        return (int)hipGetLastError();
+    }
     DISPATCH_T(dtype, (nchw_to_nhwc_kernel<T><<<grid_for((long long)B * HW * (ldc / P)), 256, 0, (hipStream_t)stream>>>(x, eps, musig, (T*)y,
                                                                                                                      B, C, HW, ldc)));
     return (int)hipGetLastError();
@@ -515,6 +627,13 @@ extern "C" int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, floa
                                  int dtype, void* stream) {
     if (!y || !eps || !dy || !loss_sum || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (lds <= 64 * 1024) {
+        const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 2048);
+        DISPATCH_T(dtype, (mse_loss_grad_tiled_kernel<T><<<nblk, 256, lds, (hipStream_t)stream>>>((const T*)y, eps, (T*)dy, loss_sum, B, C, HW,
+                                                                                                  ldc, gscale)));
+        return (int)hipGetLastError();
+    }
     DISPATCH_T(dtype, (mse_loss_grad_kernel<T><<<grid_for((long long)B * HW * (ldc / P), 256, 2048), 256, 0, (hipStream_t)stream>>>(
                           (const T*)y, eps, (T*)dy, loss_sum, B, C, HW, ldc, gscale)));
     return (int)hipGetLastError();

@@ -171,6 +171,8 @@ class Tape:
 
 
 class Engine:
+    LINEAR_DGRAD_SPLIT_MIN_ROWS = 2048  # Linear layers at least this wide take the split-reduction input-gradient route
+
     def __init__(self, net):
         self.layout = Layout(net)
         self.ln_unbiased = bool(getattr(net, "ln_unbiased", True))
@@ -298,6 +300,17 @@ class Engine:
                 tape.done(rec.w_off)
                 if not need_dx:
                     return None
+                if rec.rows >= self.LINEAR_DGRAD_SPLIT_MIN_ROWS and rec.kstride == rec.cin:
+                    # few rows, very long reduction (proj: B x 8448 -> 512): as a forward GEMM that is 4 workgroups walking
+                    # K = 8448.  It is also the weight-gradient GEMM of a 1x1 conv over rec.rows "pixels" with the weight
+                    # matrix as the input and gy^T as the output gradient -- which splits the reduction over the whole chip.
+                    ld = (rows + 3) // 4 * 4
+                    gyT = torch.zeros((rec.rows, ld), dtype=torch.float32, device=x.device)
+                    gyT[:, :rows] = gy.reshape(-1)[: rows * rec.rows].view(rows, rec.rows).t()
+                    dx = torch.zeros((rows, rec.cin), dtype=torch.float32, device=x.device)
+                    gt = self._geom(rec.rows, 1, 1, rec.cin, 1, 1, rows, ld, rows, CONV_1X1)
+                    ops.conv_wgrad(self._w(rec, DTYPE_F32), gyT, dx, gt, DTYPE_F32)
+                    return dx
                 dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
                 gd = self._geom(rows, 1, 1, rec.dg_ld, 1, 1, rec.cin, rec.cin, rec.cin, CONV_1X1)
                 ops.conv(gy, self._wT(rec, DTYPE_F32), None, dx, gd, DTYPE_F32)

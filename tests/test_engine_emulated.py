@@ -95,7 +95,10 @@ def test_forward_matches_golden(emu, golden_dir):
     assert torch.allclose(y32, torch.from_numpy(g["y32"]), atol=2e-5)
 
 
-def test_backward_matches_golden(emu, golden_dir):
+@pytest.mark.parametrize("split_min_rows", [2048, 1])  # 1: the wide-Linear input-gradient route (wgrad kernel) for every Linear
+def test_backward_matches_golden(emu, golden_dir, monkeypatch, split_min_rows):
+    from climate2weather_amd.engine import Engine
+    monkeypatch.setattr(Engine, "LINEAR_DGRAD_SPLIT_MIN_ROWS", split_min_rows)
     g = _golden(golden_dir, "tiny_net.npz")
     net = _tiny()
     x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
