@@ -27,12 +27,15 @@ class ConvArgs(Structure):
         ("B", c_int32), ("Hin", c_int32), ("Win", c_int32), ("Cin", c_int32),
         ("Hout", c_int32), ("Wout", c_int32), ("Cout", c_int32), ("ldy", c_int32),
         ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),
+        ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
+        ("ln_eps", c_float), ("ln_pad_", c_int32),
     ]
 
 
 # name -> argtypes (every function returns int status except c2w_target)
 _PROTOS = {
     "c2w_conv_forward": [POINTER(ConvArgs), c_int, c_int, c_void_p],
+    "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_void_p],
     "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,

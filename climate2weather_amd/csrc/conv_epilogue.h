@@ -23,10 +23,12 @@ __device__ __forceinline__ void epi_load_bias(const C2wConvArgs& p, int co_base,
         }
 }
 
-// one wave's 64 (co) x 64 (pixel) accumulator tile -> LDS rows; row0 = first pixel row of the wave inside O
-template <typename T>
-__device__ __forceinline__ void epi_acc_to_lds(char* O, int OS, const f32x4_t (&acc)[4][4], const float (&bv)[4][4], int act, int col0, int row0,
-                                               int li, int lg) {
+// one wave's 64 (co) x 64 (pixel) accumulator tile -> LDS rows; row0 = first pixel row of the wave inside O.
+// SILU is a template parameter: with a run-time `act` the compiler evaluated the 64 exp/rcp pairs per lane for every
+// conv and selected afterwards (stamps: 3.3k of a 27k-cycle tile, whether or not the activation was requested).
+template <typename T, bool SILU>
+__device__ __forceinline__ void epi_acc_to_lds_impl(char* O, int OS, const f32x4_t (&acc)[4][4], const float (&bv)[4][4], int col0, int row0,
+                                                    int li, int lg) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int col = col0 + m * 16 + lg * 4;
@@ -37,7 +39,7 @@ __device__ __forceinline__ void epi_acc_to_lds(char* O, int OS, const f32x4_t (&
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[m][n][r] + bv[m][r];
-                if (act == C2W_ACT_SILU) v[r] = silu_f(v[r]);
+                if constexpr (SILU) v[r] = silu_f(v[r]);
             }
             if constexpr (sizeof(T) == 4) {
                 *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -45,6 +47,16 @@ __device__ __forceinline__ void epi_acc_to_lds(char* O, int OS, const f32x4_t (&
                 *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
         }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_acc_to_lds(char* O, int OS, const f32x4_t (&acc)[4][4], const float (&bv)[4][4], int act, int col0, int row0,
+                                               int li, int lg) {
+    if (act == C2W_ACT_SILU) {  // wave-uniform branch
+        epi_acc_to_lds_impl<T, true>(O, OS, acc, bv, col0, row0, li, lg);
+    } else {
+        epi_acc_to_lds_impl<T, false>(O, OS, acc, bv, col0, row0, li, lg);
     }
 }
 
@@ -71,16 +83,137 @@ struct EpiStore {
             const long long Q = pix(row);
             off[i] = (Q >= 0 && c < p.Cout) ? (long long)((Q * p.ldy + c) * ESZ) : -1;
         }
+        issue_prefetch(p);
+    }
+
+    // Same for a tile that is 16 pixels wide inside one image (halo-patch kernels): pix0 = NHWC index of the tile's first
+    // pixel, W = image width.  Every row of the tile is inside the image, so only the channel bound can mask a thread, and
+    // the 8 (16) offsets differ by wave-uniform constants: one 64-bit multiply per thread instead of one per segment.
+    __device__ __forceinline__ void prefetch_tile16(const C2wConvArgs& p, int tid, int co0, long long pix0, int W) {
+        constexpr int RS = NTHR / SEGS;  // tile rows between two consecutive segments of a thread
+        static_assert(RS % 16 == 0 || 16 % RS == 0, "row step and tile width must nest");
+        const int r0 = tid / SEGS, cs = tid - r0 * SEGS;
+        const int c = co0 + cs * PER16;
+        const long long pitch = (long long)p.ldy * ESZ;
+        const long long off0 = c < p.Cout ? ((pix0 + (long long)(r0 >> 4) * W + (r0 & 15)) * p.ldy + c) * ESZ : -1;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const long long d = (long long)((RS * i) >> 4) * W * pitch + (long long)((RS * i) & 15) * pitch;
+            off[i] = off0 >= 0 ? off0 + d : -1;
+        }
+        issue_prefetch(p);
+    }
+
+    __device__ __forceinline__ void issue_prefetch(const C2wConvArgs& p) {
         if constexpr (EARLY) {
             if (p.res != nullptr) {
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) rr[i] = *(const u32x4_t*)((const char*)p.res + (off[i] >= 0 ? off[i] : 0));
             }
-            if (p.mul != nullptr) {
+            const void* const mulp = p.ln_x != nullptr ? p.ln_x : p.mul;  // LN mode: the multiplier slot carries the LN input rows
+            if (mulp != nullptr) {
 #pragma unroll
-                for (int i = 0; i < NIT; ++i) mm[i] = *(const u32x4_t*)((const char*)p.mul + (off[i] >= 0 ? off[i] : 0));
+                for (int i = 0; i < NIT; ++i) mm[i] = *(const u32x4_t*)((const char*)mulp + (off[i] >= 0 ? off[i] : 0));
             }
         }
+    }
+
+    // ---- fused LayerNorm backward (bf16, the tile holds whole 128-channel rows, all of one image `img`):
+    //   O rows = g (input gradient of conv1 = gradient w.r.t. the LN output);  u = ln_x + ln_m[img];  xh = (u - mean)/s
+    //   y = res + ( g - mean(g) - xh * sum(g*xh)/den ) / s ;   ln_dm[img][c] += column sums of the LN part
+    // Same arithmetic, in the same order, as ln_bwd_kernel (pointwise.hip): 16 lanes share a pixel row.
+    // `red`: 128 floats of LDS outside O, zeroed by the caller before the barrier that precedes this call.
+    __device__ __forceinline__ void finish_ln(const C2wConvArgs& p, const char* O, int OS, int tid, int img, float* red) {
+        static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN backward: bf16 tiles only");
+        typedef __attribute__((ext_vector_type(2))) float f2;  // pairs -> v_pk_{add,mul,fma}_f32: half the VALU issue slots
+        const int cs = tid & (SEGS - 1);
+        f2 m2[4];
+        if (p.ln_m != nullptr) {
+            const float* mr = p.ln_m + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + cs * PER16;
+            const f32x4_t ma = *(const f32x4_t*)mr, mb = *(const f32x4_t*)(mr + 4);
+            m2[0] = (f2){ma[0], ma[1]}; m2[1] = (f2){ma[2], ma[3]}; m2[2] = (f2){mb[0], mb[1]}; m2[3] = (f2){mb[2], mb[3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m2[k] = (f2){0.f, 0.f};
+        }
+        const float inv_den = 1.0f / (float)(128 - (p.ln_unbiased ? 1 : 0));
+        f2 am[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) am[k] = (f2){0.f, 0.f};
+        auto unpack2 = [](const u32x4_t& v, f2* f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = (f2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+        };
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int seg = tid + i * NTHR;
+            const int row = seg / SEGS;
+            f2 g[4], u[4];
+            unpack2(*(const u32x4_t*)(O + row * OS + cs * 16), g);
+            unpack2(mm[i], u);
+            f2 s2 = (f2){0.f, 0.f}, sg2 = (f2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u[k] += m2[k];
+                s2 += u[k];
+                sg2 += g[k];
+            }
+            const float mean = sub16(s2[0] + s2[1]) * (1.0f / 128.0f);
+            const float gmean = sub16(sg2[0] + sg2[1]) * (1.0f / 128.0f);
+            f2 q2 = (f2){0.f, 0.f}, d2 = (f2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u[k] -= mean;            // centred input; xhat = u * rs
+                q2 += u[k] * u[k];
+                d2 += g[k] * u[k];
+            }
+            const float rs = __builtin_amdgcn_rsqf(sub16(q2[0] + q2[1]) * inv_den + p.ln_eps);
+            const float dot = sub16(d2[0] + d2[1]) * rs * inv_den;  // sum(g * xhat) / den
+            // (g - gmean - xhat * dot) * rs  =  g * rs - gmean * rs - u * (rs * rs * dot)
+            const float c0 = gmean * rs, c2 = rs * rs * dot;
+            f2 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = g[k] * rs - c0;
+                o[k] -= u[k] * c2;
+                am[k] += o[k];
+            }
+            if (p.res != nullptr) {
+                f2 r[4];
+                unpack2(rr[i], r);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += r[k];
+            }
+            u32x4_t out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(o[k][0], o[k][1]);
+            if (off[i] >= 0) *(u32x4_t*)((char*)p.y + off[i]) = out;
+        }
+        if (p.ln_dm != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {  // rows of this wave that share the channel: lanes l, l+16, l+32, l+48
+                    float v = am[k][h];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if ((tid & 63) < 16) atomicAdd(&red[cs * PER16 + 2 * k + h], v);
+                }
+            __syncthreads();
+            if (tid < 128) atomicAdd(p.ln_dm + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + tid, red[tid]);
+        }
+    }
+
+    // sum over the 16 lanes that share a pixel row = one DPP row: four row rotations on the VALU (no LDS-pipe shuffles)
+    template <int CTRL>
+    static __device__ __forceinline__ float dpp_add(float v) {
+        return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    }
+    static __device__ __forceinline__ float sub16(float v) {
+        v = dpp_add<0x128>(v);  // row_ror:8
+        v = dpp_add<0x124>(v);  // row_ror:4
+        v = dpp_add<0x122>(v);  // row_ror:2
+        return dpp_add<0x121>(v);  // row_ror:1
     }
 
     __device__ __forceinline__ void finish(const C2wConvArgs& p, const char* O, int OS, int tid) {

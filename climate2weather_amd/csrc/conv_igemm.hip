@@ -305,6 +305,12 @@ int launch_dtype(const C2wConvArgs& a, int naive, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
+    if (a == nullptr || dtype != C2W_DTYPE_BF16) return 0;
+    if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE) return 0;
+    return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr ? 1 : 0;
+}
+
 extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void* stream) {
     if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return C2W_ERR_BAD_ARG;
     const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
@@ -314,6 +320,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
     if (a->Hout >= 65536 || a->Wout >= 65536) return C2W_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (naive == 0 && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_s1(*a, dtype, st);
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);

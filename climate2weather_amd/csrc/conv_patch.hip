@@ -233,9 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wCon
     // ---- epilogue (conv_epilogue.h): bias/activation in registers -> LDS [pixel][channel] -> 16-B NHWC stores
     constexpr int OS = 128 * ESZ + 16;
     EpiStore<T, 256, NTHREADS> est;
-    est.prefetch(p, tid, co0, [&](int row) -> long long {
-        return ((long long)b * H + oh0 + (row >> 4)) * W + ow0 + (row & 15);
-    });
+    est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
     __syncthreads();
     char* const O = smem;
     epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
@@ -413,21 +411,32 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
 
     constexpr int OS = 128 * ESZ + 16;
     C2W_STAMP(st2);
+    unsigned long long sa = 0, sb = 0, sc = 0;
     EpiStore<T, 128, H_NTHR> est;
-    est.prefetch(p, tid, co0, [&](int row) -> long long {
-        return ((long long)b * H + oh0 + (row >> 4)) * W + ow0 + (row & 15);
-    });
+    est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    C2W_STAMP(sa);
     __syncthreads();
+    C2W_STAMP(sb);
     char* const O = smem;
+    float* const red = (float*)(smem + 128 * OS);  // 128 floats behind O: column sums of the fused LN backward
+    if constexpr (ESZ == 2) {
+        if (p.ln_x != nullptr && tid < 128) red[tid] = 0.f;
+    }
     epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
+    C2W_STAMP(sc);
     __syncthreads();
     C2W_STAMP(st3);
-    est.finish(p, O, OS, tid);
+    if constexpr (ESZ == 2) {
+        if (p.ln_x != nullptr) est.finish_ln(p, O, OS, tid, b, red);
+        else est.finish(p, O, OS, tid);
+    } else {
+        est.finish(p, O, OS, tid);
+    }
     C2W_STAMP(st4);
 #if C2W_EXP & 16
     if (tid == 0 && c2w_dbg != nullptr) {
-        unsigned long long* d = c2w_dbg + (size_t)L * 5;
-        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4;
+        unsigned long long* d = c2w_dbg + (size_t)L * 8;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = sa; d[4] = sb; d[5] = sc; d[6] = st3; d[7] = st4;
     }
 #endif
 }
@@ -443,7 +452,7 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int nN = (a.Cout + 127) / 128;
-    if (getenv("C2W_CONV_FULL") == nullptr) {  // two half-tile workgroups per CU
+    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr) {  // two half-tile workgroups per CU
         static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
         static bool attr_h = false;
         if (!attr_h) {

@@ -377,11 +377,14 @@ class Engine:
             ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2)
             return y, g, rec
 
-        def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None):
-            """input gradient = implicit GEMM over gy with the transposed (and flipped) weights; (Hi,Wi) = gy's grid"""
-            dx = torch.empty((B * Ho * Wo, ld_out), dtype=T, device=dev)
+        def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None, ln=None):
+            """input gradient = implicit GEMM over gy with the transposed (and flipped) weights; (Hi,Wi) = gy's grid.
+            ``ln``: LayerNorm-backward arguments to fuse into the epilogue; returns None when the kernel cannot fuse them."""
             g = self._geom(B, Hi, Wi, rec.dg_ld, Ho, Wo, ld_out, ld_out, rec.cin, mode)
-            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=MUL_DSILU)
+            if ln is not None and not ops.conv_lnbwd_supported(g, dt):
+                return None
+            dx = torch.empty((B * Ho * Wo, ld_out), dtype=T, device=dev)
+            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=MUL_DSILU, ln=ln)
             return dx
 
         def res_block(b: BlockSpec, xin, Hc, Wc):
@@ -403,10 +406,15 @@ class Engine:
                     da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=a1)
                     ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt, dbias=self._gb(r1))
                     tape.done(r1.w_off)
-                    dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
-                    dx = torch.empty_like(dh0)
-                    ops.ln_backward(dh0, xin, m, gy, dx, dm_all.view(-1)[b.mod_offset:], npix, Hc * Wc, Cc, ldm, LN_EPS,
-                                    self.ln_unbiased, dt)
+                    dm = dm_all.view(-1)[b.mod_offset:]
+                    # conv1's input gradient feeds LN's backward directly: fused into the conv epilogue where the kernel
+                    # holds whole channel rows (128-channel levels in bf16), a separate pass otherwise
+                    dx = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc, res=gy,
+                               ln=dict(x=xin, m=m, dm=dm, ldm=ldm, eps=LN_EPS, unbiased=self.ln_unbiased))
+                    if dx is None:
+                        dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
+                        dx = torch.empty_like(dh0)
+                        ops.ln_backward(dh0, xin, m, gy, dx, dm, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
                     return dx
                 tape.steps.append(bw)
             return out

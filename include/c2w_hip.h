@@ -52,7 +52,22 @@ typedef struct C2wConvArgs {
     int32_t mode;    /* C2W_CONV_* */
     int32_t act;     /* C2W_ACT_* */
     int32_t mulmode; /* C2W_MUL_* */
+    /* Optional fused LayerNorm backward (see c2w_conv_lnbwd_supported): with ln_x != NULL the conv result g is not stored;
+     * instead y = res + dLN(g; ln_x + ln_m[b]) and ln_dm[b][c] += sum over the image's pixels of the LN part -- exactly
+     * c2w_ln_backward(dy = g, x = ln_x, m = ln_m, dres = res, dx = y, dm = ln_dm) applied to the conv's output tile while
+     * it is still on chip (model/nn.py:28,154 backward: the input gradient of conv1 feeds LN's backward directly). */
+    const void* ln_x;   /* [B*Hout*Wout][ldy] LN input rows (the block input), or NULL = no fusion */
+    const float* ln_m;  /* [B][ln_ldm] fp32 modulation rows added to ln_x before the norm, or NULL */
+    float* ln_dm;       /* [B][ln_ldm] fp32 modulation gradient, accumulated (atomics), or NULL */
+    int32_t ln_ldm;
+    int32_t ln_unbiased;
+    float ln_eps;
+    int32_t ln_pad_;
 } C2wConvArgs;
+
+/* 1 when c2w_conv_forward can run args with the fused LayerNorm backward (bf16, Cout == ldy == 128, 3x3 stride-1 on an
+ * image the halo-patch kernel tiles, no mul / act / y2), else 0.  Callers fall back to conv + c2w_ln_backward. */
+int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);
 
 /* naive == 0: product path (halo-patch MFMA kernel for 3x3 stride-1 on 16x16-tileable images, general gather MFMA
  * kernel otherwise); naive == 2: force the gather MFMA kernel; naive == 1: one-thread-per-output direct convolution

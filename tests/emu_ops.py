@@ -48,7 +48,19 @@ def _conv_core(X, Wt, g):
     raise ValueError(mode)
 
 
-def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None):
+def conv_lnbwd_supported(g, dtype):
+    return g["mode"] == CONV_S1 and g["Cout"] == g["ldy"]  # the emulation fuses wherever the semantics are defined
+
+
+def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None):
+    if ln is not None:  # y = res + dLN(conv(x); ln.x + ln.m), the conv result rounded to the storage type in between
+        assert mul is None and y2 is None and act == ACT_NONE
+        tmp = torch.zeros_like(y)
+        conv(x, w, bias, tmp, g, dtype)
+        npix = g["B"] * g["Hout"] * g["Wout"]
+        ln_backward(tmp, ln["x"], ln.get("m"), res, y, ln.get("dm"), npix, g["Hout"] * g["Wout"], g["Cout"], ln.get("ldm", 0), ln["eps"],
+                    ln["unbiased"], dtype)
+        return
     B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows = (g[k] for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ldy", "wrows"))
     taps = 1 if g["mode"] == CONV_1X1 else 9
     T = TD[dtype]

@@ -95,6 +95,39 @@ def test_conv_forward(case, dt, naive):
             close(y2, y2_ref, dt, f"conv second output mode={mode} naive={naive}")
 
 
+@pytest.mark.parametrize("unbiased", [True, False])
+@pytest.mark.parametrize("B,H,W,Cin,per_sample", [(2, 32, 48, 128, True), (3, 16, 16, 192, True), (1, 16, 32, 64, False)])
+def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased):
+    """The input-gradient conv of a res-block's first conv with LayerNorm's backward in its epilogue
+    (C2wConvArgs.ln_*): y = res + dLN(conv(x); ln_x + m), dm += column sums -- against conv followed by ln_backward."""
+    dt, C = BF16, 128
+    g = geom(B, H, W, Cin, H, W, C, C, C, ops.CONV_S1)
+    assert ops.conv_lnbwd_supported(g, dt)
+    assert not ops.conv_lnbwd_supported(g, F32)
+    assert not ops.conv_lnbwd_supported(geom(B, H, W, Cin, H, W, 256, 256, 256, ops.CONV_S1), dt)
+    npix = B * H * W
+    x = rnd((npix, Cin), dt, 1)
+    w = rnd((C, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    lnx = rnd((npix, C), dt, 3)
+    res = rnd((npix, C), dt, 4)
+    ldm_total = C + 64
+    m = rnd((B if per_sample else 1, ldm_total), F32, 5)
+    ldm = ldm_total if per_sample else 0
+    dm, dm_ref = torch.zeros_like(m), torch.zeros_like(m)
+    y = torch.full((npix, C), 7.0, dtype=TD[dt], device=dev())
+    y_ref = y.clone()
+    ln = dict(x=lnx, m=m.view(-1)[32:], dm=dm.view(-1)[32:], ldm=ldm, eps=1e-5, unbiased=unbiased)
+    ops.conv(x, w, None, y, g, dt, res=res, ln=ln)
+    E.conv(x, w, None, y_ref, g, dt, res=res, ln=dict(ln, dm=dm_ref.view(-1)[32:]))
+    torch.cuda.synchronize()
+    close(y, y_ref, dt, "fused ln bwd dx")
+    close(dm, dm_ref, dt, "fused ln bwd dm", tol=1e-2)
+    # without modulation / residual / dm
+    ops.conv(x, w, None, y, g, dt, ln=dict(x=lnx, eps=1e-5, unbiased=unbiased))
+    E.conv(x, w, None, y_ref, g, dt, ln=dict(x=lnx, eps=1e-5, unbiased=unbiased))
+    close(y, y_ref, dt, "fused ln bwd dx (no m, no res)")
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("force_gather", [False, True])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] != ops.CONV_TS2])

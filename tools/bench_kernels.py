@@ -16,6 +16,7 @@ p.add_argument("--dtypes", default="bf16,fp32")
 p.add_argument("--only", type=int, default=-1, help="run only SHAPES[i]")
 p.add_argument("--kind", default="conv,wgrad,ln")
 p.add_argument("--act", type=int, default=1)
+p.add_argument("--epilogues", action="store_true", help="time the conv with each fused epilogue variant")
 a = p.parse_args()
 dev = torch.device("cuda:0")
 
@@ -55,6 +56,15 @@ for dname in a.dtypes.split(","):
         if "conv" in a.kind:
           ms = timeit(lambda: ops.conv(x, w, bias, y, g, dt, act=a.act), a.iters)
           print(f"conv   {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+          if a.epilogues and ops.conv_lnbwd_supported(g, dt):
+              res = torch.randn(B * Ho * Ho, Cout, device=dev).to(T)
+              lnx = torch.randn(B * Ho * Ho, Cout, device=dev).to(T)
+              m = torch.randn(B, Cout, device=dev)
+              dm = torch.zeros(B, Cout, device=dev)
+              for name, kw in [("plain", dict()), ("res", dict(res=res)), ("mul+res", dict(res=res, mul=lnx, mulmode=ops.MUL_DSILU)),
+                               ("ln", dict(res=res, ln=dict(x=lnx, m=m, dm=dm, ldm=Cout, eps=1e-5, unbiased=True)))]:
+                  ms = timeit(lambda: ops.conv(x, w, None, y, g, dt, **kw), a.iters)
+                  print(f"   epilogue {name:8s}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
         if "wgrad" in a.kind:
           ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt), a.iters)
           print(f"wgrad  {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)

@@ -12,14 +12,18 @@ x = torch.randn(B*H*H, C, device=dev).to(T); w = (torch.randn(C, 9, C, device=de
 bias = torch.randn(C, device=dev); y = torch.empty(B*H*H, C, device=dev, dtype=T)
 res = torch.randn(B*H*H, C, device=dev).to(T)
 ntile = B*(H//16)**2 * (1 if os.environ.get('C2W_CONV_FULL') else 2)
-dbg = torch.zeros(ntile*5, dtype=torch.int64, device=dev)
+NS = 8 if not os.environ.get('C2W_CONV_FULL') else 5
+dbg = torch.zeros(ntile*NS, dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.c2w_debug_set.argtypes = [ctypes.c_void_p]
 assert lib.c2w_debug_set(ctypes.c_void_p(dbg.data_ptr())) == 0
-for name, kw in (("plain", {}), ("res", dict(res=res)), ("mul", dict(mul=res, mulmode=ops.MUL_DSILU)), ("y2", dict(y2=torch.empty_like(y)))):
+m = torch.randn(B, C, device=dev); dm = torch.zeros(B, C, device=dev)
+for name, kw in (("plain", {}), ("silu", dict(act=ops.ACT_SILU)), ("res", dict(res=res)), ("mul+res", dict(mul=res, res=res, mulmode=ops.MUL_DSILU)),
+                 ("y2", dict(y2=torch.empty_like(y))), ("ln", dict(res=res, ln=dict(x=res, m=m, dm=dm, ldm=C, eps=1e-5, unbiased=True)))):
     for _ in range(3):
-        ops.conv(x, w, bias, y, g, ops.DTYPE_BF16, **kw)
+        ops.conv(x, w, None if name == "ln" else bias, y, g, ops.DTYPE_BF16, **kw)
     torch.cuda.synchronize()
-    d = dbg.view(ntile, 5).cpu().double()
-    seg = [(d[:, i+1]-d[:, i]).median().item() for i in range(4)]
-    print(f"{name:6s} cycles/tile: prologue {seg[0]:.0f}  loop {seg[1]:.0f}  acc->LDS {seg[2]:.0f}  store {seg[3]:.0f}  total {(d[:,4]-d[:,0]).median().item():.0f}")
+    d = dbg.view(ntile, NS).cpu().double()
+    seg = [(d[:, i+1]-d[:, i]).median().item() for i in range(NS - 1)]
+    names = ["prologue", "loop", "prefetch", "barrier1", "acc->LDS", "barrier2", "store"] if NS == 8 else ["prologue", "loop", "acc->LDS", "store"]
+    print(f"{name:8s} cycles/tile: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, seg)) + f"  total {(d[:,NS-1]-d[:,0]).median().item():.0f}")
