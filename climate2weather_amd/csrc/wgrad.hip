@@ -293,8 +293,8 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     const int nkt = (int)((npix + KT - 1) / KT);
     const int tilesN = (NT * (a.Cin / CIB) + 3) / 4, tilesM = (a.Cout + COT - 1) / COT;
     const int tilesMN = tilesM * tilesN;
-    static const int target = getenv("C2W_WGRAD_TARGET") ? atoi(getenv("C2W_WGRAD_TARGET")) : 768;
-    int nsplit = (target + tilesMN - 1) / tilesMN;  // ~3 workgroups per CU in flight over the launch
+    static const int target = getenv("C2W_WGRAD_TARGET") ? atoi(getenv("C2W_WGRAD_TARGET")) : 432;
+    int nsplit = (target + tilesMN - 1) / tilesMN;  // one resident wave of workgroups (2 per CU): measured best on the 8x8 / stride-2 / upsampling shapes (atomics grow with the split)
     if (nsplit > nkt) nsplit = nkt;
     if (nsplit < 1) nsplit = 1;
     p.ktiles_per_split = (nkt + nsplit - 1) / nsplit;
