@@ -240,3 +240,39 @@ def test_guidance_kernel_vs_emulation_and_autograd(L, Fv, H, s_step, t_step):
     logp = -(err ** 2 / var).sum() / 2
     (J,) = torch.autograd.grad(logp, xa)
     assert torch.allclose(e.cpu(), eps - sigma * J, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ time-sharded sampler (f1)
+def test_time_sharded_sampler_single_rank_and_local_guidance(golden_dir):
+    """One rank: the sharded driver reproduces the golden trajectories on the HIP kernels.  Two-rank halo exchange runs in
+    the CPU (gloo) suite; here the per-rank guidance slice (global observation index / first-observed-frame offset) is
+    checked against the guidance of the whole trajectory."""
+    from climate2weather_amd.sharded import TimeShardedScoreFunction, sample_time_sharded
+    s = _golden(golden_dir, "sampler.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    dev = torch.device("cuda", 0)
+    for name, corrections, cond in [("uncond_c1", 1, False), ("cond_c0", 0, True)]:
+        sf = TimeShardedScoreFunction(net, markov_order=1, length=9, batch_size=4, device=dev, noise_process=pipe, rank=0, world=1)
+        if cond:
+            sf.condition_on(A=PoolStrideOperator(8, 2), y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=float(s["gamma"]))
+        zs = [torch.from_numpy(z) for z in s[name + ".z"]] if corrections else None
+        x = sample_time_sharded(pipe, sf, torch.from_numpy(s[name + ".noise"]), steps=4, corrections=corrections, tau=0.5, z_draws=zs)
+        ref = torch.from_numpy(s[name + ".x"])
+        assert (x.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), name
+    # guidance on the frames [5, 9) of rank 1 of 2 == the same frames of the whole-trajectory guidance
+    L, Fv, H = 9, 2, 32
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(L, Fv, H, H, generator=gen).cuda()
+    eps = torch.randn(L, Fv, H, H, generator=gen).cuda()
+    y = torch.from_numpy(s["y_obs"]).cuda()
+    std = torch.from_numpy(s["std"]).reshape(-1).cuda()
+    full = eps.clone()
+    mu, sigma = pipe._mu_sigma_f(0.7)
+    ops.guidance(x, full, y, std, y.shape[0], Fv, H, H, 8, 2, mu, sigma, float(s["gamma"]))
+    sf1 = TimeShardedScoreFunction(net, markov_order=1, length=L, batch_size=4, device=dev, noise_process=pipe, rank=1, world=2)
+    sf1.condition_on(A=PoolStrideOperator(8, 2), y=y, std=std, gamma=float(s["gamma"]))
+    lo, hi = sf1.bounds[1]
+    part = eps[lo:hi].clone()
+    sf1._apply_guidance(x[lo:hi].contiguous(), part, 0.7)
+    assert torch.equal(part, full[lo:hi])

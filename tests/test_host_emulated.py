@@ -197,6 +197,39 @@ def _run_fused(pipe, sf, noise, corrections, zs):
     return x
 
 
+def test_time_sharded_sampler_two_ranks_equals_reference_trajectory(golden_dir, tmp_path):
+    """the trajectory's time axis split over 2 ranks (k-frame halo exchange, scalar all-reduce for the
+    corrector, frame-local guidance) reproduces the single-process trajectories of the imported reference."""
+    import torch.multiprocessing as mp
+    from _shard_worker import run
+    mp.spawn(run, args=(2, _free_port(), golden_dir, str(tmp_path)), nprocs=2, join=True)
+    s = _golden(golden_dir, "sampler.npz")
+    r0, r1 = (torch.load(tmp_path / f"shard{r}.pt", weights_only=False) for r in (0, 1))
+    assert r0["uncond_c0.bounds"] == [(0, 5), (5, 9)]
+    for name in ("uncond_c0", "uncond_c1", "cond_c0"):
+        ref = torch.from_numpy(s[name + ".x"])
+        assert torch.equal(r0[name], r1[name]), name  # gather=True: every rank holds the whole trajectory
+        assert (r0[name] - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), name
+
+
+def test_time_sharded_partition_and_single_rank(emu, golden_dir):
+    from climate2weather_amd.sharded import TimeShardedScoreFunction, partition_frames, sample_time_sharded
+    assert partition_frames(49, 4, 6) == [(0, 13), (13, 25), (25, 37), (37, 49)]
+    assert partition_frames(8737, 8, 6)[-1] == (7645, 8737)
+    with pytest.raises(ValueError):
+        partition_frames(20, 8, 6)  # a rank would own fewer than k frames
+    s = _golden(golden_dir, "sampler.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    noise = torch.from_numpy(s["uncond_c0.noise"])
+    sf = TimeShardedScoreFunction(net, markov_order=1, length=9, batch_size=4, device=torch.device("cpu"), noise_process=pipe, rank=0, world=1)
+    x = sample_time_sharded(pipe, sf, noise, steps=4)
+    ref = torch.from_numpy(s["uncond_c0.x"])
+    assert (x - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+    with pytest.raises(NotImplementedError):
+        sf.condition_on(A=lambda z: z, y=None, std=1.0)
+
+
 def test_nan_detection_raises(emu):
     net = _tiny().eval()
     pipe = SDAPipeline()
