@@ -150,23 +150,65 @@ class Trainer:
             out.append((rate, {k: sd[k] for k in self.net.state_dict().keys()}))
         return out
 
+    def _per_param(self, flat: torch.Tensor):
+        """name -> strided view of a flat per-parameter buffer, in ``net.named_parameters()`` order (= the order the
+        reference hands parameters to its optimizer, train.py:176-181)."""
+        views = self.eng.layout.views
+        return [(n, torch.as_strided(flat, views[n][1], views[n][2], views[n][0])) for n, _ in self.net.named_parameters()]
+
+    def optimizer_state_dict(self):
+        """``torch.optim.AdamW.state_dict()`` layout: what the reference's checkpoint holds under "optimizer"
+        (src/thor/checkpoint.py:13-35 saves ``optimizer`` through Fabric = its state_dict)."""
+        ms, vs = self._per_param(self.m), self._per_param(self.v)
+        state = {}
+        if self.step_count > 0:
+            for i, ((_, m), (_, v)) in enumerate(zip(ms, vs)):
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m.clone(), exp_avg_sq=v.clone())
+        lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
+        group = dict(lr=float(lr), betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False, maximize=False,
+                     foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(ms))))
+        return dict(state=state, param_groups=[group])
+
+    def load_optimizer_state_dict(self, osd):
+        self.m.zero_()
+        self.v.zero_()
+        step = 0
+        ms, vs = self._per_param(self.m), self._per_param(self.v)
+        for i, st in osd["state"].items():
+            ms[int(i)][1].copy_(st["exp_avg"])
+            vs[int(i)][1].copy_(st["exp_avg_sq"])
+            step = max(step, int(float(st["step"])))
+        self.step_count = step
+        if osd.get("param_groups"):
+            g = osd["param_groups"][0]
+            self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
+
     def state_dict(self):
-        """Same content as the reference's training-state checkpoint (src/thor/checkpoint.py:13-35): progress, network,
-        optimizer moments, EMA."""
-        return dict(state=dict(cur_ndata=self.cur_ndata, step_count=self.step_count), net=self.net.state_dict(),
-                    optimizer=dict(m=self.m, v=self.v, step=self.step_count),
-                    ema=dict(rates=self.ema_rates, flats=self.ema_flats), pipeline=dict(eta=self.pipeline.eta))
+        """The reference's training-state checkpoint, key for key (src/thor/checkpoint.py:13-35 over the objects of
+        training_loop.py:132-138): ``state`` (progress counters), ``net`` (228-key state_dict), ``pipeline`` (its
+        ``__dict__``), ``optimizer`` (AdamW state_dict), ``ema`` (``StandardEMA.state_dict()``: rates + one state_dict each)."""
+        return dict(state=dict(cur_ndata=self.cur_ndata, total_elapsed_time=getattr(self, "total_elapsed_time", 0)),
+                    net={k: v.clone() for k, v in self.net.state_dict().items()},
+                    pipeline=dict(eta=self.pipeline.eta),
+                    optimizer=self.optimizer_state_dict(),
+                    ema=dict(rates=list(self.ema_rates), emas=[sd for _, sd in self.ema_state_dicts()]))
 
     def load_state_dict(self, sd):
-        self.net.load_state_dict(sd["net"])
+        net_sd = {k[len("_forward_module."):] if k.startswith("_forward_module.") else k: v for k, v in sd["net"].items()}
+        self.net.load_state_dict(net_sd)
         self.eng = self.net._get_engine()
         self.eng.weights_changed()
-        self.m.copy_(sd["optimizer"]["m"])
-        self.v.copy_(sd["optimizer"]["v"])
-        self.step_count = int(sd["optimizer"]["step"])
+        self.load_optimizer_state_dict(sd["optimizer"])
         self.cur_ndata = int(sd["state"]["cur_ndata"])
-        for e, s in zip(self.ema_flats, sd["ema"]["flats"]):
-            e.copy_(s)
+        self.total_elapsed_time = sd["state"].get("total_elapsed_time", 0)
+        if sd.get("pipeline"):
+            self.pipeline.eta = sd["pipeline"].get("eta", self.pipeline.eta)
+        if sd.get("ema") is not None:
+            views = self.eng.layout.views
+            for flat, esd in zip(self.ema_flats, sd["ema"]["emas"]):
+                for name, t in esd.items():
+                    off, shape, strides = views[name]
+                    torch.as_strided(flat, shape, strides, off).copy_(t)
 
 
 CKPT_RE = re.compile(r"training-state-(\d+).ckpt")

@@ -81,6 +81,14 @@ def test_training_step_matches_oracle(emu, golden_dir, tmp_path):
     for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
         assert torch.equal(a, b), k
     assert torch.equal(tr.m, tr2.m) and tr2.step_count == 1
+    # the file has the reference's schema (src/thor/checkpoint.py:13-35): torch's AdamW and StandardEMA accept its parts
+    ck = torch.load(p, weights_only=False)
+    assert set(ck) == {"state", "net", "pipeline", "optimizer", "ema"} and ck["state"]["cur_ndata"] == 2
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    opt.load_state_dict(ck["optimizer"])
+    first = next(iter(net.parameters()))
+    assert torch.equal(opt.state[first]["exp_avg"], tr._per_param(tr.m)[0][1])
+    assert ck["ema"]["rates"] == [0.9, 0.999] and set(ck["ema"]["emas"][0]) == set(net.state_dict())
 
 
 def test_gradient_accumulation_sums_rounds(emu, golden_dir):
@@ -309,3 +317,36 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.c2w_target() == b"gfx950"
     with pytest.raises(_lib.C2wError):
         c2w_ops.silu(torch.zeros(8), torch.zeros(8), 8, 0)  # CPU tensors are refused: no fallback path
+
+
+def test_reference_network_snapshot_import_and_round_trip(emu, golden_dir, tmp_path):
+    """a `network-snapshot-*.pkl` written by the reference (fixture made by tests/golden/make_snapshot.py
+    from the imported reference classes) loads without the reference's packages; an own snapshot round-trips; pickles that
+    reach outside the allow-list are refused."""
+    import pickle
+    from climate2weather_amd.snapshot import infer_config, load_network_snapshot, save_network_snapshot
+    g = _golden(golden_dir, "tiny_net.npz")
+    snap = load_network_snapshot(os.path.join(golden_dir, "ref_snapshot_tiny.pkl"))
+    assert isinstance(snap.ema, ScoreUNet) and isinstance(snap.pipeline, SDAPipeline)
+    assert snap.markov_order == 1 and snap.pipeline.eta == pytest.approx(1e-3)
+    assert snap.dataset_kwargs["train"]["window"] == 3
+    sd = snap.ema.state_dict()
+    assert list(sd.keys()) == [str(n) for n in g["param_order"]] or set(sd.keys()) == {str(n) for n in g["param_order"]}
+    for k, v in sd.items():
+        ref = torch.from_numpy(g["sd." + k]).to(torch.float16).float()  # the reference stores fp16 (training_loop.py:259)
+        assert torch.equal(v, ref), k
+    assert infer_config(sd) == dict(channels=6, spatial=2, **TINY)
+    # the imported network runs (emulated launchers here, HIP on the GPU) and is close to the fp32 golden output
+    with torch.no_grad():
+        y = snap.ema(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]))
+    assert (y - torch.from_numpy(g["y"])).abs().max().item() <= 2e-2 * float(np.abs(g["y"]).max())
+    # own snapshot: same container, this package's classes
+    p = save_network_snapshot(str(tmp_path / "network-snapshot-0000001.pkl"), snap.ema, snap.pipeline, snap.dataset_kwargs)
+    again = load_network_snapshot(p)
+    for (k, a), (_, b) in zip(sd.items(), again.ema.state_dict().items()):
+        assert torch.equal(a, b), k
+    evil = tmp_path / "evil.pkl"
+    with open(evil, "wb") as f:
+        pickle.dump(dict(ema=os.system), f)
+    with pytest.raises(pickle.UnpicklingError):
+        load_network_snapshot(str(evil))
