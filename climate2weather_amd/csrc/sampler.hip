@@ -129,6 +129,44 @@ __global__ __launch_bounds__(256) void guidance_kernel(const float* __restrict__
     }
 }
 
+// Measurement operator of the experiments, y = A(x) = AvgPool2d(s)(x[::t_step]) (exp/downscaling.py:129-132):
+// one wave per (observed frame, channel, pooled cell); builds the observation from a high-resolution trajectory in HBM.
+__global__ __launch_bounds__(256) void pool_stride_kernel(const float* __restrict__ x, float* __restrict__ y, int nobs, int F, int H, int W,
+                                                          int s, int t_step) {
+    const int lane = threadIdx.x & 63;
+    const int PH = H / s, PW = W / s;
+    const long long ncell = (long long)nobs * F * PH * PW;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= ncell) return;
+    const int pw = (int)(wave % PW);
+    long long r = wave / PW;
+    const int ph = (int)(r % PH);
+    r /= PH;
+    const int c = (int)(r % F);
+    const int o = (int)(r / F);
+    const long long base = (((long long)o * t_step) * F + c) * H * W;
+    float acc = 0.f;
+    for (int q = lane; q < s * s; q += 64) acc += x[base + (long long)(ph * s + q / s) * W + pw * s + q % s];
+    acc = wave_sum(acc);
+    if (lane == 0) y[wave] = acc / (float)(s * s);
+}
+
+// Per-variable affine map y[l][c][:] = x[l][c][:] * scale[c] + shift[c]: the quantile (de)normalisation of
+// data/pipeline.py:183-244 (all five modes are of this form) applied to an (L, F, H, W) trajectory in place or out of place.
+__global__ __launch_bounds__(256) void affine_channels_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, long long planes, int F, int HW) {
+    const int nv = HW >> 2;  // HW % 4 == 0 checked by the launcher
+    const long long total = planes * nv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long plane = i / nv;
+        const int c = (int)(plane % F);
+        const float a = scale[c], b = shift[c];
+        f32x4_t v = ((const f32x4_t*)x)[i];
+        v = v * a + b;
+        ((f32x4_t*)y)[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int c2w_window_gather(const float* x, void* y, int nw, int F, int HW, int k, int i0, int ldc, int dtype, void* stream) {
@@ -183,5 +221,19 @@ extern "C" int c2w_guidance(const float* x, float* eps, const float* yobs, const
     const long long ncell = (long long)nobs * F * (H / s_step) * (W / s_step);
     const long long blocks = (ncell + 3) / 4;
     guidance_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_pool_stride(const float* x, float* y, int nobs, int F, int H, int W, int s_step, int t_step, void* stream) {
+    if (!x || !y || nobs <= 0 || F <= 0 || s_step <= 0 || t_step <= 0 || H % s_step || W % s_step) return C2W_ERR_BAD_SHAPE;
+    const long long ncell = (long long)nobs * F * (H / s_step) * (W / s_step);
+    pool_stride_kernel<<<(unsigned)((ncell * 64 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, nobs, F, H, W, s_step, t_step);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_affine_channels(const float* x, float* y, const float* scale, const float* shift, long long planes, int F, int HW,
+                                   void* stream) {
+    if (!x || !y || !scale || !shift || planes <= 0 || F <= 0 || HW <= 0 || HW % 4) return C2W_ERR_BAD_SHAPE;
+    affine_channels_kernel<<<grid_for(planes * (HW / 4)), 256, 0, (hipStream_t)stream>>>(x, y, scale, shift, planes, F, HW);
     return (int)hipGetLastError();
 }

@@ -159,3 +159,11 @@ def sampler_correct(x, eps, z, sumsq_buf, nan_flag, n, tau, sigma_next):
 def guidance(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma):
     check(_lib.load().c2w_guidance(_p(x), _p(eps), _p(yobs), _p(stdv), nobs, F, H, W, s_step, t_step, mu, sigma, gamma, _stream()),
           "c2w_guidance")
+
+
+def pool_stride(x, y, nobs, F, H, W, s_step, t_step):
+    check(_lib.load().c2w_pool_stride(_p(x), _p(y), nobs, F, H, W, s_step, t_step, _stream()), "c2w_pool_stride")
+
+
+def affine_channels(x, y, scale, shift, planes, F, HW):
+    check(_lib.load().c2w_affine_channels(_p(x), _p(y), _p(scale), _p(shift), planes, F, HW, _stream()), "c2w_affine_channels")

@@ -28,7 +28,14 @@ class PoolStrideOperator:
         self._pool = torch.nn.AvgPool2d(self.s_step)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        return self._pool(x[:: self.t_step])
+        if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad) \
+                and x.shape[-1] % self.s_step == 0 and x.shape[-2] % self.s_step == 0 and not _wrapped(x):
+            L, F, H, W = x.shape
+            nobs = (L + self.t_step - 1) // self.t_step
+            y = torch.empty((nobs, F, H // self.s_step, W // self.s_step), dtype=torch.float32, device=x.device)
+            ops.pool_stride(x.contiguous(), y, nobs, F, H, W, self.s_step, self.t_step)
+            return y
+        return self._pool(x[:: self.t_step])  # differentiable / host path: the same torch ops as the reference
 
 
 class AbstractScoreFunction:

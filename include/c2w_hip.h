@@ -148,6 +148,12 @@ int c2w_sampler_correct(float* x, const float* eps, const float* z, const float*
  * (src/thor/score.py:24-57): eps -= sigma/mu * A^T((y - A((x - sigma eps)/mu)) / (std_c^2 + gamma (sigma/mu)^2)), in place */
 int c2w_guidance(const float* x, float* eps, const float* yobs, const float* stdv, int nobs, int F, int H, int W,
                  int s_step, int t_step, float mu, float sigma, float gamma, void* stream);
+/* the measurement operator itself: y[o][c][ph][pw] = mean of the s x s cell of x[o*t_step][c] (exp/downscaling.py:129-132) */
+int c2w_pool_stride(const float* x, float* y, int nobs, int F, int H, int W, int s_step, int t_step, void* stream);
+/* per-variable affine map over (planes = L*F) planes of HW values: y = x * scale[c] + shift[c], c = plane % F -- the quantile
+ * normalisation / de-normalisation of data/pipeline.py:183-244 either side of the sampler (x == y allowed) */
+int c2w_affine_channels(const float* x, float* y, const float* scale, const float* shift, long long planes, int F, int HW,
+                        void* stream);
 
 /* library identity: returns the gfx target string the kernels were compiled for ("gfx950") */
 const char* c2w_target(void);

@@ -70,3 +70,40 @@ def batch_split(batch_size: int, world_size: int, batch_gpu=None):
     rounds = total // batch_gpu
     assert batch_size == batch_gpu * rounds * world_size
     return batch_gpu, rounds
+
+
+# ---------------------------------------------------------------- quantile (de)normalisation, measurement operator
+_NORM_MODES = {  # data/pipeline.py:183-244: every mode is (x - lower) / range with these quantile levels
+    "minmax": (0.0, 0.0, 1.0),      # (level subtracted, range from, range to)
+    "robust": (0.5, 0.25, 0.75),
+    "robust95": (0.5, 0.05, 0.95),
+    "quant95": (0.05, 0.05, 0.95),
+    "quant99": (0.01, 0.01, 0.99),
+}
+
+
+def norm_coefficients(quantiles: dict, mode: str):
+    """quantiles: {level: [value per variable]} -> (lower, range) per variable (data/pipeline.py:189-213)."""
+    if mode not in _NORM_MODES:
+        raise ValueError(f"Invalid mode: {mode}")
+    sub, lo, hi = _NORM_MODES[mode]
+    lower = torch.as_tensor(quantiles[sub], dtype=torch.float64)
+    rng = torch.as_tensor(quantiles[hi], dtype=torch.float64) - torch.as_tensor(quantiles[lo], dtype=torch.float64)
+    return lower, rng
+
+
+def normalize(x, quantiles: dict, mode: str):
+    """data/pipeline.py:183-213 on an (L, F, H, W) array: (x - lower_f) / range_f per variable f."""
+    lower, rng = norm_coefficients(quantiles, mode)
+    return ((x.double() - lower.view(1, -1, 1, 1)) / rng.view(1, -1, 1, 1)).to(x.dtype)
+
+
+def unnormalize(x, quantiles: dict, mode: str):
+    """data/pipeline.py:216-244: x * range_f + lower_f."""
+    lower, rng = norm_coefficients(quantiles, mode)
+    return (x.double() * rng.view(1, -1, 1, 1) + lower.view(1, -1, 1, 1)).to(x.dtype)
+
+
+def measure(x, s_step: int, t_step: int):
+    """exp/downscaling.py:129-132: AvgPool2d(s_step, stride=s_step)(x[::t_step]) on (L, F, H, W)."""
+    return torch.nn.functional.avg_pool2d(x[::t_step], s_step, stride=s_step, padding=0)

@@ -300,6 +300,17 @@ def guidance(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma
     Ev[::t_step][:nobs] -= sigma * g / mu
 
 
+def pool_stride(x, y, nobs, F, H, W, s_step, t_step):
+    L = x.numel() // (F * H * W)
+    X = x.reshape(-1)[: L * F * H * W].view(L, F, H, W)
+    y.reshape(-1)[: nobs * F * (H // s_step) * (W // s_step)] = torch.nn.functional.avg_pool2d(X[::t_step][:nobs], s_step).reshape(-1)
+
+
+def affine_channels(x, y, scale, shift, planes, F, HW):
+    X = x.reshape(-1)[: planes * HW].view(planes // F, F, HW)
+    y.reshape(-1)[: planes * HW] = (X * scale.reshape(1, F, 1) + shift.reshape(1, F, 1)).reshape(-1)
+
+
 ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("F",)]
 
 

@@ -350,3 +350,29 @@ def test_reference_network_snapshot_import_and_round_trip(emu, golden_dir, tmp_p
         pickle.dump(dict(ema=os.system), f)
     with pytest.raises(pickle.UnpicklingError):
         load_network_snapshot(str(evil))
+
+
+def test_quantile_normalizer_and_measurement_operator(emu):
+    """data/pipeline.py:183-244 (five affine modes) and exp/downscaling.py:129-132 against the oracle and
+    hand-computed values."""
+    from climate2weather_amd.normalize import QuantileNormalizer
+    q = {0.0: [-5.0, 0.0], 0.01: [-4.0, 0.5], 0.05: [2.0, 1.0], 0.25: [4.0, 2.0], 0.5: [6.0, 3.0], 0.75: [9.0, 5.0], 0.95: [12.0, 9.0],
+         0.99: [16.0, 10.5], 1.0: [20.0, 12.0]}
+    x = torch.full((3, 2, 4, 4), 7.0)
+    expect = {"minmax": [(7 + 5) / 25, 7 / 12], "robust": [(7 - 6) / 5, (7 - 3) / 3], "robust95": [(7 - 6) / 10, (7 - 3) / 8],
+              "quant95": [(7 - 2) / 10, (7 - 1) / 8], "quant99": [(7 + 4) / 20, (7 - 0.5) / 10]}
+    gen = torch.Generator().manual_seed(0)
+    xr = torch.randn(5, 2, 8, 8, generator=gen) * 3 + 4
+    for mode, vals in expect.items():
+        qn = QuantileNormalizer(q, mode)
+        y = qn.normalize(x)
+        assert torch.allclose(y[:, 0], torch.full_like(y[:, 0], vals[0]), atol=1e-6), mode
+        assert torch.allclose(y[:, 1], torch.full_like(y[:, 1], vals[1]), atol=1e-6), mode
+        assert torch.allclose(oh.normalize(x, q, mode), y, atol=1e-6)
+        assert torch.allclose(qn.normalize(xr), oh.normalize(xr, q, mode), atol=1e-5)
+        assert torch.allclose(qn.unnormalize(xr), oh.unnormalize(xr, q, mode), atol=1e-5)
+        assert torch.allclose(qn.unnormalize(qn.normalize(xr)), xr, atol=1e-4)
+    with pytest.raises(ValueError, match="Invalid mode"):
+        QuantileNormalizer(q, "zscore")
+    A = PoolStrideOperator(4, 2)
+    assert torch.allclose(A(xr), oh.measure(xr, 4, 2), atol=1e-6) and A(xr).shape == (3, 2, 2, 2)
