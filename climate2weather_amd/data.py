@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import Iterator, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -64,6 +66,57 @@ class SyntheticWindowDataset(torch.utils.data.Dataset):
     def __getitem__(self, i: int):
         x = self.load_window(i)
         return x.reshape(-1, *x.shape[2:]) if self._flatten else x
+
+
+class COSMODataset(torch.utils.data.Dataset):
+    """``dataset.COSMODataset`` (dataset.py:60-126) with the same constructor keywords, properties and item contract, over
+    an array ``x[N, F, H, W]`` that is read ONCE into memory (the reference's ``cached=True``) so that ``DeviceWindowFeed``
+    can keep it in HBM.  ``data_path``: the reference's ``.h5`` file with dataset ``"x"`` (needs ``h5py``, which the
+    reference also needs), a ``.npy`` file, or an in-memory array / tensor."""
+
+    def __init__(self, data_path, num_features: int, spatial_res: int, cached: bool = True, window: int = 13, flatten: bool = True):
+        self._window, self._flatten = window, flatten
+        self._data_path = data_path if isinstance(data_path, str) else "<array>"
+        if isinstance(data_path, str):
+            path = os.path.abspath(data_path)
+            assert os.path.isfile(path), path
+            ext = os.path.splitext(path)[-1]
+            if ext == ".h5":
+                try:
+                    import h5py
+                except ImportError as e:  # pragma: no cover
+                    raise ImportError("reading the reference's .h5 files needs h5py; convert to .npy or pass the array") from e
+                with h5py.File(path, mode="r") as f:
+                    arr = f["x"][:]  # dataset.py:73,81-84
+            elif ext == ".npy":
+                arr = np.load(path)
+            else:
+                raise ValueError(f"unsupported dataset file {path}")
+            self.data = torch.from_numpy(np.ascontiguousarray(arr)).float()
+        else:
+            self.data = torch.as_tensor(data_path).float()
+        assert self.data.dim() == 4, self.data.shape
+        assert self.data.shape[-1] == self.data.shape[-2] == spatial_res  # dataset.py:90
+        self.spatial_res = spatial_res
+        assert num_features == self.num_features, (
+            f"The number of specified features ({num_features}) does not match the number of features in the data ({self.num_features}).")
+
+    window = property(lambda self: self._window)
+    flatten = property(lambda self: self._flatten)
+    raw_data_shape = property(lambda self: tuple(self.data.shape))
+    raw_spatial_res = property(lambda self: self.spatial_res)
+    num_features = property(lambda self: self.data.shape[-3])
+    data_path = property(lambda self: self._data_path)
+
+    def __len__(self) -> int:
+        return self.data.shape[0] - self._window + 1
+
+    def load_window(self, i: int):
+        return self.data[i : i + self._window]
+
+    def __getitem__(self, i: int):
+        x = self.load_window(i)
+        return x.flatten(0, 1) if self._flatten else x
 
 
 class DeviceWindowFeed:

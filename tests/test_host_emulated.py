@@ -376,3 +376,22 @@ def test_quantile_normalizer_and_measurement_operator(emu):
         QuantileNormalizer(q, "zscore")
     A = PoolStrideOperator(4, 2)
     assert torch.allclose(A(xr), oh.measure(xr, 4, 2), atol=1e-6) and A(xr).shape == (3, 2, 2, 2)
+
+
+def test_cosmo_dataset_contract(tmp_path):
+    """dataset.py:60-126 item contract over an in-memory / .npy array, feeding the device-resident feed."""
+    from climate2weather_amd.data import COSMODataset
+    arr = np.random.RandomState(0).randn(20, 4, 16, 16).astype(np.float32)
+    np.save(tmp_path / "train.npy", arr)
+    for src in (str(tmp_path / "train.npy"), arr):
+        ds = COSMODataset(src, num_features=4, spatial_res=16, window=13, flatten=True)
+        assert len(ds) == 8 and ds.window == 13 and ds.num_features == 4 and ds.raw_data_shape == (20, 4, 16, 16)
+        assert torch.equal(ds[3], oh.window_item(torch.from_numpy(arr), 3, 13))
+        assert ds[3].shape == (52, 16, 16)
+    with pytest.raises(AssertionError):
+        COSMODataset(arr, num_features=5, spatial_res=16)
+    feed = DeviceWindowFeed(ds, torch.device("cpu"), rank=1, num_replicas=2, seed=0)
+    b = feed.next_batch(3)
+    it = iter(InfiniteSampler(ds, rank=1, num_replicas=2, seed=0))
+    for j in range(3):
+        assert torch.equal(b[j], ds[next(it)])
