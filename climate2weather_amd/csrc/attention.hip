@@ -8,6 +8,11 @@
 #include "common.h"
 #include "c2w_hip.h"
 
+// matrix-core path for bf16, T = 64 (attention_mfma.hip)
+bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype);
+int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st);
+int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, hipStream_t st);
+
 namespace {
 
 constexpr int TR = 16;  // rows per tile
@@ -209,6 +214,7 @@ int set_lds(K kernel, int bytes) {
 extern "C" int c2w_attention_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, void* stream) {
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!qkv || !o || B <= 0 || Tn <= 0 || C <= 0 || C % P) return C2W_ERR_BAD_SHAPE;
+    if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_forward(qkv, o, lse, B, C, (hipStream_t)stream);
     const int lds = (TR * C + TR * Tn) * 4;
     if (lds > 160 * 1024) return C2W_ERR_UNSUPPORTED;
     dim3 grid((Tn + TR - 1) / TR, B);
@@ -228,6 +234,7 @@ extern "C" int c2w_attention_backward(const void* qkv, const void* o, const void
                                       int Tn, int C, int dtype, void* stream) {
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!qkv || !o || !d_o || !lse || !delta_ws || !dqkv || B <= 0 || Tn <= 0 || C % P) return C2W_ERR_BAD_SHAPE;
+    if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_backward(qkv, d_o, lse, dqkv, B, C, (hipStream_t)stream);
     const int lds = (TR * C + 2 * TR * Tn) * 4;
     if (lds > 160 * 1024) return C2W_ERR_UNSUPPORTED;
     dim3 grid((Tn + TR - 1) / TR, B);

@@ -1,0 +1,227 @@
+// Matrix-core version of the bottleneck attention (model/nn.py:62-85) for the shape the default network runs:
+// bf16, T = 64 tokens (8x8 pixels), one head of width C (a multiple of 32, <= 512).  One workgroup (4 waves) per image;
+// wave w owns the 16-row strip w of every 64-row matrix.  All five products are v_mfma_f32_16x16x32_bf16:
+//
+//   forward :  S = q k^T (K-dim C: both operands are K-contiguous in HBM -> fragments by 16-B global loads, no LDS),
+//              P = softmax(S * s^2) in fp32 (s = C^-1/4 on q and on k, model/nn.py:76-83), rounded to bf16 like the
+//              reference's `weight.type(x.dtype)`, O = P v (K-dim = keys: v staged in LDS and read through the
+//              transposing LDS read, P through an LDS round trip from accumulator to operand layout).
+//   backward:  recompute S, P = exp(S s^2 - lse);  dP = dO v^T;  delta = rowsum(P * dP);  dS = P * (dP - delta) * s^2
+//              dq = dS k,  dv = P^T dO,  dk = dS^T q  -- the three K-dim-64 products read k / dO / q from LDS with
+//              transposing reads; P and dS go through LDS as bf16.  No atomics, bit-reproducible.
+//
+// The fp32 / general-T kernels in attention.hip stay the reference implementation and the fallback.
+#include <cstdlib>
+#include "common.h"
+#include "c2w_hip.h"
+
+namespace {
+
+constexpr int T64 = 64;
+constexpr int PP = 144;  // row pitch (bytes) of the 64 x 64 bf16 P / dS tiles in LDS (128 + 16: rows land on different banks)
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// MFMA operand for a matrix stored [k][m] (k = reduction index = LDS row, m contiguous): lane (li, lg) receives
+// M[k0 + 8 lg + 0..7][col0 + li] -- two transposing 8-byte reads (rows +0..3 and +4..7 of the lane's 8-row group).
+__device__ __forceinline__ bf16x8_t tr_frag(const char* base, int pitch, int k0, int col0, int li, int lg) {
+    const int q = li >> 2, pp = li & 3;
+    const char* p0 = base + (k0 + 8 * lg + q) * pitch + (col0 + pp * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p0 + 4 * pitch));
+    return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// reductions over the 16 lanes (li) that hold one accumulator row = one DPP row
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_get<0x128>(v);
+    v += dpp_get<0x124>(v);
+    v += dpp_get<0x122>(v);
+    return v + dpp_get<0x121>(v);
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_get<0x128>(v));
+    v = fmaxf(v, dpp_get<0x124>(v));
+    v = fmaxf(v, dpp_get<0x122>(v));
+    return fmaxf(v, dpp_get<0x121>(v));
+}
+
+// rows [0,64) x C bf16 of a [.][ld] matrix -> LDS [64][pitch]
+__device__ __forceinline__ void stage_rows(char* dst, int pitch, const bf16_t* src, int ld, int C) {
+    const int nch = C >> 3;
+    for (int i = threadIdx.x; i < T64 * nch; i += 256) {
+        const int r = i / nch, c = i - r * nch;
+        *(u32x4_t*)(dst + r * pitch + c * 16) = *(const u32x4_t*)(src + (size_t)r * ld + c * 8);
+    }
+}
+
+// acc[n] (+)= A-strip(16 rows of `a`, starting at row w*16) . B^T, both K-contiguous in HBM: the 16 x 64 strip of a b^T
+__device__ __forceinline__ void strip_abt(f32x4_t (&acc)[4], const bf16_t* a, const bf16_t* b, int ld, int C, int w, int li, int lg) {
+    const bf16_t* ar = a + (size_t)(16 * w + li) * ld + 8 * lg;
+    const bf16_t* br = b + (size_t)li * ld + 8 * lg;
+#pragma unroll 4
+    for (int ks = 0; ks < C / 32; ++ks) {
+        const bf16x8_t av = *(const bf16x8_t*)(ar + 32 * ks);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ld + 32 * ks);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+        }
+    }
+}
+
+// out strip (16 rows starting at 16 w) = A . M, K-dim 64:  A fragments a[ks] given, M[64][C] in LDS (pitch), all C/16 column tiles
+__device__ __forceinline__ void strip_times_lds(bf16_t* out, int ldo, const bf16x8_t (&a)[2], const char* M, int pitch, int C, int w, int li,
+                                                int lg) {
+    for (int ct = 0; ct < C / 16; ++ct) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], tr_frag(M, pitch, 32 * ks, 16 * ct, li, lg), acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * w + 4 * lg + r) * ldo + 16 * ct + li] = f32_to_bf16(acc[r]);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+                                                            int C, float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VP = C * 2 + 16;
+    char* const Vl = smem;
+    char* const Pl = smem + T64 * VP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int ld = 3 * C;
+    const bf16_t* base = qkv + (size_t)blockIdx.x * T64 * ld;
+    stage_rows(Vl, VP, base + 2 * C, ld, C);
+
+    f32x4_t s[4] = {};
+    strip_abt(s, base, base + C, ld, C, w, li, lg);
+    // accumulator element s[n][r] = S[16 w + 4 lg + r][16 n + li]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s[n][r] *= scale2;
+            m = fmaxf(m, s[n][r]);
+        }
+        m = row16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s[n][r] = __expf(s[n][r] - m);
+            sum += s[n][r];
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.0f / sum;
+        const int row = 16 * w + 4 * lg + r;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bf16(s[n][r] * inv);
+        if (lse != nullptr && li == 0) lse[(size_t)blockIdx.x * T64 + row] = m + __logf(sum);
+    }
+    __syncthreads();
+    bf16x8_t pa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) pa[ks] = *(const bf16x8_t*)(Pl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
+    strip_times_lds(o + (size_t)blockIdx.x * T64 * C, C, pa, Vl, VP, C, w, li, lg);
+}
+
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                            const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int C, float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VP = C * 2 + 16;
+    char* const B0 = smem;                 // k, later q
+    char* const B1 = smem + T64 * VP;      // dO
+    char* const Pl = smem + 2 * T64 * VP;  // P  [q][key]
+    char* const Sl = Pl + T64 * PP;        // dS [q][key] (already times s^2)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int ld = 3 * C;
+    const bf16_t* base = qkv + (size_t)blockIdx.x * T64 * ld;
+    const bf16_t* dob = d_o + (size_t)blockIdx.x * T64 * C;
+    bf16_t* dbase = dqkv + (size_t)blockIdx.x * T64 * ld;
+    stage_rows(B0, VP, base + C, ld, C);
+    stage_rows(B1, VP, dob, C, C);
+
+    f32x4_t s[4] = {}, dp[4] = {};
+    strip_abt(s, base, base + C, ld, C, w, li, lg);  // q k^T
+    {   // dO v^T: dO rows have pitch C, v rows pitch 3C -> two pointers, same loop shape as strip_abt
+        const bf16_t* ar = dob + (size_t)(16 * w + li) * C + 8 * lg;
+        const bf16_t* br = base + 2 * C + (size_t)li * ld + 8 * lg;
+#pragma unroll 4
+        for (int ks = 0; ks < C / 32; ++ks) {
+            const bf16x8_t av = *(const bf16x8_t*)(ar + 32 * ks);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ld + 32 * ks);
+                dp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, dp[n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + 4 * lg + r;
+        const float l = lse[(size_t)blockIdx.x * T64 + row];
+        float delta = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s[n][r] = __expf(s[n][r] * scale2 - l);  // P
+            delta += s[n][r] * dp[n][r];
+        }
+        delta = row16_sum(delta);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float ds = s[n][r] * (dp[n][r] - delta) * scale2;
+            *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bf16(s[n][r]);
+            *(bf16_t*)(Sl + row * PP + (16 * n + li) * 2) = f32_to_bf16(ds);
+        }
+    }
+    __syncthreads();
+    bf16x8_t a[2];
+    // dq strip (query rows): dS . k
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[ks] = *(const bf16x8_t*)(Sl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
+    strip_times_lds(dbase, ld, a, B0, VP, C, w, li, lg);
+    // dv strip (key rows): P^T . dO  -- A[m = key][k = query] = P[query][key]: transposing read of the P tile
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Pl, PP, 32 * ks, 16 * w, li, lg);
+    strip_times_lds(dbase + 2 * C, ld, a, B1, VP, C, w, li, lg);
+    __syncthreads();  // every wave is done with k before q replaces it
+    stage_rows(B0, VP, base, ld, C);
+    __syncthreads();
+    // dk strip (key rows): dS^T . q
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Sl, PP, 32 * ks, 16 * w, li, lg);
+    strip_times_lds(dbase + C, ld, a, B0, VP, C, w, li, lg);
+}
+
+}  // namespace
+
+bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype) {
+    return dtype == C2W_DTYPE_BF16 && Tn == T64 && C % 32 == 0 && C <= 512 && B > 0 && getenv("C2W_ATTN_VALU") == nullptr;
+}
+
+int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st) {
+    const int lds = T64 * (C * 2 + 16) + T64 * PP;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    attn_mfma_fwd_kernel<<<B, 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, C, 1.0f / sqrtf((float)C));
+    return (int)hipGetLastError();
+}
+
+int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, hipStream_t st) {
+    const int lds = 2 * T64 * (C * 2 + 16) + 2 * T64 * PP;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    attn_mfma_bwd_kernel<<<B, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, (bf16_t*)dqkv, C, 1.0f / sqrtf((float)C));
+    return (int)hipGetLastError();
+}

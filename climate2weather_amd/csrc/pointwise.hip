@@ -340,31 +340,31 @@ __global__ __launch_bounds__(256) void mse_loss_grad_kernel(const T* __restrict_
     if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
 }
 
-// ---- LDS-tiled layout kernels: one block = one image x 128 pixels.  Channel planes (NCHW fp32) are read as coalesced rows
-//      into an LDS tile [channel][pixel], NHWC rows leave as contiguous 16-B vectors (the whole 128-pixel x ldc span of
+// ---- LDS-tiled layout kernels: one block = one image x 64 pixels.  Channel planes (NCHW fp32) are read as coalesced rows
+//      into an LDS tile [channel][pixel], NHWC rows leave as contiguous 16-B vectors (the whole 64-pixel x ldc span of
 //      the output is one contiguous byte range).  Replaces per-thread strided 16-B stores / 4-B gathers.
-constexpr int LT_PT = 128;  // pixels per tile
+constexpr int LT_PT = 64;  // pixels per tile (256-B runs of every channel plane; ldc = 128 channels -> 33 KB of LDS)
 constexpr int LT_LD = LT_PT + 1;
 
 // tile[c][px] = f(plane values) for c < ldc (zero beyond C / beyond HW)
 template <typename F>
 __device__ __forceinline__ void lt_load_planes(float* tile, int C, int ldc, int HW, int p0, size_t img_off, F&& f) {
     const int tid = threadIdx.x;
-    if ((HW & 3) == 0) {  // 16-B loads: 32 lanes cover one channel row of the tile
-        const int q = tid & 31, cb = tid >> 5;
+    if ((HW & 3) == 0) {  // 16-B loads: 16 lanes cover one channel row of the tile
+        const int q = tid & (LT_PT / 4 - 1), cb = tid / (LT_PT / 4);
         const bool in = p0 + 4 * q < HW;
 #pragma unroll 4
-        for (int c = cb; c < ldc; c += 8) {
+        for (int c = cb; c < ldc; c += 256 / (LT_PT / 4)) {
             f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             if (c < C && in) v = f(img_off + (size_t)c * HW + p0 + 4 * q);
             float* d = tile + c * LT_LD + 4 * q;
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
     } else {
-        const int px = tid & (LT_PT - 1), cb = tid >> 7;
+        const int px = tid & (LT_PT - 1), cb = tid / LT_PT;
         const bool in = p0 + px < HW;
 #pragma unroll 4
-        for (int c = cb; c < ldc; c += 2) {
+        for (int c = cb; c < ldc; c += 256 / LT_PT) {
             float v = 0.f;
             if (c < C && in) v = f(img_off + (size_t)c * HW + p0 + px, 0);
             tile[c * LT_LD + px] = v;
