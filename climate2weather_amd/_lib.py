@@ -36,6 +36,8 @@ class ConvArgs(Structure):
 _PROTOS = {
     "c2w_conv_forward": [POINTER(ConvArgs), c_int, c_int, c_void_p],
     "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
+    "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_void_p],
     "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,

@@ -305,6 +305,11 @@ int launch_dtype(const C2wConvArgs& a, int naive, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int c2w_conv_patch_supported(const C2wConvArgs* a, int dtype) {
+    (void)dtype;
+    return a != nullptr && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr ? 1 : 0;
+}
+
 extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || dtype != C2W_DTYPE_BF16) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE) return 0;

@@ -452,7 +452,7 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int nN = (a.Cout + 127) / 128;
-    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr) {  // two half-tile workgroups per CU
+    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr || (a.Hin & 15) != 0) {  // two half-tile workgroups per CU
         static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
         static bool attr_h = false;
         if (!attr_h) {
@@ -471,9 +471,9 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool c2w_conv_patch_eligible(const C2wConvArgs& a) {
-    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 15) == 0 && (a.Win & 15) == 0 &&
-           (long long)a.B * (a.Hin >> 4) * (a.Win >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
+bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // images that 8 x 16-pixel tiles cover exactly
+    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && (a.Win & 15) == 0 &&
+           (long long)a.B * (a.Hin >> 3) * (a.Win >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
 }
 
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {

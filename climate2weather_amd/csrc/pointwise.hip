@@ -264,6 +264,24 @@ __global__ __launch_bounds__(256) void sumpool2_kernel(const T* __restrict__ g, 
     }
 }
 
+// y[b][2h+i][2w+j][:] = x[b][h][w][:]   (Upsample(nearest, x2), model/nn.py:184, materialised so that the 3x3 conv after it
+// and its weight gradient run on the halo-patch kernels; the gather-mode `UP` convolution reads x directly instead)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int nvec = C / P;
+    const long long total = (long long)B * 2 * H * 2 * W * nvec;  // one 16-B vector of the OUTPUT per thread: contiguous stores
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int vec = (int)(i % nvec);
+        long long pix = i / nvec;
+        const int ow = (int)(pix % (2 * W));
+        pix /= 2 * W;
+        const int oh = (int)(pix % (2 * H));
+        const int b = (int)(pix / (2 * H));
+        ((u32x4_t*)y)[i] = *(const u32x4_t*)(x + (((size_t)b * H + (oh >> 1)) * W + (ow >> 1)) * C + vec * P);
+    }
+}
+
 // NCHW fp32 -> NHWC T with channel padding (zeros).  Optional fused noise process xt = mu[b] x + sigma[b] eps
 // (src/thor/pipelines.py:22-25): pass eps (NCHW fp32) and musig[b] = {mu, sigma}.
 template <typename T>
@@ -598,6 +616,14 @@ extern "C" int c2w_sumpool2(const void* g, void* dx, int B, int H, int W, int C,
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     DISPATCH_T(dtype, (sumpool2_kernel<T><<<grid_for((long long)B * H * W * (C / P)), 256, 0, (hipStream_t)stream>>>((const T*)g, (T*)dx, B, H,
                                                                                                                   W, C)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_upsample2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !y || !vec_ok(dtype, C)) return C2W_ERR_BAD_SHAPE;
+    const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
+    DISPATCH_T(dtype, (upsample2_kernel<T><<<grid_for((long long)B * 4 * H * W * (C / P), 256, 16384), 256, 0, (hipStream_t)stream>>>(
+                          (const T*)x, (T*)y, B, H, W, C)));
     return (int)hipGetLastError();
 }
 

@@ -497,7 +497,16 @@ class Engine:
                 ops.ln_forward(xin, None, hl, npix, Hc * Wc, Cc, 0, LN_EPS, self.ln_unbiased, dt)
                 Hl, Wl = Hc, Wc
                 Hc, Wc = Hc * 2, Wc * 2
-                cur, g_t, r_t = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop())
+                rec_t = lay.convs["unet." + lv.tail_key]
+                if ops.conv_patch_supported(self._geom(B, Hc, Wc, rec_t.kstride, Hc, Wc, rec_t.rows, rec_t.rows, rec_t.rows, CONV_S1), dt):
+                    # materialise the upsampled map once: the conv and its weight gradient then run on the halo-patch kernels
+                    # (measured 905 -> 620 + 150 us forward, 1400 -> 305 us weight gradient at 64^2 -> 128^2, B = 128)
+                    hu = torch.empty((B * Hc * Wc, Cc), dtype=T, device=dev)
+                    ops.upsample2(hl, hu, B, Hl, Wl, Cc, dt)
+                    cur, g_t, r_t = conv3("unet." + lv.tail_key, hu, Hc, Wc, Hc, Wc, CONV_S1, res=skips.pop())
+                    hl = hu
+                else:
+                    cur, g_t, r_t = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop())
                 if train:
                     def bw_tail(gy, xin=xin, hl=hl, g=g_t, rec=r_t, Hl=Hl, Wl=Wl, Hu=Hc, Wu=Wc, Cc=Cc, lvl=i - 1):
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient

@@ -50,6 +50,12 @@ def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
+def conv_patch_supported(g: dict, dtype: int) -> bool:
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    return bool(_lib.load().c2w_conv_patch_supported(ctypes.byref(a), dtype))
+
+
 def conv_lnbwd_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
@@ -86,6 +92,10 @@ def silu_backward(x, dy, dx, n, dtype):
 
 def sumpool2(g, dx, B, H, W, C, dtype):
     check(_lib.load().c2w_sumpool2(_p(g), _p(dx), B, H, W, C, dtype, _stream()), "c2w_sumpool2")
+
+
+def upsample2(x, y, B, H, W, C, dtype):
+    check(_lib.load().c2w_upsample2(_p(x), _p(y), B, H, W, C, dtype, _stream()), "c2w_upsample2")
 
 
 def nchw_to_nhwc(x, eps, musig, y, B, C, HW, ldc, dtype):

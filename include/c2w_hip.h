@@ -65,6 +65,9 @@ typedef struct C2wConvArgs {
     int32_t ln_pad_;
 } C2wConvArgs;
 
+/* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
+ * by 8 x 16-pixel tiles), 0 when it takes the general gather kernels. */
+int c2w_conv_patch_supported(const C2wConvArgs* args, int dtype);
 /* 1 when c2w_conv_forward can run args with the fused LayerNorm backward (bf16, Cout == ldy == 128, 3x3 stride-1 on an
  * image the halo-patch kernel tiles, no mul / act / y2), else 0.  Callers fall back to conv + c2w_ln_backward. */
 int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);
@@ -98,6 +101,8 @@ int c2w_silu_backward(const void* x, const void* dy, void* dx, long long n, int 
 /* adjoint of Upsample(nearest, x2) (model/nn.py:184): dx[b][h][w] = sum of the 2x2 block of g ([B][2H][2W][C]) */
 int c2w_sumpool2(const void* g, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 
+/* Upsample(nearest, x2) (model/nn.py:184) on NHWC rows: y[b][2h+i][2w+j] = x[b][h][w] */
+int c2w_upsample2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 /* NCHW fp32 <-> NHWC (padded to ldc channels).  With eps != NULL the forward noise process of
  * src/thor/pipelines.py:22-25 is fused: y = mu[b] x + sigma[b] eps, musig = {mu_0, sigma_0, mu_1, ...}. */
 int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* musig, void* y, int B, int C, int HW, int ldc,

@@ -47,6 +47,8 @@ CONV_CASES = [
     (ops.CONV_S1, 2, 4, 4, 64, 64, 64, 64),         # tiny spatial (plumbing config depth)
     (ops.CONV_S1, 2, 32, 48, 128, 128, 128, 128),   # halo-patch kernel: 2x3 tiles per image, 2 K-chunks (bf16) / 4 (fp32)
     (ops.CONV_S1, 1, 16, 32, 192, 320, 320, 320),   # halo-patch kernel: odd chunk count, 3 channel tiles (last partial)
+    (ops.CONV_S1, 2, 8, 16, 128, 128, 128, 128),    # halo-patch kernel: one 8x16 tile per image
+    (ops.CONV_S1, 1, 24, 32, 64, 128, 128, 128),    # halo-patch kernel: height a multiple of 8 only
     (ops.CONV_S2, 2, 16, 16, 64, 128, 128, 128),
     (ops.CONV_S2, 1, 32, 32, 128, 256, 256, 256),
     (ops.CONV_UP, 2, 8, 8, 128, 64, 64, 64),
@@ -193,6 +195,20 @@ def test_layernorm_fwd_bwd(shape, dt):
     ops.ln_forward(x, None, y, npix, HW, C, 0, 1e-5, False, dt)
     E.ln_forward(x, None, y_ref, npix, HW, C, 0, 1e-5, False, dt)
     close(y, y_ref, dt, "ln fwd biased")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_upsample2(dt):
+    B, H, W, C = 3, 5, 7, 64
+    x = rnd((B * H * W, C), dt, 1)
+    y = torch.empty((B * 4 * H * W, C), dtype=TD[dt], device=dev())
+    y_ref = torch.empty_like(y)
+    ops.upsample2(x, y, B, H, W, C, dt)
+    E.upsample2(x, y_ref, B, H, W, C, dt)
+    assert torch.equal(y, y_ref)
+    assert ops.conv_patch_supported(geom(2, 8, 16, 64, 8, 16, 128, 128, 128, ops.CONV_S1), dt)
+    assert not ops.conv_patch_supported(geom(2, 8, 8, 64, 8, 8, 128, 128, 128, ops.CONV_S1), dt)
+    assert not ops.conv_patch_supported(geom(2, 16, 16, 64, 8, 8, 128, 128, 128, ops.CONV_S2), dt)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
