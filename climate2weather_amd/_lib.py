@@ -28,7 +28,7 @@ class ConvArgs(Structure):
         ("Hout", c_int32), ("Wout", c_int32), ("Cout", c_int32), ("ldy", c_int32),
         ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),
         ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
-        ("ln_eps", c_float), ("ln_pad_", c_int32),
+        ("ln_eps", c_float), ("ln_pad_", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p),
     ]
 
 
@@ -36,6 +36,7 @@ class ConvArgs(Structure):
 _PROTOS = {
     "c2w_conv_forward": [POINTER(ConvArgs), c_int, c_int, c_void_p],
     "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_void_p],

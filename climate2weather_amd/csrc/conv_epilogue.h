@@ -204,6 +204,65 @@ struct EpiStore {
         }
     }
 
+    // ---- fused LayerNorm FORWARD of the consumer (bf16 tile with whole 128-channel rows of one image `img`):
+    //   y = O (+ res), stored; lnf_y = LN_C(y_as_stored + lnf_m[img])  -- the arithmetic of ln_fwd_kernel (two-pass variance)
+    __device__ __forceinline__ void finish_lnf(const C2wConvArgs& p, const char* O, int OS, int tid, int img) {
+        static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN forward: bf16 tiles only");
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        const int cs = tid & (SEGS - 1);
+        f2 m2[4];
+        if (p.lnf_m != nullptr) {
+            const float* mr = p.lnf_m + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + cs * PER16;
+            const f32x4_t ma = *(const f32x4_t*)mr, mb = *(const f32x4_t*)(mr + 4);
+            m2[0] = (f2){ma[0], ma[1]}; m2[1] = (f2){ma[2], ma[3]}; m2[2] = (f2){mb[0], mb[1]}; m2[3] = (f2){mb[2], mb[3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m2[k] = (f2){0.f, 0.f};
+        }
+        const float inv_den = 1.0f / (float)(128 - (p.ln_unbiased ? 1 : 0));
+        auto unpack2 = [](const u32x4_t& v, f2* f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = (f2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+        };
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int seg = tid + i * NTHR;
+            const int row = seg / SEGS;
+            u32x4_t out = *(const u32x4_t*)(O + row * OS + cs * 16);
+            f2 u[4];
+            if (p.res != nullptr) {
+                f2 r[4];
+                unpack2(out, u);
+                unpack2(rr[i], r);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    u[k] += r[k];
+                    out[k] = pack_bf16x2(u[k][0], u[k][1]);
+                }
+            }
+            if (off[i] >= 0) *(u32x4_t*)((char*)p.y + off[i]) = out;
+            unpack2(out, u);  // the values as stored (bf16), like the separate LN pass would read them
+            f2 s2 = (f2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u[k] += m2[k];
+                s2 += u[k];
+            }
+            const float mean = sub16(s2[0] + s2[1]) * (1.0f / 128.0f);
+            f2 q2 = (f2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u[k] -= mean;
+                q2 += u[k] * u[k];
+            }
+            const float rs = __builtin_amdgcn_rsqf(sub16(q2[0] + q2[1]) * inv_den + p.ln_eps);
+            u32x4_t ln;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ln[k] = pack_bf16x2(u[k][0] * rs, u[k][1] * rs);
+            if (off[i] >= 0) *(u32x4_t*)((char*)p.lnf_y + off[i]) = ln;
+        }
+    }
+
     // sum over the 16 lanes that share a pixel row = one DPP row: four row rotations on the VALU (no LDS-pipe shuffles)
     template <int CTRL>
     static __device__ __forceinline__ float dpp_add(float v) {

@@ -310,6 +310,15 @@ extern "C" int c2w_conv_patch_supported(const C2wConvArgs* a, int dtype) {
     return a != nullptr && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr ? 1 : 0;
 }
 
+extern "C" int c2w_conv_lnfwd_supported(const C2wConvArgs* a, int dtype) {
+    if (a == nullptr || dtype != C2W_DTYPE_BF16) return 0;
+    if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE || a->ln_x != nullptr) return 0;
+    return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr &&
+                   getenv("C2W_NO_LNF") == nullptr
+               ? 1
+               : 0;
+}
+
 extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || dtype != C2W_DTYPE_BF16) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE) return 0;
@@ -326,6 +335,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->Hout >= 65536 || a->Wout >= 65536) return C2W_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
+    if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if (naive == 0 && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_s1(*a, dtype, st);
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     C2W_STAMP(st3);
     if constexpr (ESZ == 2) {
         if (p.ln_x != nullptr) est.finish_ln(p, O, OS, tid, b, red);
+        else if (p.lnf_y != nullptr) est.finish_lnf(p, O, OS, tid, b);
         else est.finish(p, O, OS, tid);
     } else {
         est.finish(p, O, OS, tid);
@@ -452,7 +453,7 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int nN = (a.Cout + 127) / 128;
-    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr || (a.Hin & 15) != 0) {  // two half-tile workgroups per CU
+    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr || a.lnf_y != nullptr || (a.Hin & 15) != 0) {  // two half-tile workgroups per CU
         static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
         static bool attr_h = false;
         if (!attr_h) {

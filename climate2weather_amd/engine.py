@@ -369,12 +369,21 @@ class Engine:
             x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
             ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
 
-        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None):
+        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None, want_ln=None):
+            """want_ln: None, or the consumer's LayerNorm to emit from this conv's epilogue: ("mod", modulation rows) for a
+            residual block, ("plain", None) for an up-block.  Returns (y, geometry, record[, LN output or None])."""
             rec = lay.convs[name]
             ldy_ = ldy or rec.rows
             y = torch.empty((B * Ho * Wo, ldy_), dtype=T, device=dev)
             g = self._geom(B, Hi, Wi, rec.kstride, Ho, Wo, cout or rec.rows, ldy_, rec.rows, mode)
-            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2)
+            hn = None
+            lnf = None
+            if want_ln is not None and act == ACT_NONE and y2 is None and ops.conv_lnfwd_supported(g, dt):
+                hn = torch.empty_like(y)
+                lnf = dict(y=hn, m=want_ln[1], ldm=ldm if want_ln[1] is not None else 0, eps=LN_EPS, unbiased=self.ln_unbiased)
+            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2, lnf=lnf)
+            if want_ln is not None:
+                return y, g, rec, hn
             return y, g, rec
 
         def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None, ln=None):
@@ -387,19 +396,25 @@ class Engine:
             ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=MUL_DSILU, ln=ln)
             return dx
 
-        def res_block(b: BlockSpec, xin, Hc, Wc):
+        def res_block(b: BlockSpec, xin, Hc, Wc, h0=None, want_ln=None):
+            """h0: LN(xin + m) if the producer of xin already emitted it; want_ln: the consumer's LayerNorm to emit from
+            conv2's epilogue (see conv3).  Returns (block output, consumer's LN input or None)."""
             p = "unet." + b.key
             Cc = b.channels
             npix = B * Hc * Wc
             m = m_all.view(-1)[b.mod_offset:]
-            h0 = torch.empty((npix, Cc), dtype=T, device=dev)
-            ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
+            if h0 is None:
+                h0 = torch.empty((npix, Cc), dtype=T, device=dev)
+                ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
             # training keeps the pre-activation (for silu') and the activation: both come out of the conv's epilogue
             h1 = torch.empty((npix, Cc), dtype=T, device=dev) if train else None
             a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE if train else ACT_SILU, y2=h1)
             if not train:
                 h1 = a1
-            out, g2, r2 = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin)
+            if want_ln is not None:
+                out, g2, r2, hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin, want_ln=want_ln)
+            else:
+                (out, g2, r2), hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin), None
             if train:
                 def bw(gy):
                     ops.conv_wgrad(h1, gy, self._gw(r2), g2, dt, dbias=self._gb(r2))
@@ -417,7 +432,7 @@ class Engine:
                         ops.ln_backward(dh0, xin, m, gy, dx, dm, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
                     return dx
                 tape.steps.append(bw)
-            return out
+            return out, hn
 
         def attn_block(b: BlockSpec, xin, Hc, Wc):
             p = "unet." + b.key
@@ -466,6 +481,23 @@ class Engine:
                     return None
                 return dgrad(rec, gy, H, W, H, W, CONV_S1, lay.cin_pad)
             tape.steps.append(bw_head0)
+        def mod_of(b: BlockSpec):
+            return ("mod", m_all.view(-1)[b.mod_offset:])
+
+        def run_blocks(blocks, cur, Hc, Wc, h0, tail_ln):
+            """The blocks of one level side in order.  Each residual block asks its producer -- the previous block's second
+            conv -- for its LayerNorm input; ``tail_ln`` is what the consumer after the last block wants.  Returns the
+            output and that consumer's LN input (None if it was not fused)."""
+            hn = h0
+            for j, b in enumerate(blocks):
+                if b.kind == "res":
+                    nb = blocks[j + 1] if j + 1 < len(blocks) else None
+                    want = (mod_of(nb) if nb.kind == "res" else None) if nb is not None else tail_ln
+                    cur, hn = res_block(b, cur, Hc, Wc, h0=hn, want_ln=want)
+                else:
+                    cur, hn = attn_block(b, cur, Hc, Wc), None
+            return cur, hn
+
         skips: List[torch.Tensor] = []
         for i, lv in enumerate(lay.levels):
             if i > 0:
@@ -480,21 +512,24 @@ class Engine:
                         # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
                         return dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
                     tape.steps.append(bw_head)
-            for b in lv.descent:
-                cur = res_block(b, cur, Hc, Wc) if b.kind == "res" else attn_block(b, cur, Hc, Wc)
+            cur, _ = run_blocks(lv.descent, cur, Hc, Wc, None, None)
             if i < L - 1:
                 skips.append(cur)
         # ---- ascent
+        h0_carry = None  # LN input of the level's first block when the up-conv below already produced it
         for i in reversed(range(L)):
             lv = lay.levels[i]
-            for b in lv.ascent:
-                cur = res_block(b, cur, Hc, Wc) if b.kind == "res" else attn_block(b, cur, Hc, Wc)
+            cur, hl_ready = run_blocks(lv.ascent, cur, Hc, Wc, h0_carry, ("plain", None) if i > 0 else None)
+            h0_carry = None
             if i > 0:
                 xin = cur
                 Cc = lv.channels
                 npix = B * Hc * Wc
-                hl = torch.empty((npix, Cc), dtype=T, device=dev)
-                ops.ln_forward(xin, None, hl, npix, Hc * Wc, Cc, 0, LN_EPS, self.ln_unbiased, dt)
+                if hl_ready is not None:
+                    hl = hl_ready
+                else:
+                    hl = torch.empty((npix, Cc), dtype=T, device=dev)
+                    ops.ln_forward(xin, None, hl, npix, Hc * Wc, Cc, 0, LN_EPS, self.ln_unbiased, dt)
                 Hl, Wl = Hc, Wc
                 Hc, Wc = Hc * 2, Wc * 2
                 rec_t = lay.convs["unet." + lv.tail_key]
@@ -503,7 +538,11 @@ class Engine:
                     # (measured 905 -> 620 + 150 us forward, 1400 -> 305 us weight gradient at 64^2 -> 128^2, B = 128)
                     hu = torch.empty((B * Hc * Wc, Cc), dtype=T, device=dev)
                     ops.upsample2(hl, hu, B, Hl, Wl, Cc, dt)
-                    cur, g_t, r_t = conv3("unet." + lv.tail_key, hu, Hc, Wc, Hc, Wc, CONV_S1, res=skips.pop())
+                    nxt = lay.levels[i - 1].ascent[0] if lay.levels[i - 1].ascent else None
+                    if nxt is not None and nxt.kind == "res":  # the up-conv also emits the next level's first LayerNorm input
+                        cur, g_t, r_t, h0_carry = conv3("unet." + lv.tail_key, hu, Hc, Wc, Hc, Wc, CONV_S1, res=skips.pop(), want_ln=mod_of(nxt))
+                    else:
+                        cur, g_t, r_t = conv3("unet." + lv.tail_key, hu, Hc, Wc, Hc, Wc, CONV_S1, res=skips.pop())
                     hl = hu
                 else:
                     cur, g_t, r_t = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop())

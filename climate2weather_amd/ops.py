@@ -32,21 +32,26 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None) -> ConvArgs:
+def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=None) -> ConvArgs:
     a = ConvArgs(_p(x), _p(w), _p(bias), _p(res), _p(mul), _p(y), _p(y2), g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"],
                  g["Cout"], g["ldy"], g["wrows"], g["mode"], act, mulmode)
     if ln is not None:
         a.ln_x, a.ln_m, a.ln_dm = _p(ln["x"]), _p(ln.get("m")), _p(ln.get("dm"))
         a.ln_ldm, a.ln_unbiased, a.ln_eps = int(ln.get("ldm", 0)), int(ln["unbiased"]), float(ln["eps"])
+    if lnf is not None:
+        a.lnf_y, a.lnf_m = _p(lnf["y"]), _p(lnf.get("m"))
+        a.ln_ldm, a.ln_unbiased, a.ln_eps = int(lnf.get("ldm", 0)), int(lnf["unbiased"]), float(lnf["eps"])
     return a
 
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
-         ln=None):
+         ln=None, lnf=None):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
-    dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so."""
-    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln)
+    dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.
+    lnf = dict(y, m, ldm, eps, unbiased): also write y = LN(result + m), the consumer block's normalised input -- only where
+    conv_lnfwd_supported(g, dtype) says so."""
+    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf)
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
@@ -54,6 +59,12 @@ def conv_patch_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
     return bool(_lib.load().c2w_conv_patch_supported(ctypes.byref(a), dtype))
+
+
+def conv_lnfwd_supported(g: dict, dtype: int) -> bool:
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    return bool(_lib.load().c2w_conv_lnfwd_supported(ctypes.byref(a), dtype))
 
 
 def conv_lnbwd_supported(g: dict, dtype: int) -> bool:

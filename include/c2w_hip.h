@@ -63,11 +63,20 @@ typedef struct C2wConvArgs {
     int32_t ln_unbiased;
     float ln_eps;
     int32_t ln_pad_;
+    /* Optional fused LayerNorm FORWARD of the consumer (see c2w_conv_lnfwd_supported): with lnf_y != NULL the kernel also
+     * writes lnf_y = LN_C(y + lnf_m[b]) -- c2w_ln_forward(x = y as stored, m = lnf_m, ldm = ln_ldm, eps = ln_eps,
+     * unbiased = ln_unbiased) -- i.e. the next residual block's normalised input (model/nn.py:28,154) leaves the conv that
+     * produced the block input, without a separate pass over it. */
+    void* lnf_y;        /* [B*Hout*Wout][ldy] or NULL */
+    const float* lnf_m; /* [B][ln_ldm] fp32 modulation rows of the CONSUMER block, or NULL (plain LayerNorm) */
 } C2wConvArgs;
 
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
  * by 8 x 16-pixel tiles), 0 when it takes the general gather kernels. */
 int c2w_conv_patch_supported(const C2wConvArgs* args, int dtype);
+/* 1 when c2w_conv_forward can also emit the consumer's LayerNorm (lnf_y): same shape conditions as the backward fusion,
+ * residual allowed. */
+int c2w_conv_lnfwd_supported(const C2wConvArgs* args, int dtype);
 /* 1 when c2w_conv_forward can run args with the fused LayerNorm backward (bf16, Cout == ldy == 128, 3x3 stride-1 on an
  * image the halo-patch kernel tiles, no mul / act / y2), else 0.  Callers fall back to conv + c2w_ln_backward. */
 int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);

@@ -61,7 +61,17 @@ def conv_lnbwd_supported(g, dtype):
     return g["mode"] == CONV_S1 and g["Cout"] == g["ldy"]  # the emulation fuses wherever the semantics are defined
 
 
-def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None):
+def conv_lnfwd_supported(g, dtype):
+    return g["mode"] == CONV_S1 and g["Cout"] == g["ldy"]
+
+
+def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None):
+    if lnf is not None:  # second output: LN of the stored result (+ the consumer's modulation)
+        assert ln is None and mul is None and y2 is None and act == ACT_NONE
+        conv(x, w, bias, y, g, dtype, res=res)
+        npix = g["B"] * g["Hout"] * g["Wout"]
+        ln_forward(y, lnf.get("m"), lnf["y"], npix, g["Hout"] * g["Wout"], g["Cout"], lnf.get("ldm", 0), lnf["eps"], lnf["unbiased"], dtype)
+        return
     if ln is not None:  # y = res + dLN(conv(x); ln.x + ln.m), the conv result rounded to the storage type in between
         assert mul is None and y2 is None and act == ACT_NONE
         tmp = torch.zeros_like(y)

@@ -98,6 +98,32 @@ def test_conv_forward(case, dt, naive):
 
 
 @pytest.mark.parametrize("unbiased", [True, False])
+@pytest.mark.parametrize("B,H,W,Cin,per_sample,use_res", [(2, 32, 48, 128, True, True), (3, 8, 16, 192, True, False), (1, 16, 32, 64, False, True)])
+def test_conv_with_fused_ln_forward_output(B, H, W, Cin, per_sample, use_res, unbiased):
+    """Second output of the conv epilogue: the consumer's LayerNorm input LN(y + m) (C2wConvArgs.lnf_*), against conv
+    followed by ln_forward on the stored result."""
+    dt, C = BF16, 128
+    g = geom(B, H, W, Cin, H, W, C, C, C, ops.CONV_S1)
+    assert ops.conv_lnfwd_supported(g, dt) and not ops.conv_lnfwd_supported(g, F32)
+    npix = B * H * W
+    x = rnd((npix, Cin), dt, 1)
+    w = rnd((C, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd((C,), F32, 3)
+    res = rnd((npix, C), dt, 4) if use_res else None
+    m = rnd((B if per_sample else 1, C + 64), F32, 5)
+    ldm = C + 64 if per_sample else 0
+    y, hn = (torch.full((npix, C), 7.0, dtype=TD[dt], device=dev()) for _ in range(2))
+    y_ref, hn_ref = y.clone(), hn.clone()
+    for mm in (m.view(-1)[32:], None):
+        lnf = dict(m=mm, ldm=ldm if mm is not None else 0, eps=1e-5, unbiased=unbiased)
+        ops.conv(x, w, bias, y, g, dt, res=res, lnf=dict(lnf, y=hn))
+        E.conv(x, w, bias, y_ref, g, dt, res=res, lnf=dict(lnf, y=hn_ref))
+        torch.cuda.synchronize()
+        close(y, y_ref, dt, "conv output next to the fused LN")
+        close(hn, hn_ref, dt, "fused LN forward output")
+
+
+@pytest.mark.parametrize("unbiased", [True, False])
 @pytest.mark.parametrize("B,H,W,Cin,per_sample", [(2, 32, 48, 128, True), (3, 16, 16, 192, True), (1, 16, 32, 64, False)])
 def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased):
     """The input-gradient conv of a res-block's first conv with LayerNorm's backward in its epilogue
