@@ -54,6 +54,7 @@ _PROTOS = {
     "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],
     "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
     "c2w_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_weight_transpose_batched": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "c2w_adamw_ema": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
                       c_float, c_int, c_float, c_float, c_void_p],
     "c2w_ema_update": [c_void_p, c_void_p, c_longlong, c_float, c_void_p],

@@ -516,6 +516,35 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
+// The same for every conv of the network in ONE launch: desc[j] = {w_off, out_off, R, NT, K, ldk, ldr, flip} (offsets in
+// elements into `flat` / `out`); blockIdx.y = conv, blockIdx.x strides over its 32 x 32 x tap tiles.
+template <typename TO>
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const float* __restrict__ flat, TO* __restrict__ outb,
+                                                                       const long long* __restrict__ desc) {
+    __shared__ float tile[32][33];
+    const long long* d = desc + (size_t)blockIdx.y * 8;
+    const float* w = flat + d[0];
+    TO* out = outb + d[1];
+    const int R = (int)d[2], NT = (int)d[3], K = (int)d[4], ldk = (int)d[5], ldr = (int)d[6], flip = (int)d[7];
+    const int nk = (K + 31) / 32, nr = (R + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = blockIdx.x; t < nk * nr * NT; t += gridDim.x) {
+        const int tap = t / (nk * nr), rem = t - tap * nk * nr;
+        const int r0 = (rem / nk) * 32, k0 = (rem - (rem / nk) * nk) * 32;
+        const int otap = flip ? NT - 1 - tap : tap;
+        for (int i = ty; i < 32; i += 8) {
+            const int r = r0 + i, k = k0 + tx;
+            tile[i][tx] = (r < R && k < K) ? w[((size_t)r * NT + tap) * ldk + k] : 0.f;
+        }
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int k = k0 + i, r = r0 + tx;
+            if (k < K && r < R) Elem<TO>::st(out + ((size_t)k * NT + otap) * ldr + r, tile[tx][i]);
+        }
+        __syncthreads();
+    }
+}
+
 // Fused AdamW (torch.optim.AdamW, train.py:176-181) + EMA (src/thor/ema.py:23-27) + low-precision shadow refresh.
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ shadow,
@@ -687,6 +716,13 @@ extern "C" int c2w_weight_transpose(const float* w, void* out, int R, int NT, in
     if (!w || !out || R <= 0 || NT <= 0 || K <= 0 || ldk < K || ldr < R) return C2W_ERR_BAD_SHAPE;
     dim3 grid((K + 31) / 32, (R + 31) / 32, NT);
     DISPATCH_T(dtype, (weight_transpose_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(w, (T*)out, R, NT, K, ldk, ldr, flip)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_weight_transpose_batched(const float* flat, void* out, const long long* desc, int nconv, int dtype, void* stream) {
+    if (!flat || !out || !desc || nconv <= 0) return C2W_ERR_BAD_ARG;
+    dim3 grid(256, nconv);
+    DISPATCH_T(dtype, (weight_transpose_batched_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(flat, (T*)out, desc)));
     return (int)hipGetLastError();
 }
 

@@ -183,6 +183,7 @@ class Engine:
         self.dg: Dict[int, torch.Tensor] = {}
         self.dg_lin: Optional[torch.Tensor] = None
         self._dg_ver: Dict[object, int] = {}
+        self._dg_desc: Dict[object, tuple] = {}
         self._manual_ver = 0
         self.attach(net)
 
@@ -210,6 +211,7 @@ class Engine:
         self.dg_lin = None
         self._shadow_ver = -1
         self._dg_ver.clear()
+        self._dg_desc.clear()
 
     def is_attached(self, net) -> bool:
         if self.flat is None:
@@ -269,10 +271,13 @@ class Engine:
                 self.dg[dt] = torch.zeros(max(lay.dg_numel, 1), dtype=TORCH_DTYPE[dt], device=self.flat.device)
             buf, d = self.dg[dt], dt
         if self._dg_ver.get(key, -1) != self._version():
-            for r in lay.convs.values():
-                if r.dg_off < 0 or r.lin != rec.lin:
-                    continue
-                ops.weight_transpose(self.flat[r.w_off:], buf[r.dg_off:], r.rows, r.taps, r.cin, r.kstride, r.dg_ld, r.flip, d)
+            if key not in self._dg_desc:  # one launch for all matrices of the group: descriptor table built once
+                recs = [r for r in lay.convs.values() if r.dg_off >= 0 and r.lin == rec.lin]
+                tab = [v for r in recs for v in (r.w_off, r.dg_off, r.rows, r.taps, r.cin, r.kstride, r.dg_ld, int(bool(r.flip)))]
+                self._dg_desc[key] = (torch.tensor(tab, dtype=torch.int64, device=self.flat.device), len(recs))
+            desc, n = self._dg_desc[key]
+            if n:
+                ops.weight_transpose_batched(self.flat, buf, desc, n, d)
             self._dg_ver[key] = self._version()
         return buf[rec.dg_off:]
 

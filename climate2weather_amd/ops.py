@@ -138,6 +138,10 @@ def weight_transpose(w, out, R, NT, K, ldk, ldr, flip, dtype):
     check(_lib.load().c2w_weight_transpose(_p(w), _p(out), R, NT, K, ldk, ldr, int(flip), dtype, _stream()), "c2w_weight_transpose")
 
 
+def weight_transpose_batched(flat, out, desc, nconv, dtype):
+    check(_lib.load().c2w_weight_transpose_batched(_p(flat), _p(out), _p(desc), nconv, dtype, _stream()), "c2w_weight_transpose_batched")
+
+
 def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale):
     check(_lib.load().c2w_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(shadow), n, lr, beta1, beta2, eps, weight_decay, step,
                                     ema_rate, grad_scale, _stream()), "c2w_adamw_ema")

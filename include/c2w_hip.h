@@ -129,6 +129,9 @@ int c2w_cast_f32(const float* in, void* out, long long n, int dtype, void* strea
  * input-gradient convolution (dgrad = the same implicit GEMM over dy with these weights). */
 int c2w_weight_transpose(const float* w, void* out, int R, int NT, int K, int ldk, int ldr, int flip, int dtype,
                          void* stream);
+/* the same for nconv weight matrices in one launch: desc (device memory) holds 8 int64 per matrix
+ * {w_off, out_off, R, NT, K, ldk, ldr, flip}, offsets in elements into flat / out */
+int c2w_weight_transpose_batched(const float* flat, void* out, const long long* desc, int nconv, int dtype, void* stream);
 /* fused torch.optim.AdamW step (train.py:176-181) + EMA (src/thor/ema.py:23-27) + bf16 shadow refresh over a flat
  * parameter buffer; ema / shadow_bf16 may be NULL; g is multiplied by grad_scale first. */
 int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr,

@@ -226,6 +226,12 @@ def weight_transpose(w, out, R, NT, K, ldk, ldr, flip, dtype):
     O[:] = Wm.permute(2, 1, 0).to(TD[dtype])
 
 
+def weight_transpose_batched(flat, out, desc, nconv, dtype):
+    for j in range(nconv):
+        w_off, o_off, R, NT, K, ldk, ldr, flip = (int(v) for v in desc[j * 8: j * 8 + 8])
+        weight_transpose(flat.reshape(-1)[w_off:], out.reshape(-1)[o_off:], R, NT, K, ldk, ldr, flip, dtype)
+
+
 def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale):
     P, G, M, V = (a.reshape(-1)[:n] for a in (p, g, m, v))
     gi = G * grad_scale

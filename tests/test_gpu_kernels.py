@@ -224,6 +224,23 @@ def test_layernorm_fwd_bwd(shape, dt):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+def test_weight_transpose_batched(dt):
+    """all input-gradient operands of a network in one launch == one launch per matrix"""
+    specs = [(64, 9, 40, 64, 72, 1), (128, 1, 128, 128, 128, 0), (33, 9, 64, 64, 40, 1)]  # (R, NT, K, ldk, ldr, flip)
+    flat = rnd((200000,), F32, 1)
+    out = torch.zeros(400000, dtype=TD[dt], device=dev())
+    out_ref = out.clone()
+    desc, w_off, o_off = [], 0, 0
+    for R, NT, K, ldk, ldr, flip in specs:
+        desc += [w_off, o_off, R, NT, K, ldk, ldr, flip]
+        ops.weight_transpose(flat[w_off:], out_ref[o_off:], R, NT, K, ldk, ldr, flip, dt)
+        w_off += R * NT * ldk
+        o_off += K * NT * ldr
+    ops.weight_transpose_batched(flat, out, torch.tensor(desc, dtype=torch.int64, device=dev()), len(specs), dt)
+    assert torch.equal(out, out_ref)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 def test_upsample2(dt):
     B, H, W, C = 3, 5, 7, 64
     x = rnd((B * H * W, C), dt, 1)
