@@ -305,8 +305,13 @@ struct EpiStore {
                     if (p.mul != nullptr) {
                         float gm[PER16];
                         unpack16<T>(EARLY ? mm[EARLY ? g0 + i : 0] : m2[i], gm);
+                        if (p.mulmode == C2W_MUL_DSILU) {  // wave-uniform branch: the plain multiplier pays no exp/rcp
 #pragma unroll
-                        for (int e = 0; e < PER16; ++e) f[e] *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(gm[e]) : gm[e];
+                            for (int e = 0; e < PER16; ++e) f[e] *= dsilu_f(gm[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < PER16; ++e) f[e] *= gm[e];
+                        }
                     }
                     if (p.res != nullptr) {
                         float gr[PER16];
@@ -316,7 +321,20 @@ struct EpiStore {
                     }
                     v[i] = pack16<T>(f);
                 }
-                if (o >= 0) {
+                if (p.act == C2W_ACT_SILU_PAIR && p.y2 != nullptr) {  // y = silu(a), y2 = silu'(a): one exp/rcp pair serves both
+                    float a_[PER16], h_[PER16], d_[PER16];
+                    unpack16<T>(v[i], a_);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) {
+                        const float sg = sigmoid_f(a_[e]);
+                        h_[e] = a_[e] * sg;
+                        d_[e] = sg + h_[e] * (1.0f - sg);
+                    }
+                    if (o >= 0) {
+                        *(u32x4_t*)((char*)p.y + o) = pack16<T>(h_);
+                        *(u32x4_t*)((char*)p.y2 + o) = pack16<T>(d_);
+                    }
+                } else if (o >= 0) {
                     *(u32x4_t*)((char*)p.y + o) = v[i];
                     if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
                         float f2[PER16];

@@ -265,6 +265,13 @@ __global__ void conv_naive_kernel(const C2wConvArgs p) {
             acc *= (p.mulmode == C2W_MUL_DSILU) ? dsilu_f(g) : g;
         }
         if (p.res) acc += Elem<T>::ld((const T*)p.res + off);
+        if (p.act == C2W_ACT_SILU_PAIR && p.y2) {
+            Elem<T>::st((T*)p.y + off, acc);
+            const float a_ = Elem<T>::ld((const T*)p.y + off);  // as stored
+            Elem<T>::st((T*)p.y + off, silu_f(a_));
+            Elem<T>::st((T*)p.y2 + off, dsilu_f(a_));
+            continue;
+        }
         Elem<T>::st((T*)p.y + off, acc);
         if (p.y2) Elem<T>::st((T*)p.y2 + off, silu_f(Elem<T>::ld((const T*)p.y + off)));
     }

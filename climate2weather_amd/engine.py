@@ -16,6 +16,8 @@ Everything runs on torch's current stream; torch is the allocator, nothing else.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -23,7 +25,7 @@ import torch
 
 from . import ops
 from .nn import BlockSpec, LevelSpec
-from .ops import (ACT_NONE, ACT_SILU, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F32, MUL_DSILU, TORCH_DTYPE)
+from .ops import (ACT_NONE, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F32, MUL_DSILU, MUL_PLAIN, TORCH_DTYPE)
 
 LN_EPS = 1e-5
 ALIGN = 64  # elements; keeps every region 256-B aligned in fp32 and 128-B aligned in the bf16 shadow
@@ -391,14 +393,14 @@ class Engine:
                 return y, g, rec, hn
             return y, g, rec
 
-        def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None, ln=None):
+        def dgrad(rec, gy, Hi, Wi, Ho, Wo, mode, ld_out, mul=None, res=None, ln=None, mulmode=MUL_DSILU):
             """input gradient = implicit GEMM over gy with the transposed (and flipped) weights; (Hi,Wi) = gy's grid.
             ``ln``: LayerNorm-backward arguments to fuse into the epilogue; returns None when the kernel cannot fuse them."""
             g = self._geom(B, Hi, Wi, rec.dg_ld, Ho, Wo, ld_out, ld_out, rec.cin, mode)
             if ln is not None and not ops.conv_lnbwd_supported(g, dt):
                 return None
             dx = torch.empty((B * Ho * Wo, ld_out), dtype=T, device=dev)
-            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=MUL_DSILU, ln=ln)
+            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=mulmode, ln=ln)
             return dx
 
         def res_block(b: BlockSpec, xin, Hc, Wc, h0=None, want_ln=None):
@@ -411,11 +413,15 @@ class Engine:
             if h0 is None:
                 h0 = torch.empty((npix, Cc), dtype=T, device=dev)
                 ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
-            # training keeps the pre-activation (for silu') and the activation: both come out of the conv's epilogue
-            h1 = torch.empty((npix, Cc), dtype=T, device=dev) if train else None
-            a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE if train else ACT_SILU, y2=h1)
-            if not train:
-                h1 = a1
+            # training: conv1's epilogue writes silu(a) for the next conv and silu'(a) for the backward pass; the pre-activation
+            # itself is never stored
+            d1 = torch.empty((npix, Cc), dtype=T, device=dev) if train else None
+            mulmode = MUL_PLAIN
+            if train and os.environ.get("C2W_KEEP_PREACT"):  # diagnostic A/B: keep a and silu(a), evaluate silu'(a) in the backward pass
+                a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE, y2=d1)
+                h1, d1, mulmode = d1, a1, MUL_DSILU
+            else:
+                h1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_SILU_PAIR if train else ACT_SILU, y2=d1)
             if want_ln is not None:
                 out, g2, r2, hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin, want_ln=want_ln)
             else:
@@ -423,7 +429,7 @@ class Engine:
             if train:
                 def bw(gy):
                     ops.conv_wgrad(h1, gy, self._gw(r2), g2, dt, dbias=self._gb(r2))
-                    da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=a1)
+                    da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=d1, mulmode=mulmode)
                     ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt, dbias=self._gb(r1))
                     tape.done(r1.w_off)
                     dm = dm_all.view(-1)[b.mod_offset:]

@@ -33,7 +33,10 @@ enum {
     C2W_CONV_UP = 3,  /* Upsample(nearest,x2) -> Conv2d 3x3: model/nn.py:184-189, upsample folded into the gather */
     C2W_CONV_TS2 = 4  /* input-gradient of C2W_CONV_S2 (x := dy, y := dx) */
 };
-enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1 };
+/* C2W_ACT_SILU_PAIR (training): with a = the conv result as stored, y = silu(a) and y2 = silu'(a) -- the activation the next
+ * conv reads and the factor the backward pass multiplies by (model/nn.py:156 forward/backward), so the pre-activation itself
+ * is never written and the backward epilogue needs no transcendental. */
+enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1, C2W_ACT_SILU_PAIR = 2 };
 enum { C2W_MUL_PLAIN = 0, C2W_MUL_DSILU = 1 };
 
 /* y[q][co] = act( sum_{tap,ci} w[co][tap][ci] * x[src(q,tap)][ci] + bias[co] ) (* mul' ) (+ res)

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_SILU_PAIR = 0, 1, 2
 MUL_PLAIN, MUL_DSILU = 0, 1
 TD = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
 
@@ -101,6 +101,11 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
         out = out * (_dsilu(mm) if mulmode == MUL_DSILU else mm)
     if res is not None:
         out = out + _rows(res, npix, ldy)[:, :Cout].float()
+    if act == ACT_SILU_PAIR:  # y = silu(a), y2 = silu'(a) with a = the result rounded to the storage type
+        a_ = out.to(T).float()
+        _rows(y, npix, ldy)[:, :Cout] = F.silu(a_).to(T)
+        _rows(y2, npix, ldy)[:, :Cout] = _dsilu(a_).to(T)
+        return
     _rows(y, npix, ldy)[:, :Cout] = out.to(T)
     if y2 is not None:
         _rows(y2, npix, ldy)[:, :Cout] = F.silu(out.to(T).float()).to(T)

@@ -97,6 +97,33 @@ def test_conv_forward(case, dt, naive):
             close(y2, y2_ref, dt, f"conv second output mode={mode} naive={naive}")
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("naive", [0, 1, 2])
+@pytest.mark.parametrize("case", [(ops.CONV_S1, 2, 16, 16, 64, 128, 128, 128), (ops.CONV_S1, 3, 8, 8, 128, 192, 192, 192),
+                                  (ops.CONV_S1, 1, 24, 32, 64, 128, 128, 128)])
+def test_conv_silu_pair_outputs(case, dt, naive):
+    """training epilogue of a res-block's first conv: y = silu(a), y2 = silu'(a) (C2W_ACT_SILU_PAIR), and the plain
+    multiplier the backward pass then uses"""
+    mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
+    g = geom(B, Hin, Win, Cin, Hin, Win, Cout, ldy, wrows, mode)
+    x = rnd((B * Hin * Win, Cin), dt, 1)
+    w = rnd((wrows, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd((wrows,), F32, 3)
+    y, y2 = (torch.full((B * Hin * Win, ldy), 7.0, dtype=TD[dt], device=dev()) for _ in range(2))
+    y_ref, y2_ref = y.clone(), y2.clone()
+    ops.conv(x, w, bias, y, g, dt, act=ops.ACT_SILU_PAIR, y2=y2, naive=naive)
+    E.conv(x, w, bias, y_ref, g, dt, act=ops.ACT_SILU_PAIR, y2=y2_ref)
+    torch.cuda.synchronize()
+    close(y, y_ref, dt, "silu output")
+    close(y2, y2_ref, dt, "silu' output")
+    dx, dx_ref = torch.empty_like(y), torch.empty_like(y)
+    wT = rnd((Cout, 9, Cout), dt, 4, scale=1.0 / math.sqrt(9 * Cout))
+    gd = geom(B, Hin, Win, ldy, Hin, Win, Cout, ldy, Cout, mode)
+    ops.conv(y, wT, None, dx, gd, dt, mul=y2, mulmode=ops.MUL_PLAIN, naive=naive)
+    E.conv(y, wT, None, dx_ref, gd, dt, mul=y2, mulmode=ops.MUL_PLAIN)
+    close(dx, dx_ref, dt, "plain multiplier epilogue")
+
+
 @pytest.mark.parametrize("unbiased", [True, False])
 @pytest.mark.parametrize("B,H,W,Cin,per_sample,use_res", [(2, 32, 48, 128, True, True), (3, 8, 16, 192, True, False), (1, 16, 32, 64, False, True)])
 def test_conv_with_fused_ln_forward_output(B, H, W, Cin, per_sample, use_res, unbiased):
