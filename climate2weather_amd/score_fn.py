@@ -151,6 +151,8 @@ class _WindowScore(AbstractScoreFunction):
         if lay.in_channels != w * F:
             raise ValueError(f"network expects {lay.in_channels} channels, window gives {w * F}")
         bs = self.batch_size or nwin
+        if self.use_graphs and xd.is_cuda and src_dev == self.device:
+            return self._score_graphed(xd, t, eng, dt, lay, k, w, nwin, bs)
         eps = torch.empty_like(xd)
         td = torch.as_tensor(t).to(self.device)
         for i0 in range(0, nwin, bs):
@@ -160,6 +162,46 @@ class _WindowScore(AbstractScoreFunction):
             y = eng.forward(None, td, dt, x_nhwc=xin, shape=(nw, w * F, H, W), nhwc_out=True)
             ops.window_scatter(y, eps, nw, F, H * W, k, i0, nwin, lay.cout_pad, dt)
         return eps if src_dev == self.device else eps.to(src_dev)
+
+    # hipGraph replay of the launch sequence (BASELINE.json configs[4]: "hipGraph-captured sampler step").  A score evaluation
+    # is ~200 short launches per window batch; at the shipped trajectory lengths (37 / 109 windows) the host-side launch path,
+    # not the GPU, sets the step time.  Everything the kernels read is at fixed addresses: the trajectory tensor the sampler
+    # updates in place, a persistent eps buffer and a one-element time buffer that is overwritten before each replay.
+    use_graphs = False
+
+    def _score_graphed(self, xd, t, eng, dt, lay, k, w, nwin, bs):
+        L, F, H, W = xd.shape
+        key = (xd.data_ptr(), L, F, H, W, bs, dt, eng._version())
+        st = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        if st is None:
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            self._graphs.clear()  # one live trajectory at a time: a new tensor / new weights invalidate the old captures
+            eps = torch.empty_like(xd)
+            td = torch.zeros(1, dtype=torch.float32, device=self.device)
+            td.fill_(float(t))
+
+            def run(i0, nw):
+                xin = torch.empty((nw * H * W, lay.cin_pad), dtype=TORCH_DTYPE[dt], device=self.device)
+                ops.window_gather(xd, xin, nw, F, H * W, k, i0, lay.cin_pad, dt)
+                y = eng.forward(None, td, dt, x_nhwc=xin, shape=(nw, w * F, H, W), nhwc_out=True)
+                ops.window_scatter(y, eps, nw, F, H * W, k, i0, nwin, lay.cout_pad, dt)
+
+            batches = [(i0, min(bs, nwin - i0)) for i0 in range(0, nwin, bs)]
+            for i0, nw in batches[:1] + batches[-1:]:  # eager once per distinct batch size: lazy kernel attributes / weight casts
+                run(i0, nw)
+            torch.cuda.synchronize()
+            graphs = []
+            for i0, nw in batches:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run(i0, nw)
+                graphs.append(g)
+            st = self._graphs[key] = dict(eps=eps, td=td, graphs=graphs)
+        st["td"].fill_(float(t))
+        for g in st["graphs"]:
+            g.replay()
+        return st["eps"]
 
     def _score_generic(self, x, t):
         win = self.unfold(x)

@@ -301,3 +301,24 @@ def test_quantile_normalizer_kernel_and_round_trip_at_full_size():
         assert torch.allclose(y[:5].cpu(), oh.normalize(x[:5], q, mode), rtol=1e-5, atol=1e-5), mode
         assert torch.allclose(qn.unnormalize(xg)[:5].cpu(), oh.unnormalize(x[:5], q, mode), rtol=1e-5, atol=1e-5), mode
         assert torch.allclose(qn.unnormalize(y), xg, rtol=1e-5, atol=1e-4), mode  # size-independent round trip, full sampler shape
+
+
+def test_graph_replayed_score_function_equals_eager(golden_dir):
+    """hipGraph capture of the score evaluation (window gather -> network -> fold), replayed every sampler step: identical
+    trajectories to the eager launches and to the golden end point."""
+    s = _golden(golden_dir, "sampler.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    dev = torch.device("cuda", 0)
+    outs = []
+    for graphs in (False, True):
+        sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=dev, noise_process=pipe)  # 7 windows: batches of 4 + 3
+        sf.condition_on(A=PoolStrideOperator(8, 2), y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=float(s["gamma"]),
+                        exact_grad=False)
+        sf.use_graphs = graphs
+        outs.append(pipe.sample(sf, torch.from_numpy(s["cond_c0.noise"]), steps=4, corrections=0, tau=0.5, device=dev, show_progressbar=False))
+        if graphs:
+            assert len(sf._graphs) == 1 and len(next(iter(sf._graphs.values()))["graphs"]) == 2
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.from_numpy(s["cond_c0.x"])
+    assert (outs[1].cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()

@@ -1,0 +1,35 @@
+"""Sampler throughput at the reference's shipped trajectory lengths (exp/configs: L = 49 / 121, F = 4, k = 6, 128x128):
+window-forwards/s and sampler steps/s of the device-resident predictor loop, eager launches vs hipGraph replay."""
+import argparse, contextlib, io, os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from climate2weather_amd.pipelines import SDAPipeline
+from climate2weather_amd.score import ScoreUNet
+from climate2weather_amd.score_fn import BatchedScoreFunction
+
+p = argparse.ArgumentParser()
+p.add_argument("--lengths", default="49,121")
+p.add_argument("--steps", type=int, default=16)
+p.add_argument("--batch", type=int, default=128)
+p.add_argument("--graph", type=int, default=0)
+a = p.parse_args()
+dev = torch.device("cuda:0")
+CFG = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3, padding_mode="zeros", attention_levels=[4])
+torch.manual_seed(0)
+net = ScoreUNet(channels=52, spatial=2, activation=torch.nn.SiLU, **CFG).to(dev).eval()
+net.precision = "bf16"
+pipe = SDAPipeline()
+for L in [int(v) for v in a.lengths.split(",")]:
+    sf = BatchedScoreFunction(net, markov_order=6, batch_size=a.batch, device=dev, noise_process=pipe)
+    if a.graph:
+        sf.use_graphs = True
+    noise = torch.randn(L, 4, 128, 128, device=dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        pipe.sample(sf, noise, steps=2, show_progressbar=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.sample(sf, noise, steps=a.steps, show_progressbar=False)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nwin = L - 12
+    print(f"L={L} windows={nwin} graph={a.graph}: {a.steps / dt:8.2f} sampler steps/s  {nwin * a.steps / dt:9.1f} window-forwards/s  {1e3 * dt / a.steps:7.2f} ms/step", flush=True)
