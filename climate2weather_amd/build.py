@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libc2w_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "wgrad.hip", "wgrad_patch.hip", "pointwise.hip", "attention.hip", "attention_mfma.hip",
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch3.hip", "wgrad.hip", "wgrad_patch.hip", "pointwise.hip", "attention.hip", "attention_mfma.hip",
            "sampler.hip"]
 
 

@@ -478,6 +478,7 @@ bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // images that 8 x 16-pixe
 }
 
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {
+    if (c2w_conv_patch3_wanted(a, dtype)) return c2w_conv_patch3(a, st);
     if (dtype == C2W_DTYPE_F32) return launch<float>(a, st);
     if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, st);
     return C2W_ERR_BAD_ARG;

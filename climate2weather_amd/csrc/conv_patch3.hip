@@ -1,0 +1,267 @@
+// Third-generation halo-patch kernel for the bf16 3x3 stride-1 convolutions: 32-channel stages, 16x16 tiles (or 8x16, three per CU).
+//
+// Ablation builds of this kernel (C2W_EXP, 128->128 @128^2, B = 128; 0.73 ms complete): 0.51 ms with the MFMAs removed,
+// 0.42 ms with the fragment reads removed as well, 0.26 ms with the weight LDS-DMA removed too -- the matrix pipes are not
+// the critical path; streaming all 295 KB of weights through LDS for every 128-pixel tile is (4.8 GB of L2 -> LDS per
+// launch, 20 B/cycle/CU).  Three workgroups per CU on 8x16 tiles (TR = 8: 50 KB LDS, 168 VGPRs) therefore measured no
+// faster than conv_patch_half_kernel; doubling the pixels per weight byte does:
+//   * TR = 16: a workgroup owns 16x16 pixels x 128 output channels, 4 waves x (64 co x 128 px) = 128 accumulator VGPRs,
+//     0.375 fragment reads per MFMA instead of 0.5, halo overhead 1.27 instead of 1.41, half the weight bytes per pixel;
+//   * the patch row pitch is 20 pixels instead of 24 (18 x 20 x 128 B = 46,080 B; pieces run through the flattened pixel
+//     index, 45 LDS-DMA pieces of 1 KiB);
+//   * a stage is one tap x HALF a K chunk (32 channels): the weight ring is 3 x 8 KiB ([128 co][64 B] rows, XOR-swizzled
+//     by (row >> 2) & 3 on the source address so the 16 rows of a fragment read cover all 64 banks); 70.7 KB of LDS and
+//     247 VGPRs => two workgroups per CU, one barrier per 32 MFMAs per wave.
+// MFMA shape and the epilogue (conv_epilogue.h: bias / SiLU / pair / multiplier / residual / fused LayerNorm forward and
+// backward, in two passes of 8 tile rows) are those of conv_patch_half_kernel; A = weights, B = pixels.
+// Lesson kept in the code below: nothing may spill -- scratch loads return out of order with the LDS-DMA loads and break the
+// counted vmcnt waits (seen as wrong weight rows at chunk boundaries with 40 spilled registers).
+#include <cstdlib>
+
+#include "conv_epilogue.h"
+
+#ifndef C2W_EXP
+#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA
+#endif             // in the loop, 32 no epilogue (accumulators reduced to one store per lane)
+
+namespace {
+
+constexpr int T3_NTHR = 256;
+constexpr int T3_PW = 20;                     // patch row pitch in pixels (18 used)
+constexpr int T3_WBYTES = 128 * 64;           // one stage of weights: 128 co x 32 ci
+constexpr int T3_OS = 128 * 2 + 16;           // epilogue row stride
+
+// TR = tile rows: 8 -> 8x16 pixels, three workgroups per CU; 16 -> 16x16 pixels (wave tile 64 co x 128 px), two per CU and
+// half the weight bytes streamed per output pixel.
+template <int TR> struct T3Cfg {
+    static constexpr int NPIECE = ((TR + 2) * T3_PW + 7) / 8;  // 1 KiB LDS-DMA pieces of 8 pixels: 25 / 45
+    static constexpr int PBYTES = NPIECE * 1024;               // 25,600 / 46,080
+    static constexpr int ROUNDS = (NPIECE + 3) / 4;            // pieces per wave: 7 / 12
+    static constexpr int NB = TR / 8;                          // 64-pixel blocks per wave
+    static constexpr int LDS_LOOP = PBYTES + 3 * T3_WBYTES;    // 50,176 / 70,656
+    static constexpr int LDS_EPI = TR * 16 * T3_OS + 512;      // output tile + LayerNorm column sums
+    static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+    static constexpr int WAVES_PER_SIMD = TR == 8 ? 3 : 2;
+};
+
+template <int N> struct IC3 { static constexpr int value = N; };
+
+// column -> 16-B slot permutation of a patch pixel: consecutive columns AND columns 8 apart land on different slots
+__device__ __forceinline__ uint32_t t3_pswz(int col) { return (uint32_t)((col + (col >> 3)) & 7); }
+
+__device__ __forceinline__ void t3_wait(int outstanding) {
+    if (outstanding >= 2) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <int TR>
+__global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch_t3_kernel(const C2wConvArgs p) {
+    typedef bf16_t T;
+    typedef T3Cfg<TR> CF;
+    constexpr int ESZ = 2;
+    constexpr int NB = CF::NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [patch | W0 | W1 | W2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int nN = (p.Cout + 127) / 128;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hin, W = p.Win;
+    const int tw = W >> 4, tpi = (H / TR) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty * TR, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    // patch pieces (rounds past the end repeat the last piece).  The source offsets are recomputed at every chunk start instead
+    // of living in VGPRs through the loop: anything spilled would come back through scratch loads, which return out of order
+    // with the LDS-DMA loads and break the counted vmcnt waits below (seen: wrong weight rows with 40 spilled registers).
+    auto issue_patch = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < CF::ROUNDS; ++r) {
+            int pc = r * 4 + wid;
+            pc = pc < CF::NPIECE ? pc : CF::NPIECE - 1;
+            const int f = pc * 8 + (lane >> 3);  // flattened patch pixel
+            const int pr = f / T3_PW, px = f - pr * T3_PW;
+            const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18 && pr < TR + 2;
+            const uint32_t cg = (uint32_t)(lane & 7) ^ t3_pswz(px);
+            const uint32_t voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (cg << 4) : C2W_OOB;
+            glds16(rx, smem + pc * 1024, voff, (uint32_t)chunk * 128u);
+        }
+    };
+    // weight stage: 128 rows x 4 slots of 16 B = 2 rounds; lane -> row = (round * 4 + wave) * 16 + lane / 4, slot = lane & 3
+    uint32_t wvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wid) * 16 + (lane >> 2);
+        const uint32_t cg = (uint32_t)(lane & 3) ^ (uint32_t)((row >> 2) & 3);
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (cg << 4);
+    }
+    auto issue_w = [&](int chunk, int tap, int half, int wslot) {
+        if constexpr ((C2W_EXP & 4) != 0) {
+            if (chunk + tap + half > 0) return;
+        }
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * 64 + half * 32) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rw, smem + CF::PBYTES + wslot * T3_WBYTES + (i * 4 + wid) * 1024, wvo[i], so);
+    };
+
+    // fragment read offsets.  A: row = wm*64 + m*16 + li, its swizzle (row >> 2) & 3 = (li >> 2) & 3 does not depend on m, so
+    // A[m] = offA + m * 1024; B: pixel (wn*4*NB + n + kh, li + kw): offB[kw] + (n + kh) * pitch; k-half 1 flips slot bit 2.
+    const uint32_t offA = (uint32_t)(CF::PBYTES + (wm * 64 + li) * 64 + ((lg ^ ((li >> 2) & 3)) << 4));
+    uint32_t offB[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = li + kw;
+        offB[kw] = (uint32_t)((wn * 4 * NB * T3_PW + px) * 128 + (((uint32_t)lg ^ t3_pswz(px)) << 4));
+    }
+
+    f32x4_t acc[NB][4][4];  // [pixel block of 4 rows][co tile][pixel row]
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[j][m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nchunk = p.Cin / 64;
+    const int NS = nchunk * 18;
+
+    float bv[4][4];
+    if constexpr (TR == 16) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);  // two per CU: registers to spare, latency hidden by the loop
+    issue_patch(0);
+    issue_w(0, 0, 0, 0);
+    issue_w(0, 0, 1, 1);
+
+    // stage s = (chunk c, tap, half): weights of stage s live in ring slot s % 3 (18 stages per chunk: slot = (2 tap + half) % 3)
+    auto stage = [&](auto TAPc, auto HALFc, int c) {
+        constexpr int TAP = decltype(TAPc)::value, HALF = decltype(HALFc)::value;
+        constexpr int KH = TAP / 3, KW = TAP % 3, IDX = 2 * TAP + HALF, WS = IDX % 3;
+        const int s = c * 18 + IDX;
+        t3_wait(s + 1 < NS ? 2 : 0);  // everything but the next stage's two weight pieces has landed
+        __builtin_amdgcn_s_barrier();
+        if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+            issue_patch(c);
+            if (s + 2 < NS) issue_w(c, 1, 0, 2);  // stage s + 2 = (c, tap 1, half 0) -> slot (s + 2) % 3 = 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // patch landed (once per chunk: no counting games here)
+            __builtin_amdgcn_s_barrier();
+        } else if (s + 2 < NS) {
+            constexpr int I2 = IDX + 2;
+            if constexpr (I2 < 18) {
+                issue_w(c, I2 / 2, I2 % 2, I2 % 3);
+            } else {
+                issue_w(c + 1, (I2 - 18) / 2, (I2 - 18) % 2, I2 % 3);
+            }
+        }
+        u32x4_t a[4], bq[4 * NB];
+        if constexpr ((C2W_EXP & 2) == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *(const u32x4_t*)(smem + offA + m * 1024 + WS * T3_WBYTES);
+#pragma unroll
+            for (int n = 0; n < 4 * NB; ++n) bq[n] = *(const u32x4_t*)(smem + (offB[KW] ^ (HALF * 64)) + (n + KH) * T3_PW * 128);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = (u32x4_t){offA, (uint32_t)s, 3u, 4u};
+#pragma unroll
+            for (int n = 0; n < 4 * NB; ++n) bq[n] = (u32x4_t){offB[KW], (uint32_t)s, 5u, 6u};
+        }
+#pragma unroll
+        for (int n = 0; n < 4 * NB; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if constexpr ((C2W_EXP & 1) == 0) {
+                    acc[n >> 2][m][n & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[m]),
+                                                                                     __builtin_bit_cast(bf16x8_t, bq[n]), acc[n >> 2][m][n & 3], 0, 0, 0);
+                } else {
+                    asm volatile("" ::"v"(a[m]), "v"(bq[n]));
+                }
+            }
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        stage(IC3<0>{}, IC3<0>{}, c); stage(IC3<0>{}, IC3<1>{}, c); stage(IC3<1>{}, IC3<0>{}, c); stage(IC3<1>{}, IC3<1>{}, c);
+        stage(IC3<2>{}, IC3<0>{}, c); stage(IC3<2>{}, IC3<1>{}, c); stage(IC3<3>{}, IC3<0>{}, c); stage(IC3<3>{}, IC3<1>{}, c);
+        stage(IC3<4>{}, IC3<0>{}, c); stage(IC3<4>{}, IC3<1>{}, c); stage(IC3<5>{}, IC3<0>{}, c); stage(IC3<5>{}, IC3<1>{}, c);
+        stage(IC3<6>{}, IC3<0>{}, c); stage(IC3<6>{}, IC3<1>{}, c); stage(IC3<7>{}, IC3<0>{}, c); stage(IC3<7>{}, IC3<1>{}, c);
+        stage(IC3<8>{}, IC3<0>{}, c); stage(IC3<8>{}, IC3<1>{}, c);
+    }
+
+    if constexpr ((C2W_EXP & 32) != 0) {
+        f32x4_t t = acc[0][0][0];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) t += acc[j][m][n];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678f) ((float*)p.y)[tid] = t[0];
+        return;
+    }
+    // epilogue: the residual / multiplier rows are fetched AFTER the accumulators have left the registers (the half-tile
+    // kernel prefetches them next to live accumulators; that does not fit here) -- the co-resident workgroups cover the
+    // exposed latency.  Output rows go through LDS in blocks of 128 (= 8 tile rows), one EpiStore pass each.
+    if constexpr (TR == 8) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    __syncthreads();
+    char* const O = smem;
+    float* const red = (float*)(smem + TR * 16 * T3_OS);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        epi_acc_to_lds<T>(O, T3_OS, acc[j], bv, p.act, wm * 64, (wn * NB + j) * 64, li, lg);
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+        if (p.ln_x != nullptr && tid < 128) red[tid] = 0.f;
+        EpiStore<T, 128, T3_NTHR> est;
+        est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0 + 8 * h) * W + ow0, W);
+        __syncthreads();
+        const char* const Oh = O + h * 128 * T3_OS;
+        if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid, b, red);
+        else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid, b);
+        else est.finish(p, Oh, T3_OS, tid);
+        if (h + 1 < NB) __syncthreads();  // the LayerNorm column sums are re-zeroed for the next block only after everyone read them
+    }
+}
+
+template <int TR>
+int t3_launch(const C2wConvArgs& a, hipStream_t st) {
+    typedef T3Cfg<TR> CF;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+        attr = true;
+    }
+    const int nN = (a.Cout + 127) / 128;
+    const int nM = a.B * (a.Hin / TR) * (a.Win >> 4);
+    conv_patch_t3_kernel<TR><<<nM * nN, T3_NTHR, CF::LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// The 16x16-tile variant pays off where the launch still fills the chip several times over (measured on MI355X, B = 128:
+// 128->128 @128^2 0.596 vs 0.621 ms, @64^2 0.156 vs 0.166 ms; 384->384 @16^2 with 384 workgroups 0.093 vs 0.079 ms).
+// C2W_CONV_T3 = 0 disables it, = 16 forces it wherever the image is tiled by 16x16.  The 8-row instantiation (three
+// workgroups per CU) measured no faster than conv_patch_half_kernel and is not dispatched.
+bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype) {
+    static const int mode = getenv("C2W_CONV_T3") ? atoi(getenv("C2W_CONV_T3")) : -1;
+    if (dtype != C2W_DTYPE_BF16 || mode == 0 || (a.Hin & 15) != 0 || (a.Win & 15) != 0) return false;
+    const long long wgs = (long long)a.B * (a.Hin >> 4) * (a.Win >> 4) * ((a.Cout + 127) / 128);
+    return mode == 16 || wgs >= 1024;
+}
+
+int c2w_conv_patch3(const C2wConvArgs& a, hipStream_t st) { return t3_launch<16>(a, st); }
