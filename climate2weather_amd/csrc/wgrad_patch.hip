@@ -16,8 +16,16 @@
 //   * the bias gradient rides along as one extra MFMA per co-tile against a vector of ones.
 #include "conv_geom.h"
 
+#ifndef C2W_EXP
+#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA after the
+#endif             // first tile, 32 no epilogue
+
 namespace {
 
+// Measured alternatives (128->128 @128^2, B = 128, this layout 0.62-0.69 ms depending on the box): ablation builds run 0.49 ms
+// with the LDS-DMA after the first tile removed and 0.42 ms with the MFMAs removed; 4-row K tiles in a 4-slot ring (three
+// tiles of prefetch instead of one, same LDS) were SLOWER (0.75 ms; 0.22 vs 0.17 ms at 64^2): twice the barriers and 10 % more
+// halo bytes cost more than the deeper prefetch gave back.
 constexpr int NTHREADS = 512;
 constexpr int KPX = 128;                 // pixels per K tile (8 rows x 16 cols)
 constexpr int ABYTES = KPX * 256;        // dY tile
@@ -150,12 +158,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     for (int t = t0; t < t1; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading the other slot
-        if (t + 1 < t1) issue(t + 1, slot ^ 1);
+        if ((C2W_EXP & 4) == 0 && t + 1 < t1) issue(t + 1, slot ^ 1);
         const char* const S = smem + slot * SLOT;
         if constexpr (BF) {
             typedef __attribute__((ext_vector_type(4))) short s16x4_t;
             typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
             auto tr8 = [&](uint32_t o0, uint32_t o1) {
+                if constexpr ((C2W_EXP & 2) != 0) return (bf16x8_t){(short)o0, (short)o1, (short)t, 3, 4, 5, 6, 7};
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o0));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o1));
                 return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -169,7 +178,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 for (int tp = 0; tp < 9; ++tp) {
                     const bf16x8_t bfr = tr8(offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bfr, acc[tp][m], 0, 0, 0);
+                    for (int m = 0; m < MTW; ++m) {
+                        if constexpr ((C2W_EXP & 1) == 0) {
+                            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bfr, acc[tp][m], 0, 0, 0);
+                        } else {
+                            asm volatile("" ::"v"(a[m]), "v"(bfr));
+                        }
+                    }
                 }
                 if (do_bias) {
                     const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
@@ -197,6 +212,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 
     // ---- epilogue: per tap, tile -> LDS [co][ci] fp32 -> atomics as whole (co, tap) rows of CIB floats
     if (t0 >= t1) return;
+    if constexpr ((C2W_EXP & 32) != 0) {
+        f32x4_t tsum = acc[0][0];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) tsum += acc[tp][m];
+        if (tsum[0] + tsum[1] + tsum[2] + tsum[3] == 12345.678f) p.dw[tid] = tsum[0];
+        return;
+    }
     if (do_bias && li == 0) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
