@@ -24,12 +24,19 @@
 
 namespace {
 
-constexpr int BM = 256;       // pixels per block tile
-constexpr int BN = 128;       // output channels per block tile
-constexpr int NTHREADS = 512;
-constexpr int PBYTES = BM * 128;  // one pixel-tile stage  (32 KiB)
+constexpr int BN = 128;           // output channels per block tile
 constexpr int WBYTES = BN * 128;  // one weight-tile stage (16 KiB)
-constexpr int NSLOT = 3;          // ring depth (3 x 48 KiB = 144 KiB of the CU's 160 KiB LDS)
+constexpr int NSLOT = 3;          // ring depth
+// NW = pixel-side waves of the block: 4 -> 256 pixels x 128 co, 8 waves (3 x 48 KiB of LDS); 2 -> 128 pixels, 4 waves
+// (3 x 32 KiB), used when the larger tile would leave the chip under-filled (8x8 level at B = 128: 128 -> 256 workgroups)
+template <int NW> struct GCfg {
+    static constexpr int BM = 64 * NW;         // pixels per block tile
+    static constexpr int NTHREADS = 128 * NW;
+    static constexpr int PBYTES = BM * 128;    // one pixel-tile stage
+    static constexpr int ROWS_PER_ROUND = NTHREADS / 8;   // tile rows one round of 16-B pieces covers
+    static constexpr int WROUNDS = BN / ROWS_PER_ROUND;   // 2 / 4
+    static constexpr int ROUND_BYTES = NTHREADS * 16;     // 8192 / 4096
+};
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -45,8 +52,10 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvArgs p) {
+template <typename T, int MODE, int NW>
+__global__ __launch_bounds__(GCfg<NW>::NTHREADS, 2) void conv_igemm_kernel(const C2wConvArgs p) {
+    constexpr int BM = GCfg<NW>::BM, NTHREADS = GCfg<NW>::NTHREADS, PBYTES = GCfg<NW>::PBYTES;
+    constexpr int RPR = GCfg<NW>::ROWS_PER_ROUND, WROUNDS = GCfg<NW>::WROUNDS, RB = GCfg<NW>::ROUND_BYTES;
     constexpr int ESZ = sizeof(T);
     constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
     constexpr int CK = 128 / ESZ;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     uint32_t plc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int q = (tid >> 3) + 64 * i;
+        const int q = (tid >> 3) + RPR * i;
         const int Q = tm * BM + q;
         int b, oh, ow;
         row_pixel(Q, b, oh, ow);
@@ -128,10 +137,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
         pyx[i] = (oh << 16) | ow;
         plc[i] = (uint32_t)(((tid & 7) ^ (q & 7)) << 4);
     }
-    uint32_t wvo[2];
+    uint32_t wvo[WROUNDS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 3) + 64 * i;
+    for (int i = 0; i < WROUNDS; ++i) {
+        const int row = (tid >> 3) + RPR * i;
         wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(NT * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
     }
 
@@ -158,12 +167,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
             int ih, iw;
             const bool ok = src_pixel<MODE>(p, pyx[i] >> 16, pyx[i] & 0xffff, kh, kw, ih, iw) && pb[i] >= 0;
             const uint32_t voff = ok ? (uint32_t)(((pb[i] + ih) * p.Win + iw) * p.Cin) * ESZ + plc[i] : C2W_OOB;
-            glds16(rx, pdst + i * 8192, voff, (uint32_t)chunk * 128u);
+            glds16(rx, pdst + i * RB, voff, (uint32_t)chunk * 128u);
         }
         char* const wdst = Wbuf + buf * WBYTES + wid * 1024;
         const uint32_t wso = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(rw, wdst + i * 8192, wvo[i], wso);
+        for (int i = 0; i < WROUNDS; ++i) glds16(rw, wdst + i * RB, wvo[i], wso);
     };
 
     // ---- fragment read offsets (bytes inside a stage buffer); k-half ks toggles bit 6
@@ -193,7 +202,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const C2wConvAr
     for (int s = 0; s < NS; ++s) {
         // each wave issues 6 LDS-DMA loads per stage: all but the youngest 6 retired <=> stage s has landed
         if (s + 1 < NS) {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (WROUNDS == 2) {
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -277,6 +290,22 @@ __global__ void conv_naive_kernel(const C2wConvArgs p) {
     }
 }
 
+template <typename T, int MODE, int NW>
+int launch_tile(const C2wConvArgs& a, long long npix, int nN, hipStream_t st) {
+    typedef GCfg<NW> CF;
+    constexpr int ESZ = sizeof(T);
+    constexpr int lds_loop = NSLOT * (CF::PBYTES + WBYTES), lds_epi = CF::BM * (BN * ESZ + 16);
+    constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int nM = (int)((npix + CF::BM - 1) / CF::BM);
+    conv_igemm_kernel<T, MODE, NW><<<nM * nN, CF::NTHREADS, lds, st>>>(a);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int MODE>
 int launch_mode(const C2wConvArgs& a, int naive, hipStream_t st) {
     const long long npix = (long long)a.B * a.Hout * a.Wout;
@@ -286,16 +315,11 @@ int launch_mode(const C2wConvArgs& a, int naive, hipStream_t st) {
         conv_naive_kernel<T, MODE><<<grid, 256, 0, st>>>(a);
         return (int)hipGetLastError();
     }
-    constexpr int ESZ = sizeof(T);
-    constexpr int lds = NSLOT * (PBYTES + WBYTES) > BM * (BN * ESZ + 16) ? NSLOT * (PBYTES + WBYTES) : BM * (BN * ESZ + 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    const int nM = (int)((npix + BM - 1) / BM), nN = (a.Cout + BN - 1) / BN;
-    conv_igemm_kernel<T, MODE><<<nM * nN, NTHREADS, lds, st>>>(a);
-    return (int)hipGetLastError();
+    const int nN = (a.Cout + BN - 1) / BN;
+    // 256-pixel tiles unless they would leave CUs idle (fewer workgroups than CUs): then 128-pixel tiles, twice the workgroups
+    static const int force_nw = getenv("C2W_GATHER_NW") ? atoi(getenv("C2W_GATHER_NW")) : 0;
+    const bool small = force_nw ? force_nw == 2 : ((npix + 255) / 256) * nN < 256;
+    return small ? launch_tile<T, MODE, 2>(a, npix, nN, st) : launch_tile<T, MODE, 4>(a, npix, nN, st);
 }
 
 template <typename T>
