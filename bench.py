@@ -164,13 +164,13 @@ def main():
         roof = None
         if k_ms:
             ach = flops_launch / (k_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="conv_patch_half_kernel<bf16> 128->128 @%dx%d (res-block conv fwd + dgrad)" % (a.size, a.size),
+            roof = dict(bound="mfma", kernel="conv_patch_t3_kernel<16> (bf16) 128->128 @%dx%d (res-block conv fwd + dgrad, fused epilogues included)" % (a.size, a.size),
                         achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                         # HBM bytes per launch from the PMC passes of the same kernel and shape (FETCH_SIZE x2 gfx950 correction +
-                        # WRITE_SIZE; profiles/r01c_pmc_patch_kernels_b128.md) -- equal to the algorithmic 537 MB in + 537 MB out
-                        traffic=1.052e9 if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
-                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01c_pmc_patch_kernels_b128.md",
-                        mfma_busy_pmc=0.485, clock_ghz_under_load_pmc=1.81,
+                        # WRITE_SIZE; profiles/r01g_pmc_conv_patch3_b128.md) -- equal to the algorithmic 537 MB in + 537 MB out
+                        traffic=1.064e9 if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
+                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01g_pmc_conv_patch3_b128.md",
+                        mfma_busy_pmc=0.556, clock_ghz_under_load_pmc=1.85,
                         launches_timed=k_n, avg_launch_ms=round(k_ms, 4), flops_per_launch=flops_launch)
         out = dict(metric="UNet denoise steps/sec (train fwd+bwd+allreduce+AdamW+EMA windows/s)", value=round(value, 2), unit="windows/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * elapsed / a.steps, 3), higher_is_better=True,
