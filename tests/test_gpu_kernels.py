@@ -97,6 +97,45 @@ def test_conv_forward(case, dt, naive):
             close(y2, y2_ref, dt, f"conv second output mode={mode} naive={naive}")
 
 
+def test_conv_16x16_tile_kernel_all_epilogues():
+    """Launches with >= 1024 workgroups take conv_patch_t3_kernel<16> (conv_patch3.hip); every epilogue variant of it against the
+    PyTorch restatement at a size that dispatches there (B = 16, 128x128, 128 -> 128: 1024 tiles), 2 K-chunks."""
+    dt, B, H, W, C = BF16, 16, 128, 128, 128
+    g = geom(B, H, W, C, H, W, C, C, C, ops.CONV_S1)
+    npix = B * H * W
+    x = rnd((npix, C), dt, 1)
+    w = rnd((C, 9, C), dt, 2, scale=1.0 / math.sqrt(9 * C))
+    bias = rnd((C,), F32, 3)
+    res = rnd((npix, C), dt, 4)
+    mul = rnd((npix, C), dt, 5)
+    m = rnd((B, C + 64), F32, 6)
+    y, y2 = (torch.full((npix, C), 7.0, dtype=TD[dt], device=dev()) for _ in range(2))
+    y_ref, y2_ref = y.clone(), y2.clone()
+    variants = [dict(bias=bias), dict(bias=bias, act=ops.ACT_SILU), dict(bias=bias, res=res), dict(mul=mul, mulmode=ops.MUL_DSILU, res=res),
+                dict(mul=mul, mulmode=ops.MUL_PLAIN), dict(bias=bias, y2=True), dict(bias=bias, act=ops.ACT_SILU_PAIR, y2=True)]
+    for kw in variants:
+        kw = dict(kw)
+        b = kw.pop("bias", None)
+        two = kw.pop("y2", False)
+        ops.conv(x, w, b, y, g, dt, y2=y2 if two else None, **kw)
+        E.conv(x, w, b, y_ref, g, dt, y2=y2_ref if two else None, **kw)
+        torch.cuda.synchronize()
+        close(y, y_ref, dt, f"16x16 tile kernel {sorted(kw)}")
+        if two:
+            close(y2, y2_ref, dt, f"16x16 tile kernel second output {sorted(kw)}")
+    dm, dm_ref = torch.zeros_like(m), torch.zeros_like(m)
+    ln = dict(x=mul, m=m.view(-1)[32:], ldm=C + 64, eps=1e-5, unbiased=True)
+    ops.conv(x, w, None, y, g, dt, res=res, ln=dict(ln, dm=dm.view(-1)[32:]))
+    E.conv(x, w, None, y_ref, g, dt, res=res, ln=dict(ln, dm=dm_ref.view(-1)[32:]))
+    close(y, y_ref, dt, "16x16 tile kernel, fused LN backward")
+    close(dm, dm_ref, dt, "16x16 tile kernel, fused LN backward dm", tol=1e-2)
+    lnf = dict(m=m.view(-1)[32:], ldm=C + 64, eps=1e-5, unbiased=True)
+    ops.conv(x, w, bias, y, g, dt, res=res, lnf=dict(lnf, y=y2))
+    E.conv(x, w, bias, y_ref, g, dt, res=res, lnf=dict(lnf, y=y2_ref))
+    close(y, y_ref, dt, "16x16 tile kernel next to fused LN forward")
+    close(y2, y2_ref, dt, "16x16 tile kernel, fused LN forward output")
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("naive", [0, 1, 2])
 @pytest.mark.parametrize("case", [(ops.CONV_S1, 2, 16, 16, 64, 128, 128, 128), (ops.CONV_S1, 3, 8, 8, 128, 192, 192, 192),
