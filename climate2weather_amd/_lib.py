@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_ulonglong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C2W_LIB") or os.path.join(HERE, "libc2w_hip.so")  # C2W_LIB: diagnostic builds only
@@ -40,6 +40,7 @@ _PROTOS = {
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_void_p],
+    "c2w_set_workspace": [c_void_p, c_ulonglong],
     "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,
                         c_int, c_void_p],

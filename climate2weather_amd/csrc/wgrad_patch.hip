@@ -14,6 +14,8 @@
 //   * 36 accumulator tiles per wave (bf16: 4 co-tiles x 1 ci-tile x 9 taps); split-K over pixel ranges across
 //     workgroups, partial sums combined with fp32 atomics issued as full 256-B rows (staged through LDS per tap);
 //   * the bias gradient rides along as one extra MFMA per co-tile against a vector of ones.
+#include <algorithm>
+#include <cstdlib>
 #include "conv_geom.h"
 
 #ifndef C2W_EXP
@@ -42,7 +44,12 @@ struct WpArgs {
     float* db;
     int B, H, W, Cin, Cout, ldy;
     int ktiles, ktiles_per_split;
+    float* ws;  // optional workspace [split][tile][tap][COT][CIB] fp32: partial sums by plain stores, reduced by a second launch
 };
+
+// process-wide workspace registered by the host (c2w_set_workspace): one thread per rank, launches on one stream are ordered
+float* g_ws = nullptr;
+size_t g_ws_bytes = 0;
 
 __device__ __forceinline__ uint32_t swzA(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
 __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2)); }
@@ -240,11 +247,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 #pragma unroll
             for (int r = 0; r < 4; ++r) O[((mt0 + m) * 16 + lg * 4 + r) * OS + nt * 16 + li] = acc[tp][m][r];
         __syncthreads();
-        for (int idx = tid; idx < COT * CIB; idx += NTHREADS) {
-            const int row = idx / CIB, col = idx - row * CIB;
-            const int co = co0 + row;
-            if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * 9 + tp) * p.Cin + ci0 + col, O[row * OS + col]);
+        if (p.ws != nullptr) {  // partial sums: coalesced stores, no atomics (75 MB of atomics per launch otherwise)
+            float* const dst = p.ws + (((size_t)split * tilesMN + mn) * 9 + tp) * (COT * CIB);
+            for (int idx = tid; idx < COT * CIB; idx += NTHREADS) dst[idx] = O[(idx / CIB) * OS + (idx % CIB)];
+        } else {
+            for (int idx = tid; idx < COT * CIB; idx += NTHREADS) {
+                const int row = idx / CIB, col = idx - row * CIB;
+                const int co = co0 + row;
+                if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * 9 + tp) * p.Cin + ci0 + col, O[row * OS + col]);
+            }
         }
+    }
+}
+
+// dw[co][tap][ci] += sum over splits of ws[split][tile][tap][row][col]   (one thread per output element, no atomics)
+template <int COT, int CIB>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesMN, int ncib,
+                                                           int Cin, int Cout) {
+    const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_split; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % CIB);
+        size_t r = i / CIB;
+        const int row = (int)(r % COT);
+        r /= COT;
+        const int tp = (int)(r % 9);
+        const int mn = (int)(r / 9);
+        const int tm = mn / ncib, cb = mn - tm * ncib;
+        const int co = tm * COT + row;
+        if (co >= Cout) continue;
+        float acc = 0.f;
+        for (int sidx = 0; sidx < nsplit; ++sidx) acc += ws[(size_t)sidx * per_split + i];
+        dw[((size_t)co * 9 + tp) * Cin + cb * CIB + col] += acc;
     }
 }
 
@@ -267,7 +300,14 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
+    const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
+    p.ws = (g_ws != nullptr && need <= g_ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? g_ws : nullptr;
     wgrad_patch_kernel<T><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
+    if (p.ws != nullptr) {
+        const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
+        const int grid = (int)std::min<size_t>((per_split + 255) / 256, 4096);
+        wgrad_reduce_kernel<COT, CIB><<<grid, 256, 0, st>>>(p.ws, dw, nsplit, tilesMN, a.Cin / CIB, a.Cin, a.Cout);
+    }
     return (int)hipGetLastError();
 }
 
@@ -281,4 +321,12 @@ int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipSt
     if (dtype == C2W_DTYPE_F32) return launch<float>(a, dw, db, st);
     if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, dw, db, st);
     return C2W_ERR_BAD_ARG;
+}
+
+// Scratch memory for the split-K partial sums of the weight-gradient kernels (caller-owned device buffer; NULL / 0 to
+// unregister).  Without it the kernels combine their partial sums with fp32 atomics.
+extern "C" int c2w_set_workspace(void* ptr, unsigned long long bytes) {
+    g_ws = (float*)ptr;
+    g_ws_bytes = (size_t)bytes;
+    return 0;
 }

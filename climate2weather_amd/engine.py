@@ -231,6 +231,8 @@ class Engine:
         a view into it, so optimizers / all-reduce see one contiguous tensor."""
         if self.flat_grad is None:
             self.flat_grad = torch.zeros_like(self.flat)
+            if self.flat.is_cuda:
+                ops.ensure_workspace(self.flat.device)  # split-K partial sums of the weight-gradient kernels
         if bind and net is not None:
             for name, (off, shape, strides) in self.layout.views.items():
                 mod, attr = _resolve(net, name)

@@ -80,6 +80,26 @@ def conv_wgrad(x, dy, dw, g: dict, dtype: int, dbias=None):
     check(_lib.load().c2w_conv_wgrad(ctypes.byref(a), _p(dw), _p(dbias), dtype, _stream()), "c2w_conv_wgrad")
 
 
+_WORKSPACE = {}
+
+
+def ensure_workspace(device, nbytes: int = 96 << 20) -> None:
+    """Register a scratch buffer for the weight-gradient kernels' split-K partial sums (c2w_set_workspace): 96 MB covers
+    every layer of the default network at any batch (75.5 MB per launch, independent of the batch size)."""
+    key = str(device)
+    if key not in _WORKSPACE:
+        buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        _WORKSPACE.clear()  # the library keeps ONE pointer: one device per process
+        _WORKSPACE[key] = buf
+        check(_lib.load().c2w_set_workspace(_p(buf), nbytes), "c2w_set_workspace")
+
+
+def drop_workspace() -> None:
+    """Unregister the scratch buffer (the kernels fall back to fp32 atomics)."""
+    _WORKSPACE.clear()
+    check(_lib.load().c2w_set_workspace(None, 0), "c2w_set_workspace")
+
+
 def ln_forward(x, m, y, npix, HW, C, ldm, eps, unbiased, dtype):
     check(_lib.load().c2w_ln_forward(_p(x), _p(m), _p(y), npix, HW, C, ldm, eps, int(unbiased), dtype, _stream()), "c2w_ln_forward")
 

@@ -95,6 +95,11 @@ int c2w_conv_forward(const C2wConvArgs* args, int dtype, int naive, void* stream
  * dbias (may be NULL): [Cout] fp32, += sum_q dY[q][co] (the bias gradient, from the same pass over dY).
  * Replaces autograd's weight/bias backward of every Conv2d/Conv1d/Linear cited above. */
 int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, float* dbias, int dtype, void* stream);
+/* Optional scratch buffer (caller-owned device memory, fp32) for the split-K partial sums of c2w_conv_wgrad's halo-patch
+ * kernel: with it the workgroups store their partial tiles and a second launch reduces them (75 MB of coalesced stores +
+ * reads per launch instead of 75 MB of fp32 atomics); without it, or if it is too small for a launch, atomics are used.
+ * Process-wide (one rank = one process = one stream of launches); pass NULL, 0 to unregister. */
+int c2w_set_workspace(void* ptr, unsigned long long bytes);
 
 /* y = LN_C(x + m[b]): parameter-free channel LayerNorm (zuko.nn.LayerNorm at model/nn.py:44,154,183) fused with
  * the time-modulation add of model/nn.py:28.  x,y: [npix][C]; m: fp32 rows of C (row b = pixel / HW, stride ldm;

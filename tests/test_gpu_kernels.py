@@ -223,11 +223,17 @@ def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("force_gather", [False, True])
+@pytest.mark.parametrize("force_gather", [False, True, "workspace"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] != ops.CONV_TS2])
 def test_conv_wgrad(case, dt, force_gather, monkeypatch):
     mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
-    if force_gather:
+    if force_gather == "workspace":  # split-K partial sums through the registered scratch buffer instead of atomics
+        if mode != ops.CONV_S1:
+            pytest.skip("only the halo-patch weight-gradient kernel uses the workspace")
+        ops.ensure_workspace(dev())
+    else:
+        ops.drop_workspace()
+    if force_gather is True:
         if mode != ops.CONV_S1:
             pytest.skip("only 3x3 stride-1 has two kernels")
         monkeypatch.setenv("C2W_FORCE_GATHER", "1")  # the general kernel on shapes the halo-patch kernel would take
