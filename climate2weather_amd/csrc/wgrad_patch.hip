@@ -260,24 +260,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     }
 }
 
-// dw[co][tap][ci] += sum over splits of ws[split][tile][tap][row][col]   (one thread per output element, no atomics)
+// dw[co][tap][ci] += sum over splits of ws[split][tile][tap][row][col].  64 float4 columns x 4 split groups per block: every
+// thread streams a quarter of the splits with 16-B loads (8 in flight), the groups meet in LDS, group 0 updates dw (no atomics:
+// one thread per output vector, launches on a stream are ordered).
 template <int COT, int CIB>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesMN, int ncib,
                                                            int Cin, int Cout) {
-    const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_split; i += (size_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % CIB);
-        size_t r = i / CIB;
-        const int row = (int)(r % COT);
-        r /= COT;
-        const int tp = (int)(r % 9);
-        const int mn = (int)(r / 9);
-        const int tm = mn / ncib, cb = mn - tm * ncib;
-        const int co = tm * COT + row;
-        if (co >= Cout) continue;
-        float acc = 0.f;
-        for (int sidx = 0; sidx < nsplit; ++sidx) acc += ws[(size_t)sidx * per_split + i];
-        dw[((size_t)co * 9 + tp) * Cin + cb * CIB + col] += acc;
+    __shared__ f32x4_t red[4][64];
+    const size_t per4 = (size_t)tilesMN * 9 * COT * CIB / 4;  // float4 vectors per split
+    const f32x4_t* ws4 = (const f32x4_t*)ws;
+    const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < per4; base += (size_t)gridDim.x * 64) {
+        const size_t i4 = base + q;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        if (i4 < per4) {
+#pragma unroll 8
+            for (int sidx = grp; sidx < nsplit; sidx += 4) acc += ws4[(size_t)sidx * per4 + i4];
+        }
+        red[grp][q] = acc;
+        __syncthreads();
+        if (grp == 0 && i4 < per4) {
+            acc = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+            const size_t i = i4 * 4;
+            const int col = (int)(i % CIB);
+            size_t r = i / CIB;
+            const int row = (int)(r % COT);
+            r /= COT;
+            const int tp = (int)(r % 9);
+            const int mn = (int)(r / 9);
+            const int tm = mn / ncib, cb = mn - tm * ncib;
+            const int co = tm * COT + row;
+            if (co < Cout) {
+                f32x4_t* d = (f32x4_t*)(dw + ((size_t)co * 9 + tp) * Cin + cb * CIB + col);
+                *d = *d + acc;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -305,7 +323,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     wgrad_patch_kernel<T><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
-        const int grid = (int)std::min<size_t>((per_split + 255) / 256, 4096);
+        const int grid = (int)std::min<size_t>((per_split / 4 + 63) / 64, 4096);
         wgrad_reduce_kernel<COT, CIB><<<grid, 256, 0, st>>>(p.ws, dw, nsplit, tilesMN, a.Cin / CIB, a.Cin, a.Cout);
     }
     return (int)hipGetLastError();
