@@ -43,3 +43,7 @@ int c2w_conv_patch3(const C2wConvArgs& a, hipStream_t st);
 // halo-patch weight-gradient kernel for the same convolutions (wgrad_patch.hip)
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a);
 int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st);
+
+// scratch buffer for split-K partial sums of the weight-gradient kernels (c2w_set_workspace, wgrad_patch.hip)
+extern float* c2w_g_ws;
+extern size_t c2w_g_ws_bytes;

@@ -32,6 +32,7 @@ struct WgradArgs {
     int B, Hin, Win, Cin, Hout, Wout, Cout, ldy;
     int nsplit, ktiles_per_split;
     FastDiv div_hw, div_w;
+    float* ws;  // optional scratch [split][tile][COT][4*CIB] fp32 for the partial sums (else fp32 atomics)
 };
 
 __device__ __forceinline__ uint32_t swz(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
@@ -258,6 +259,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
                 if (co < p.Cout) atomicAdd(p.db + co, accb[m][r]);
             }
     }
+    if (p.ws != nullptr) {  // partial tile by coalesced stores; wgrad_gather_reduce_kernel adds the splits into dw
+        float* const dst = p.ws + ((size_t)split * tilesMN + mn) * (COT * NCOL);
+        for (int idx = tid; idx < COT * NCOL; idx += NTHREADS) dst[idx] = O[(idx / NCOL) * OS + (idx % NCOL)];
+        return;
+    }
     for (int idx = tid; idx < COT * NCOL; idx += NTHREADS) {
         const int row = idx / NCOL, col = idx - row * NCOL;
         const int cb = col / CIB, cil = col - cb * CIB;
@@ -268,6 +274,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
             const int ci = (nb - tap * cib_per_tap) * CIB + cil;
             atomicAdd(p.dw + ((size_t)co * NT + tap) * p.Cin + ci, O[row * OS + col]);
         }
+    }
+}
+
+// dw += sum over splits of the partial tiles (same 64 x 4 layout of a block as wgrad_reduce_kernel in wgrad_patch.hip)
+template <int COT, int CIB, int NT>
+__global__ __launch_bounds__(256) void wgrad_gather_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesM,
+                                                                  int tilesN, int Cin, int Cout) {
+    constexpr int NCOL = 4 * CIB;
+    __shared__ f32x4_t red[4][64];
+    const size_t per4 = (size_t)tilesM * tilesN * COT * NCOL / 4;
+    const f32x4_t* ws4 = (const f32x4_t*)ws;
+    const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int cib_per_tap = Cin / CIB, nb_total = NT * cib_per_tap;
+    for (size_t base = (size_t)blockIdx.x * 64; base < per4; base += (size_t)gridDim.x * 64) {
+        const size_t i4 = base + q;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        if (i4 < per4) {
+#pragma unroll 8
+            for (int sidx = grp; sidx < nsplit; sidx += 4) acc += ws4[(size_t)sidx * per4 + i4];
+        }
+        red[grp][q] = acc;
+        __syncthreads();
+        if (grp == 0 && i4 < per4) {
+            acc = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+            const size_t i = i4 * 4;
+            const int col = (int)(i % NCOL);
+            size_t r = i / NCOL;
+            const int row = (int)(r % COT);
+            const int mn = (int)(r / COT);
+            const int tm = mn / tilesN, tn = mn - tm * tilesN;
+            const int cb = col / CIB, cil = col - cb * CIB;
+            const int nb = tn * 4 + cb;
+            const int co = tm * COT + row;
+            if (nb < nb_total && co < Cout) {
+                const int tap = nb / cib_per_tap;
+                const int ci = (nb - tap * cib_per_tap) * CIB + cil;
+                f32x4_t* d = (f32x4_t*)(dw + ((size_t)co * NT + tap) * Cin + ci);
+                *d = *d + acc;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -309,7 +356,14 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    const size_t need = (size_t)p.nsplit * tilesMN * COT * 4 * CIB * sizeof(float);
+    p.ws = (c2w_g_ws != nullptr && need <= c2w_g_ws_bytes && p.nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? c2w_g_ws : nullptr;
     wgrad_kernel<T, MODE><<<tilesMN * p.nsplit, NTHREADS, lds, st>>>(p);
+    if (p.ws != nullptr) {
+        const size_t per4 = (size_t)tilesMN * COT * 4 * CIB / 4;
+        const int grid = (int)((per4 + 63) / 64 < 4096 ? (per4 + 63) / 64 : 4096);
+        wgrad_gather_reduce_kernel<COT, CIB, NT><<<grid, 256, 0, st>>>(p.ws, dw, p.nsplit, tilesM, tilesN, a.Cin, a.Cout);
+    }
     return (int)hipGetLastError();
 }
 

@@ -22,6 +22,10 @@
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA after the
 #endif             // first tile, 32 no epilogue
 
+// process-wide workspace registered by the host (c2w_set_workspace): one thread per rank, launches on one stream are ordered
+float* c2w_g_ws = nullptr;
+size_t c2w_g_ws_bytes = 0;
+
 namespace {
 
 // Measured alternatives (128->128 @128^2, B = 128, this layout 0.62-0.69 ms depending on the box): ablation builds run 0.49 ms
@@ -47,9 +51,7 @@ struct WpArgs {
     float* ws;  // optional workspace [split][tile][tap][COT][CIB] fp32: partial sums by plain stores, reduced by a second launch
 };
 
-// process-wide workspace registered by the host (c2w_set_workspace): one thread per rank, launches on one stream are ordered
-float* g_ws = nullptr;
-size_t g_ws_bytes = 0;
+
 
 __device__ __forceinline__ uint32_t swzA(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
 __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2)); }
@@ -319,7 +321,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
         attr_set = true;
     }
     const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
-    p.ws = (g_ws != nullptr && need <= g_ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? g_ws : nullptr;
+    p.ws = (c2w_g_ws != nullptr && need <= c2w_g_ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? c2w_g_ws : nullptr;
     wgrad_patch_kernel<T><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
@@ -344,7 +346,7 @@ int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipSt
 // Scratch memory for the split-K partial sums of the weight-gradient kernels (caller-owned device buffer; NULL / 0 to
 // unregister).  Without it the kernels combine their partial sums with fp32 atomics.
 extern "C" int c2w_set_workspace(void* ptr, unsigned long long bytes) {
-    g_ws = (float*)ptr;
-    g_ws_bytes = (size_t)bytes;
+    c2w_g_ws = (float*)ptr;
+    c2w_g_ws_bytes = (size_t)bytes;
     return 0;
 }

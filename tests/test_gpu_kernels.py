@@ -228,8 +228,6 @@ def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased):
 def test_conv_wgrad(case, dt, force_gather, monkeypatch):
     mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
     if force_gather == "workspace":  # split-K partial sums through the registered scratch buffer instead of atomics
-        if mode != ops.CONV_S1:
-            pytest.skip("only the halo-patch weight-gradient kernel uses the workspace")
         ops.ensure_workspace(dev())
     else:
         ops.drop_workspace()
