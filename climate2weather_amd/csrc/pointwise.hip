@@ -606,7 +606,12 @@ extern "C" int c2w_ln_backward(const void* dy, const void* x, const float* m, co
     if (!dy || !x || !dx || !vec_ok(dtype, C) || C > 16 * LN_MAXV * (dtype == C2W_DTYPE_F32 ? 4 : 8) || C < 2) return C2W_ERR_BAD_SHAPE;
     const float inv_den = 1.0f / (float)(unbiased ? C - 1 : C);
     if (HW <= 0 || npix % HW != 0) return C2W_ERR_BAD_SHAPE;
-    const int ppb = HW < 512 ? HW : 512;
+    // pixels per block: 512 at the large levels; fewer where that would leave the chip with under ~2048 blocks (32x32 and
+    // below at B = 128: 256 / 128 blocks of 4 waves were latency-bound at 3.5 TB/s)
+    long long want = (npix / 2048 + 15) / 16 * 16;
+    if (want < 16) want = 16;
+    if (want > 512) want = 512;
+    const int ppb = HW < want ? HW : (int)want;
     dim3 grid((HW + ppb - 1) / ppb, (unsigned)(npix / HW));
     const int nv = (C + 16 * (dtype == C2W_DTYPE_F32 ? 4 : 8) - 1) / (16 * (dtype == C2W_DTYPE_F32 ? 4 : 8));
 #define LN_BWD(NVV) DISPATCH_T(dtype, (ln_bwd_kernel<T, NVV><<<grid, 256, 0, (hipStream_t)stream>>>( \
