@@ -6,6 +6,7 @@ bf16 mode <= 2e-2 of the output scale (bf16 has 8 significand bits; K up to 4608
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -456,3 +457,79 @@ def test_attention(shape, dt):
     ops.attention_backward(qkv, o_ref, do, lse_ref, delta, dq, B, T, C, dt)
     E.attention_backward(qkv, o_ref, do, lse_ref, delta, dq_ref, B, T, C, dt)
     close(dq, dq_ref, dt, "attention bwd")
+
+
+def test_conv_random_shapes_product_vs_direct_kernel():
+    """Seeded sweep over the shape space the dispatcher splits between its kernels (halo-patch 8x16 / 16x16 tiles, gather
+    256- and 128-pixel tiles, parity-class TS2): the product path against the one-thread-per-output direct kernel (naive=1),
+    both on the GPU, with bias / activation / residual / multiplier drawn at random."""
+    rs = np.random.RandomState(1234)
+    modes = [ops.CONV_S1, ops.CONV_S1, ops.CONV_S1, ops.CONV_S2, ops.CONV_UP, ops.CONV_TS2, ops.CONV_1X1]
+    for it in range(48):
+        mode = modes[rs.randint(len(modes))]
+        dt = [F32, BF16][rs.randint(2)]
+        B = int(rs.randint(1, 4))
+        Hin, Win = int(rs.choice([4, 8, 12, 16, 24, 32, 40])), int(rs.choice([4, 8, 16, 32, 48]))
+        if mode == ops.CONV_S2:
+            Hin, Win = Hin * 2, Win * 2
+        Cin = int(rs.choice([64, 128, 192])) if dt == BF16 else int(rs.choice([32, 64, 96]))
+        ldy = int(rs.choice([8, 64, 72, 128, 136, 200]))
+        Cout = ldy if rs.rand() < 0.7 else max(8, ldy - 8 * int(rs.randint(0, 3)))
+        wrows = Cout if rs.rand() < 0.7 else max(1, Cout - int(rs.randint(1, 8)))
+        Hout, Wout = _out_hw(mode, Hin, Win)
+        taps = 1 if mode == ops.CONV_1X1 else 9
+        g = geom(B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows, mode)
+        x = rnd((B * Hin * Win, Cin), dt, 10 * it + 1)
+        w = rnd((wrows, taps, Cin), dt, 10 * it + 2, scale=1.0 / math.sqrt(taps * Cin))
+        bias = rnd((wrows,), F32, 10 * it + 3) if rs.rand() < 0.6 else None
+        kw = {}
+        if rs.rand() < 0.4:
+            kw["act"] = ops.ACT_SILU
+        if rs.rand() < 0.5:
+            kw["res"] = rnd((B * Hout * Wout, ldy), dt, 10 * it + 4)
+        if "act" not in kw and rs.rand() < 0.4:
+            kw["mul"] = rnd((B * Hout * Wout, ldy), dt, 10 * it + 5)
+            kw["mulmode"] = [ops.MUL_PLAIN, ops.MUL_DSILU][rs.randint(2)]
+        y = torch.full((B * Hout * Wout, ldy), 7.0, dtype=TD[dt], device=dev())
+        y_ref = y.clone()
+        ops.conv(x, w, bias, y, g, dt, naive=0, **kw)
+        ops.conv(x, w, bias, y_ref, g, dt, naive=1, **kw)
+        torch.cuda.synchronize()
+        close(y, y_ref, dt, f"random conv #{it}: mode={mode} dt={dt} B={B} {Hin}x{Win} {Cin}->{Cout}/{ldy} wrows={wrows} {sorted(kw)}",
+              tol=2e-4 if dt == F32 else 2e-2)
+
+
+def test_wgrad_random_shapes_vs_restatement():
+    """Seeded sweep of the weight-gradient kernels (halo-patch / gather; atomics / workspace reduction) against autograd of the
+    PyTorch restatement, including ragged channel counts and the bias gradient."""
+    rs = np.random.RandomState(4321)
+    modes = [ops.CONV_S1, ops.CONV_S1, ops.CONV_S2, ops.CONV_UP, ops.CONV_1X1]
+    for it in range(24):
+        mode = modes[rs.randint(len(modes))]
+        dt = [F32, BF16][rs.randint(2)]
+        if rs.rand() < 0.5:
+            ops.ensure_workspace(dev())
+        else:
+            ops.drop_workspace()
+        B = int(rs.randint(1, 4))
+        Hin, Win = int(rs.choice([4, 8, 16, 24])), int(rs.choice([8, 16, 32]))
+        if mode == ops.CONV_S2:
+            Hin, Win = Hin * 2, Win * 2
+        Cin = int(rs.choice([64, 128, 192])) if dt == BF16 else int(rs.choice([32, 64, 96]))
+        ldy = int(rs.choice([8, 64, 72, 128, 200]))
+        Cw = ldy if rs.rand() < 0.6 else max(1, ldy - int(rs.randint(1, 9)))
+        Hout, Wout = _out_hw(mode, Hin, Win)
+        taps = 1 if mode == ops.CONV_1X1 else 9
+        g = geom(B, Hin, Win, Cin, Hout, Wout, Cw, ldy, Cw, mode)
+        x = rnd((B * Hin * Win, Cin), dt, 20 * it + 1)
+        dy = rnd((B * Hout * Wout, ldy), dt, 20 * it + 2)
+        dw = torch.zeros(Cw * taps * Cin, dtype=torch.float32, device=dev())
+        db = torch.zeros(Cw, dtype=torch.float32, device=dev())
+        dw_ref, db_ref = dw.clone(), db.clone()
+        ops.conv_wgrad(x, dy, dw, g, dt, dbias=db)
+        E.conv_wgrad(x, dy, dw_ref, g, dt, dbias=db_ref)
+        torch.cuda.synchronize()
+        what = f"random wgrad #{it}: mode={mode} dt={dt} B={B} {Hin}x{Win} {Cin}->{Cw}/{ldy}"
+        close(dw, dw_ref, dt, what, tol=1e-4 if dt == F32 else 1e-2)
+        close(db, db_ref, dt, what + " bias", tol=1e-4 if dt == F32 else 1e-2)
+    ops.drop_workspace()
