@@ -138,3 +138,29 @@ def test_full_size_net_fp32_vs_reference_fingerprint(golden_dir):
     with torch.no_grad():
         yb = net(x.cuda(), torch.tensor([0.3], device="cuda")).cpu()
     assert _rel(yb[:, :, ::16, ::16], ref) <= 3e-2
+
+
+def test_full_size_bf16_large_batch_matches_fp32_path():
+    """At B = 16 the 128^2 and 64^2 levels dispatch to the 16x16-tile bf16 kernel (>= 1024 workgroups) with the fused LayerNorm
+    epilogues; the fp32 mode runs the 8x16 kernels without those fusions and is pinned to the reference by the fingerprint
+    test above.  Forward and parameter gradients of the two modes on the same inputs: bf16 tolerance 3e-2 of the scale."""
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=52, spatial=2, activation=torch.nn.SiLU, **DEFAULT).cuda()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(16, 52, 128, 128, generator=g) * 0.5 + 0.5).cuda()
+    t = torch.rand(16, generator=g).cuda()
+    eps = torch.randn(16, 52, 128, 128, generator=g).cuda()
+    outs, grads = {}, {}
+    for mode in ("fp32", "bf16"):
+        net.precision = mode
+        for p in net.parameters():
+            p.grad = None
+        y = net(x, t)
+        loss = ((y - eps) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        outs[mode] = y.detach().float().clone()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    assert _rel(outs["bf16"], outs["fp32"]) <= 3e-2
+    worst = max((_rel(grads["bf16"][n], grads["fp32"][n]), n) for n in grads["fp32"] if n.endswith("weight"))
+    assert worst[0] <= 6e-2, worst  # gradients pass through ~100 bf16 layers: twice the forward tolerance
