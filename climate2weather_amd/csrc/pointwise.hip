@@ -463,6 +463,33 @@ __global__ __launch_bounds__(256) void mse_loss_grad_tiled_kernel(const T* __res
     if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
 }
 
+// NHWC T -> NCHW fp32 through the same LDS tile: rows of 64 pixels x ldc channels are read as one contiguous run, channel planes
+// leave as 256-B runs (the untiled kernel gathered 2-byte elements at a stride of ldc: 2 ms for 32 x 80 x 256^2)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_tiled_kernel(const T* __restrict__ y, float* __restrict__ out, int B, int C, int HW, int ldc) {
+    constexpr int P = Elem<T>::PER16;
+    extern __shared__ float lt_tile[];
+    const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
+    for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
+        const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
+        const int npx = min(LT_PT, HW - p0);
+        for (int i = threadIdx.x; i < npx * nvec; i += 256) {
+            const int px = i / nvec, v = i - px * nvec;
+            float f[P];
+            unpack16<T>(*(const u32x4_t*)(y + ((size_t)b * HW + p0) * ldc + (size_t)i * P), f);
+#pragma unroll
+            for (int e = 0; e < P; ++e) lt_tile[(v * P + e) * LT_LD + px] = f[e];
+        }
+        __syncthreads();
+        const int px = threadIdx.x & (LT_PT - 1), cb = threadIdx.x / LT_PT;
+        if (px < npx) {
+#pragma unroll 4
+            for (int c = cb; c < C; c += 256 / LT_PT) out[((size_t)b * C + c) * HW + p0 + px] = lt_tile[c * LT_LD + px];
+        }
+        __syncthreads();
+    }
+}
+
 // timestep_embedding (model/score.py:14-34): out[b] = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(max_period) i/half)
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim, float max_period) {
     const int half = dim / 2;
@@ -678,6 +705,12 @@ extern "C" int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* m
 
 extern "C" int c2w_nhwc_to_nchw(const void* y, float* out, int B, int C, int HW, int ldc, int dtype, void* stream) {
     if (!y || !out || ldc < C) return C2W_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (vec_ok(dtype, ldc) && lds <= 64 * 1024) {
+        const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
+        DISPATCH_T(dtype, (nhwc_to_nchw_tiled_kernel<T><<<nblk, 256, lds, (hipStream_t)stream>>>((const T*)y, out, B, C, HW, ldc)));
+        return (int)hipGetLastError();
+    }
     DISPATCH_T(dtype, (nhwc_to_nchw_kernel<T><<<grid_for((long long)B * C * HW), 256, 0, (hipStream_t)stream>>>((const T*)y, out, B, C, HW,
                                                                                                              ldc)));
     return (int)hipGetLastError();
