@@ -164,3 +164,36 @@ def test_full_size_bf16_large_batch_matches_fp32_path():
     assert _rel(outs["bf16"], outs["fp32"]) <= 3e-2
     worst = max((_rel(grads["bf16"][n], grads["fp32"][n]), n) for n in grads["fp32"] if n.endswith("weight"))
     assert worst[0] <= 6e-2, worst  # gradients pass through ~100 bf16 layers: twice the forward tolerance
+
+
+@pytest.mark.parametrize("B,H,W,channels,cfg", [
+    (1, 16, 32, 5, dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 2], attention_levels=[1])),
+    (3, 48, 16, 9, dict(embedding_dim=96, hidden_channels=[128, 64, 192], hidden_blocks=[1, 1, 1], attention_levels=[])),
+    (5, 8, 8, 65, dict(embedding_dim=64, hidden_channels=[64, 64], hidden_blocks=[2, 1], attention_levels=[0, 1])),
+    (2, 32, 64, 13, dict(embedding_dim=64, hidden_channels=[128, 128, 128, 128], hidden_blocks=[1, 1, 1, 1], attention_levels=[3])),
+])
+def test_ragged_configurations_fp32_vs_oracle(B, H, W, channels, cfg):
+    """Non-square images, odd batches, channel counts that need padding, attention at several levels and token counts (incl.
+    T = 64 on a non-default width and T != 64), levels wider than their neighbours: forward and all parameter gradients of
+    the fp32 mode against the CPU oracle (<= 1e-4 / 3e-4), bf16 forward within 3e-2."""
+    cfg = dict(cfg, kernel_size=3, padding_mode="zeros")
+    torch.manual_seed(B * 100 + H)
+    net = ScoreUNet(channels=channels, spatial=2, activation=torch.nn.SiLU, **cfg)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda()
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, channels, H, W, generator=g)
+    t = torch.rand(B, generator=g)
+    eps = torch.randn(B, channels, H, W, generator=g)
+    yo = ou.score_unet_forward(sdo, x, t, cfg["hidden_blocks"], cfg["attention_levels"])
+    go = torch.autograd.grad(((yo - eps) ** 2).mean(), list(sdo.values()))
+    net.precision = "fp32"
+    y = net(x.cuda(), t.cuda())
+    assert _rel(y, yo.detach()) <= 1e-4
+    ((y - eps.cuda()) ** 2).mean().backward()
+    named = dict(net.named_parameters())
+    for (k, _), gr in zip(sdo.items(), go):
+        assert _rel(named[k].grad, gr) <= 3e-4, k
+    net.precision = "bf16"
+    with torch.no_grad():
+        assert _rel(net(x.cuda(), t.cuda()), yo.detach()) <= 3e-2
