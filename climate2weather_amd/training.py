@@ -29,7 +29,7 @@ class Trainer:
     def __init__(self, net, pipeline: Optional[SDAPipeline] = None, *, lr: float = 1e-4, lr_fn: Optional[Callable[[int], float]] = None,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-3, ema_rates: Sequence[float] = (0.9999,),
                  precision: str = "bf16", batch_size: Optional[int] = None, loss_scaling: float = 1.0,
-                 process_group=None, bucket_mb: float = 48.0):
+                 process_group=None, bucket_mb: float = 25.0):
         self.net = net
         self.pipeline = pipeline or SDAPipeline()
         self.lr, self.lr_fn = lr, lr_fn
