@@ -14,6 +14,9 @@
 //     247 VGPRs => two workgroups per CU, one barrier per 32 MFMAs per wave.
 // MFMA shape and the epilogue (conv_epilogue.h: bias / SiLU / pair / multiplier / residual / fused LayerNorm forward and
 // backward, in two passes of 8 tile rows) are those of conv_patch_half_kernel; A = weights, B = pixels.
+// Measured and rejected on this kernel: a 4-slot weight ring (three stages of prefetch, 78.8 KB LDS) -1 %; pixel-fragment reads
+// hoisted above the barrier -0.7 %; residual rows prefetched for both 8-row blocks right after staging -0.5 %; prefetching them
+// next to live accumulators spills.
 // Lesson kept in the code below: nothing may spill -- scratch loads return out of order with the LDS-DMA loads and break the
 // counted vmcnt waits (seen as wrong weight rows at chunk boundaries with 40 spilled registers).
 #include <cstdlib>
