@@ -188,9 +188,10 @@ def main():
     if a.sample_steps > 0 and a.size == 128:
         net.precision = a.precision
         L = 128 + w - 1
-        sf = BatchedScoreFunction(net, markov_order=a.markov_order, batch_size=128, device=dev, noise_process=trainer.pipeline)
-        noise = torch.randn(L, a.vars, a.size, a.size, device=dev)
         import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):  # stdout carries exactly one line: the JSON below
+            sf = BatchedScoreFunction(net, markov_order=a.markov_order, batch_size=128, device=dev, noise_process=trainer.pipeline)
+        noise = torch.randn(L, a.vars, a.size, a.size, device=dev)
         with contextlib.redirect_stdout(io.StringIO()):
             trainer.pipeline.sample(sf, noise, steps=1, show_progressbar=False)
             torch.cuda.synchronize()
