@@ -393,7 +393,7 @@ __device__ __forceinline__ void lt_load_planes(float* tile, int C, int ldc, int 
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                                  const float* __restrict__ musig, T* __restrict__ y, int B, int C, int HW,
-                                                                 int ldc) {
+                                                                 int ldc, long long img_stride) {
     constexpr int P = Elem<T>::PER16;
     extern __shared__ float lt_tile[];
     const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __
             }
             __device__ __forceinline__ float operator()(size_t o, int) const { return eps ? mu * x[o] + sg * eps[o] : x[o]; }
         } ld{x, eps, mu, sg};
-        lt_load_planes(lt_tile, C, ldc, HW, p0, (size_t)b * C * HW, ld);
+        lt_load_planes(lt_tile, C, ldc, HW, p0, (size_t)b * img_stride, ld);  // img_stride < C*HW: overlapping windows of a trajectory
         __syncthreads();
         const int npx = min(LT_PT, HW - p0);
         for (int i = threadIdx.x; i < npx * nvec; i += 256) {
@@ -695,11 +695,21 @@ extern "C" int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* m
     const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
     if (lds <= 64 * 1024) {
         const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
-        DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T><<<nblk, 256, lds, (hipStream_t)stream>>>(x, eps, musig, (T*)y, B, C, HW, ldc)));
+        DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T><<<nblk, 256, lds, (hipStream_t)stream>>>(x, eps, musig, (T*)y, B, C, HW, ldc,
+                                                                                                 (long long)C * HW)));
         return (int)hipGetLastError();
     }
     DISPATCH_T(dtype, (nchw_to_nhwc_kernel<T><<<grid_for((long long)B * HW * (ldc / P)), 256, 0, (hipStream_t)stream>>>(x, eps, musig, (T*)y,
                                                                                                                      B, C, HW, ldc)));
+    return (int)hipGetLastError();
+}
+
+// used by c2w_window_gather (sampler.hip): image b starts img_stride floats after image b - 1 (windows of a trajectory overlap)
+int c2w_planes_to_rows_strided(const float* x, void* y, int B, int C, int HW, int ldc, long long img_stride, int dtype, hipStream_t st) {
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (!vec_ok(dtype, ldc) || lds > 64 * 1024 || (img_stride & 3) != 0) return C2W_ERR_UNSUPPORTED;
+    const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
+    DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T><<<nblk, 256, lds, st>>>(x, nullptr, nullptr, (T*)y, B, C, HW, ldc, img_stride)));
     return (int)hipGetLastError();
 }
 

@@ -6,6 +6,8 @@
 #include "common.h"
 #include "c2w_hip.h"
 
+int c2w_planes_to_rows_strided(const float* x, void* y, int B, int C, int HW, int ldc, long long img_stride, int dtype, hipStream_t st);
+
 namespace {
 
 inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
@@ -40,21 +42,22 @@ __global__ __launch_bounds__(256) void window_gather_kernel(const float* __restr
 
 // fold (src/thor/score.py:76-88 / _window_score :111-141): keep the centre frame of every window, the leading k frames of
 // the first window and the trailing k frames of the last one.
+// One thread per (window, pixel): the kept channels of a window are one contiguous run of its NHWC row -- [k F, (k+1) F) for an
+// interior window, from 0 for the first, to w F for the last -- and land in the planes (gi F + c) of the trajectory.
 template <typename T>
 __global__ __launch_bounds__(256) void window_scatter_kernel(const T* __restrict__ y, float* __restrict__ eps, int nw, int F, int HW, int k,
                                                              int i0, int nwin_total, int ldc) {
     const int w = 2 * k + 1;
-    const long long total = (long long)nw * w * F * HW;
+    const long long total = (long long)nw * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int pix = (int)(i % HW);
-        long long r = i / HW;
-        const int c = (int)(r % F);
-        r /= F;
-        const int tau = (int)(r % w);
-        const int j = (int)(r / w);
+        const int j = (int)(i / HW);
         const int gi = i0 + j;
-        const bool keep = tau == k || (gi == 0 && tau < k) || (gi == nwin_total - 1 && tau > k);
-        if (keep) eps[((long long)(gi + tau) * F + c) * HW + pix] = Elem<T>::ld(y + ((size_t)j * HW + pix) * ldc + tau * F + c);
+        const int c_lo = gi == 0 ? 0 : k * F;
+        const int c_hi = gi == nwin_total - 1 ? w * F : (k + 1) * F;
+        const T* row = y + ((size_t)j * HW + pix) * ldc;
+        float* dst = eps + (long long)gi * F * HW + pix;
+        for (int c = c_lo; c < c_hi; ++c) dst[(long long)c * HW] = Elem<T>::ld(row + c);
     }
 }
 
@@ -173,6 +176,10 @@ extern "C" int c2w_window_gather(const float* x, void* y, int nw, int F, int HW,
     const int CW = (2 * k + 1) * F;
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!x || !y || nw <= 0 || ldc < CW || ldc % P) return C2W_ERR_BAD_SHAPE;
+    // a window's (w F, H, W) tensor is the contiguous run of planes starting at frame i0 + j: the LDS-tiled plane -> row kernel
+    // with an image stride of one frame (pointwise.hip); the per-thread gather below is the fallback for shapes it does not take
+    if (c2w_planes_to_rows_strided(x + (long long)i0 * F * HW, y, nw, CW, HW, ldc, (long long)F * HW, dtype, (hipStream_t)stream) == 0)
+        return (int)hipGetLastError();
     const long long total = (long long)nw * HW * (ldc / P);
     if (dtype == C2W_DTYPE_F32)
         window_gather_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (float*)y, nw, CW, HW, (long long)F * HW, i0, ldc);
@@ -186,7 +193,7 @@ extern "C" int c2w_window_gather(const float* x, void* y, int nw, int F, int HW,
 extern "C" int c2w_window_scatter(const void* y, float* eps, int nw, int F, int HW, int k, int i0, int nwin_total, int ldc, int dtype,
                                   void* stream) {
     if (!y || !eps || nw <= 0 || ldc < (2 * k + 1) * F) return C2W_ERR_BAD_SHAPE;
-    const long long total = (long long)nw * (2 * k + 1) * F * HW;
+    const long long total = (long long)nw * HW;
     if (dtype == C2W_DTYPE_F32)
         window_scatter_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const float*)y, eps, nw, F, HW, k, i0, nwin_total, ldc);
     else if (dtype == C2W_DTYPE_BF16)
