@@ -14,6 +14,9 @@
 //     247 VGPRs => two workgroups per CU, one barrier per 32 MFMAs per wave.
 // MFMA shape and the epilogue (conv_epilogue.h: bias / SiLU / pair / multiplier / residual / fused LayerNorm forward and
 // backward, in two passes of 8 tile rows) are those of conv_patch_half_kernel; A = weights, B = pixels.
+// Tried and abandoned: a persistent variant (workgroup walks tiles, next tile's first patch chunk requested during the epilogue,
+// output staged behind the patch region): 141 spilled SGPRs -> 400-700 spilled VGPRs; the scalar state of two tiles plus the
+// argument block does not fit.
 // Measured and rejected on this kernel: a 4-slot weight ring (three stages of prefetch, 78.8 KB LDS) -1 %; pixel-fragment reads
 // hoisted above the barrier -0.7 %; residual rows prefetched for both 8-row blocks right after staging -0.5 %; prefetching them
 // next to live accumulators spills.
