@@ -322,3 +322,30 @@ def test_graph_replayed_score_function_equals_eager(golden_dir):
     assert torch.equal(outs[0], outs[1])
     ref = torch.from_numpy(s["cond_c0.x"])
     assert (outs[1].cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+
+
+def test_bf16_training_tracks_fp32_training():
+    """60 optimizer steps on a small network and a fixed synthetic batch stream: the bf16 throughput mode must learn like the fp32
+    parity mode (same data, noise and times injected): losses fall, and the two curves stay within 5 % of each other."""
+    cfg = dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(11)
+        net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg).cuda()
+        tr = Trainer(net, lr=2e-3, precision=prec, ema_rates=[0.999])
+        gen = torch.Generator().manual_seed(3)
+        base = torch.randn(8, 6, 32, 32, generator=gen) * 0.5 + 0.5
+        losses = []
+        for s in range(60):
+            x = (base + 0.05 * torch.randn(8, 6, 32, 32, generator=gen)).cuda()
+            t = torch.rand(8, generator=gen).cuda()
+            eps = torch.randn(8, 6, 32, 32, generator=gen).cuda()
+            losses.append(float(tr.step(x, t=t, eps=eps)))
+        curves[prec] = losses
+    first = sum(curves["fp32"][:5]) / 5
+    for prec in curves:
+        last = sum(curves[prec][-10:]) / 10
+        assert last < 0.6 * first, (prec, first, last)
+    a = torch.tensor(curves["fp32"][-20:]).mean().item()
+    b = torch.tensor(curves["bf16"][-20:]).mean().item()
+    assert abs(a - b) <= 0.05 * a, (a, b)
