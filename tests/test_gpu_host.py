@@ -349,3 +349,22 @@ def test_bf16_training_tracks_fp32_training():
     a = torch.tensor(curves["fp32"][-20:]).mean().item()
     b = torch.tensor(curves["bf16"][-20:]).mean().item()
     assert abs(a - b) <= 0.05 * a, (a, b)
+
+
+def test_ensemble_driver_on_device():
+    """a14 on the GPU: members of one rank, conditioned with the experiment's operator, state resident in HBM, bf16 network."""
+    from climate2weather_amd.sampling import run_ensemble
+    torch.manual_seed(1)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").cuda().eval()  # bf16 needs channel counts in 64s
+    A = PoolStrideOperator(8, 2)
+    truth = torch.rand(9, 2, 32, 32)
+    y = A(truth)
+    kw = dict(length=9, n_vars=2, height=32, width=32, markov_order=1, num_samples=4, steps=8, batch_size=4, seed=3, A=A, y=y,
+              std=torch.tensor([0.1, 0.1]).view(1, 2, 1, 1), gamma=1e-2, device=torch.device("cuda", 0), precision="bf16")
+    out = run_ensemble(net, world=2, rank=1, **kw)
+    assert [i for i, _ in out] == [2, 3]
+    for _, x in out:
+        assert x.is_cuda and x.shape == (9, 2, 32, 32) and torch.isfinite(x).all()
+    again = run_ensemble(net, world=2, rank=1, **kw)
+    assert all(torch.equal(a[1], b[1]) for a, b in zip(out, again))

@@ -397,3 +397,30 @@ def test_cosmo_dataset_contract(tmp_path):
     it = iter(InfiniteSampler(ds, rank=1, num_replicas=2, seed=0))
     for j in range(3):
         assert torch.equal(b[j], ds[next(it)])
+
+
+def test_ensemble_driver_shards_members_by_rank(emu):
+    """exp/downscaling.py:96-103,208-265: num_samples % world == 0, rank r generates members r*n .. (r+1)*n - 1, the RNG stream
+    differs by rank through the seed, every member is a full trajectory; no collective."""
+    from climate2weather_amd.sampling import run_ensemble
+    net = _tiny().eval()
+    kw = dict(length=5, n_vars=2, height=16, width=16, markov_order=1, num_samples=4, steps=2, batch_size=4, seed=7,
+              device=torch.device("cpu"), precision="fp32")
+    r0 = run_ensemble(net, world=2, rank=0, **kw)
+    r1 = run_ensemble(net, world=2, rank=1, **kw)
+    assert [i for i, _ in r0] == [0, 1] and [i for i, _ in r1] == [2, 3]
+    for _, x in r0 + r1:
+        assert x.shape == (5, 2, 16, 16) and torch.isfinite(x).all()
+    assert not torch.equal(r0[0][1], r1[0][1]) and not torch.equal(r0[0][1], r0[1][1])
+    again = run_ensemble(net, world=2, rank=1, **kw)
+    assert all(torch.equal(a[1], b[1]) for a, b in zip(r1, again))  # same seed and rank -> same members
+    seen = []
+    run_ensemble(net, world=1, rank=0, on_sample=lambda i, x: seen.append(i), **dict(kw, num_samples=2))
+    assert seen == [0, 1]
+    with pytest.raises(AssertionError, match="divisible"):
+        run_ensemble(net, world=2, rank=0, **dict(kw, num_samples=3))
+    # conditioned members (the shipped experiment's operator)
+    A = PoolStrideOperator(8, 2)
+    truth = torch.rand(5, 2, 16, 16)
+    rc = run_ensemble(net, world=1, rank=0, A=A, y=A(truth), std=torch.tensor([0.5, 0.5]).view(1, 2, 1, 1), gamma=1e-2, **dict(kw, num_samples=1))
+    assert rc[0][1].shape == (5, 2, 16, 16)
