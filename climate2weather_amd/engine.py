@@ -37,7 +37,8 @@ def _round_up(n: int, m: int) -> int:
 
 @dataclass
 class ConvRec:
-    """One weight matrix [rows][taps][kstride] (+ bias[rows]) inside the flat buffer."""
+    """One weight matrix [rows][taps][cin] (+ bias[rows]) inside the flat buffer -- dense, so that every Parameter is a
+    non-overlapping dense view (optimizers, DDP bucket views and the autograd layout contract all assume that)."""
     name: str
     rows: int  # Cout
     cin: int  # real input channels
@@ -131,9 +132,9 @@ class Layout:
 
     def _add(self, name: str, rows: int, cin: int, taps: int, kstride: Optional[int] = None, lin=False, dg_ld=None, flip=False, ndim=4):
         off = self._off
-        ks = kstride or cin
-        rec = ConvRec(name, rows, cin, ks, taps, lin=lin, dg_ld=dg_ld if dg_ld is not None else rows, flip=flip)
+        rec = ConvRec(name, rows, cin, kstride or cin, taps, lin=lin, dg_ld=dg_ld if dg_ld is not None else rows, flip=flip)
         rec.w_off = off
+        ks = cin  # storage is dense; a layer whose operand stride differs (kstride > cin) reads a padded copy (Engine._w)
         if taps == 9:
             self.views[name + ".weight"] = (off, (rows, cin, 3, 3), (9 * ks, 1, 3 * ks, ks))
         elif ndim == 3:
@@ -186,6 +187,8 @@ class Engine:
         self.dg_lin: Optional[torch.Tensor] = None
         self._dg_ver: Dict[object, int] = {}
         self._dg_desc: Dict[object, tuple] = {}
+        self._wpad: Dict[object, tuple] = {}   # (name, dtype) -> (version, zero-padded operand copy)
+        self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
         self.attach(net)
 
@@ -203,9 +206,9 @@ class Engine:
             for name, (off, shape, strides) in lay.views.items():
                 view = torch.as_strided(flat, shape, strides, off)
                 view.copy_(params[name].detach().to(torch.float32))
-                mod, attr = _resolve(net, name)
-                newp = torch.nn.Parameter(view, requires_grad=params[name].requires_grad)
-                mod._parameters[attr] = newp
+                # the Parameter OBJECT stays (optimizers, DDP reducers and EMA copies made before the first forward hold it, as
+                # training_loop.py:116-131 does); only its storage moves into the flat buffer
+                params[name].data = view
         self.flat = flat
         self.flat_grad = None
         self.shadow = None
@@ -214,6 +217,8 @@ class Engine:
         self._shadow_ver = -1
         self._dg_ver.clear()
         self._dg_desc.clear()
+        self._wpad.clear()
+        self._gwpad.clear()
 
     def is_attached(self, net) -> bool:
         if self.flat is None:
@@ -250,6 +255,16 @@ class Engine:
             self._shadow_ver = self._version()
 
     def _w(self, rec: ConvRec, dt: int) -> torch.Tensor:
+        if rec.kstride != rec.cin:  # network-input conv: the kernels want K in whole 128-byte chunks -> zero-padded operand copy
+            key = (rec.name, dt)
+            ent = self._wpad.get(key)
+            if ent is None or ent[0] != self._version():
+                buf = ent[1] if ent is not None else torch.zeros(rec.rows * rec.taps * rec.kstride, dtype=TORCH_DTYPE[dt], device=self.flat.device)
+                buf.view(rec.rows, rec.taps, rec.kstride)[:, :, : rec.cin].copy_(
+                    self.flat[rec.w_off: rec.w_off + rec.rows * rec.taps * rec.cin].view(rec.rows, rec.taps, rec.cin))
+                self._wpad[key] = (self._version(), buf)
+                ent = self._wpad[key]
+            return ent[1]
         if rec.lin or dt == DTYPE_F32:
             return self.flat[rec.w_off:]
         if self.shadow is None:
@@ -277,7 +292,7 @@ class Engine:
         if self._dg_ver.get(key, -1) != self._version():
             if key not in self._dg_desc:  # one launch for all matrices of the group: descriptor table built once
                 recs = [r for r in lay.convs.values() if r.dg_off >= 0 and r.lin == rec.lin]
-                tab = [v for r in recs for v in (r.w_off, r.dg_off, r.rows, r.taps, r.cin, r.kstride, r.dg_ld, int(bool(r.flip)))]
+                tab = [v for r in recs for v in (r.w_off, r.dg_off, r.rows, r.taps, r.cin, r.cin, r.dg_ld, int(bool(r.flip)))]
                 self._dg_desc[key] = (torch.tensor(tab, dtype=torch.int64, device=self.flat.device), len(recs))
             desc, n = self._dg_desc[key]
             if n:
@@ -290,6 +305,21 @@ class Engine:
 
     def _gb(self, rec: ConvRec) -> torch.Tensor:
         return self.flat_grad[rec.b_off:]
+
+    def _wgrad(self, rec: ConvRec, x: torch.Tensor, gy: torch.Tensor, g: dict, dt: int) -> None:
+        """dW (+ dbias) of ``rec`` into the flat gradient buffer; a padded-operand layer goes through a padded scratch."""
+        if rec.kstride == rec.cin:
+            ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
+            return
+        n = rec.rows * rec.taps * rec.kstride
+        buf = self._gwpad.get(rec.name)
+        if buf is None or buf.device != self.flat.device:
+            buf = self._gwpad[rec.name] = torch.zeros(n, dtype=torch.float32, device=self.flat.device)
+        else:
+            buf.zero_()
+        ops.conv_wgrad(x, gy, buf, g, dt, dbias=self._gb(rec))
+        self.flat_grad[rec.w_off: rec.w_off + rec.rows * rec.taps * rec.cin].view(rec.rows, rec.taps, rec.cin).add_(
+            buf.view(rec.rows, rec.taps, rec.kstride)[:, :, : rec.cin])
 
     # ------------------------------------------------------------------ small helpers
     @staticmethod
@@ -488,7 +518,7 @@ class Engine:
         cur, g_h0, r_h0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1)
         if train:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
-                ops.conv_wgrad(x0, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
+                self._wgrad(rec, x0, gy, g, dt)
                 tape.done(rec.w_off)
                 if not want_dx:
                     return None

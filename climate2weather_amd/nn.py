@@ -116,6 +116,14 @@ class UNet(torch.nn.Module):
         self.tails = torch.nn.ModuleList(reversed(tails))
         self.descent = torch.nn.ModuleList(descent)
         self.ascent = torch.nn.ModuleList(reversed(ascent))
+        # Conv2d weights take their final memory format NOW ([Cout][kh][kw][Cin] = channels_last, the K-contiguous operand of the
+        # implicit GEMM; same values, same OIHW shape).  The engine later only moves their storage into its flat buffer, with
+        # these strides: whatever captured the parameters in between -- torch DDP builds its bucket views from the strides it
+        # sees at construction and silently permutes gradients if they change -- keeps seeing the same layout.
+        with torch.no_grad():
+            for p in self.parameters():
+                if p.dim() == 4:
+                    p.data = p.data.contiguous(memory_format=torch.channels_last)
 
     # ---- static description consumed by the engine
     def spec(self) -> List[LevelSpec]:

@@ -33,3 +33,41 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_module_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
+    """The reference's own training-loop shape (training_loop.py:116,369-391): the module wrapped in torch DDP, autograd
+    backward, torch.optim.AdamW over net.parameters() -- the drop-in seam with nothing replaced but the class name."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import emu_ops
+    from climate2weather_amd import ops as c2w_ops
+    for name in emu_ops.ALL:
+        if hasattr(c2w_ops, name):
+            setattr(c2w_ops, name, getattr(emu_ops, name))
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score import ScoreUNet
+
+    g = np.load(os.path.join(golden_dir, "tiny_net.npz"))
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    pipe = SDAPipeline()
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    sl = slice(rank, rank + 1)
+    opt.zero_grad(set_to_none=True)
+    tt = t[sl].reshape(-1, 1, 1, 1)
+    xt = pipe.mu(tt) * x[sl] + pipe.sigma(tt) * eps[sl]  # src/thor/pipelines.py:22-25 with the golden noise injected
+    loss = ((ddp(xt, t[sl].reshape(-1)) - eps[sl]) ** 2).mean()
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+    opt.step()
+    torch.save(dict(loss=float(loss), grads=grads, sd={k: v.clone() for k, v in net.state_dict().items()}),
+               os.path.join(out_dir, f"mod{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

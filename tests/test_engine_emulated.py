@@ -61,15 +61,23 @@ def test_full_size_state_dict_fingerprint(golden_dir):
 def test_flatten_keeps_values_and_views(emu, golden_dir):
     net = _tiny()
     before = {k: v.clone() for k, v in net.state_dict().items()}
+    objs = {k: p for k, p in net.named_parameters()}
+    strides = {k: p.stride() for k, p in net.named_parameters()}
     eng = net._get_engine()
     assert eng.is_attached(net)
     for k, v in net.state_dict().items():
         assert torch.equal(v, before[k]), k
-    # parameters alias the flat buffer; conv weights are K-contiguous [co][kh][kw][ci]
+    # attaching moves storage only: the Parameter OBJECTS (what optimizers / DDP reducers / EMA copies captured before the first
+    # forward hold) and their strides (what DDP built its bucket views from) are unchanged, and every parameter is dense
+    for k, p in net.named_parameters():
+        assert p is objs[k] and p.stride() == strides[k], k
+        assert p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last), k
+        assert p.untyped_storage().data_ptr() == eng.flat.untyped_storage().data_ptr(), k
+    # conv weights are K-contiguous [co][kh][kw][ci] from construction on
     w = net.unet.descent[0][0].residue[1].weight
     assert w.stride() == (9 * 32, 1, 3 * 32, 32)
     w0 = net.unet.heads[0].weight
-    assert w0.shape == (32, 6, 3, 3) and w0.stride() == (9 * 64, 1, 3 * 64, 64)
+    assert w0.shape == (32, 6, 3, 3) and w0.stride() == (9 * 6, 1, 3 * 6, 6)
     # deepcopy / state_dict round trip / pickle
     import copy, pickle
     net2 = copy.deepcopy(net)
@@ -128,3 +136,24 @@ def test_input_gradient_and_jacrev(emu, golden_dir):
         return (net(xx, t) * w).sum()
     J = torch.func.jacrev(f, chunk_size=1)(x.detach())
     assert torch.allclose(J, gxo, atol=1e-5 + 2e-4 * gxo.abs().max().item())
+
+
+def test_optimizer_created_before_first_forward_trains_the_engine_weights(emu, golden_dir):
+    """training_loop.py:116-131 builds the optimizer (and DDP, EMA) from net.parameters() before any forward; the engine
+    attaches lazily at the first forward.  The step must land in the weights the engine computes with."""
+    g = _golden(golden_dir, "tiny_net.npz")
+    net = _tiny()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    loss = od.loss(net, x, t, eps).mean()
+    loss.backward()
+    opt.step()
+    from oracle import host as oh
+    for n, p in net.named_parameters():
+        p0, gr = torch.from_numpy(g["sd." + n]), torch.from_numpy(g["grad." + n])
+        exp = oh.adamw_step(p0, gr, torch.zeros_like(p0), torch.zeros_like(p0), 1, 1e-3)[0]
+        big = gr.abs() > 1e-5
+        assert torch.allclose(p.detach()[big], exp[big], atol=3e-6), n
+    with torch.no_grad():  # and the next forward uses the stepped weights (the engine sees the optimizer's in-place update)
+        y1 = net(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]))
+    assert (y1 - torch.from_numpy(g["y"])).abs().max().item() > 1e-5

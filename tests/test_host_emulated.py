@@ -424,3 +424,22 @@ def test_ensemble_driver_shards_members_by_rank(emu):
     truth = torch.rand(5, 2, 16, 16)
     rc = run_ensemble(net, world=1, rank=0, A=A, y=A(truth), std=torch.tensor([0.5, 0.5]).view(1, 2, 1, 1), gamma=1e-2, **dict(kw, num_samples=1))
     assert rc[0][1].shape == (5, 2, 16, 16)
+
+
+def test_module_under_torch_ddp_matches_golden_gradients(golden_dir, tmp_path):
+    """INTEGRATION.md section 1, "nothing else changes": ScoreUNet wrapped in torch's DistributedDataParallel (what
+    fabric.setup_module does, training_loop.py:116), autograd backward, torch.optim.AdamW.  Two gloo ranks, one item each:
+    the averaged gradients equal the golden gradients of the mean loss over the batch of 2, and the ranks stay identical."""
+    import torch.multiprocessing as mp
+    from _ddp_worker import run_module_ddp
+    mp.spawn(run_module_ddp, args=(2, _free_port(), golden_dir, str(tmp_path)), nprocs=2, join=True)
+    g = _golden(golden_dir, "tiny_net.npz")
+    r0, r1 = (torch.load(tmp_path / f"mod{r}.pt", weights_only=False) for r in (0, 1))
+    assert 0.5 * (r0["loss"] + r1["loss"]) == pytest.approx(float(g["loss"]), rel=1e-5)
+    for n, gr in r0["grads"].items():
+        ref = torch.from_numpy(g["grad." + n])
+        assert torch.equal(gr, r1["grads"][n]), n  # DDP averaged them
+        assert torch.allclose(gr, ref, atol=1e-5 + 2e-4 * ref.abs().max().item()), n
+    for k, v in r0["sd"].items():
+        assert torch.equal(v, r1["sd"][k]), k
+        assert not torch.equal(v, torch.from_numpy(g["sd." + k])) or v.numel() == 0  # the optimizer moved the weights
