@@ -368,3 +368,55 @@ def test_ensemble_driver_on_device():
         assert x.is_cuda and x.shape == (9, 2, 32, 32) and torch.isfinite(x).all()
     again = run_ensemble(net, world=2, rank=1, **kw)
     assert all(torch.equal(a[1], b[1]) for a, b in zip(out, again))
+
+
+def test_reference_style_training_loop_on_the_module_api(golden_dir, tmp_path):
+    """The reference's loop with only the class names changed: module -> .cuda() -> StandardEMA deep copies ->
+    torch.optim.AdamW(net.parameters()) -> [pipeline.loss(net, x).mean().backward(); optimizer.step(); ema.update()] -> snapshot.
+    Everything that captures parameters is created BEFORE the first forward, like training_loop.py:116-131.  fp32: first step
+    against the golden gradients / the oracle's AdamW; then autocast steps keep the loss finite and move the EMA."""
+    from climate2weather_amd.ema import StandardEMA
+    from climate2weather_amd.snapshot import load_network_snapshot, save_network_snapshot
+    g = _golden(golden_dir, "tiny_net.npz")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).cuda()
+    ema = StandardEMA(net, rates=[0.9])
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    pipe = SDAPipeline()
+    x, t, eps = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "eps"))
+    opt.zero_grad(set_to_none=True)
+    loss = od.loss(net, x, t, eps).mean()
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-4)
+    opt.step()
+    ema.update()
+    for n, p in net.named_parameters():
+        p0, gr = torch.from_numpy(g["sd." + n]), torch.from_numpy(g["grad." + n])
+        exp = oh.adamw_step(p0, gr, torch.zeros_like(p0), torch.zeros_like(p0), 1, 1e-3)[0]
+        _assert_adam_close(p.detach().cpu(), exp, gr, 1e-3, n)
+        e = dict(ema.emas[0].named_parameters())[n].detach().cpu()
+        assert torch.allclose(e, 0.9 * p0 + 0.1 * p.detach().cpu(), atol=1e-6), n
+    # the same loop under autocast (fabric precision "bf16-mixed") on a network whose channel counts suit the bf16 kernels
+    torch.manual_seed(4)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").cuda()
+    ema = StandardEMA(net, rates=[0.9])
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-3)
+    w_before = net.unet.heads[0].weight.detach().clone()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            l = pipe.loss(net, x).mean()
+        l.backward()
+        opt.step()
+        ema.update()
+        losses.append(l.item())
+    assert all(np.isfinite(losses)) and not torch.equal(net.unet.heads[0].weight.detach(), w_before)
+    assert not torch.equal(ema.emas[0].unet.heads[0].weight, w_before)
+    p = save_network_snapshot(str(tmp_path / "network-snapshot-0000001-0.900000.pkl"), ema.emas[0], pipe, dict(train=dict(window=3)))
+    snap = load_network_snapshot(p, device="cuda")
+    with torch.no_grad():
+        ya = ema.emas[0](x, t.reshape(-1))
+        yb = snap.ema(x, t.reshape(-1))
+    assert (ya - yb).abs().max().item() <= 2e-2 * ya.abs().max().item()  # the snapshot stores fp16 weights
