@@ -10,8 +10,6 @@ path runs.  ``net.precision = "fp32" | "bf16"`` pins it.
 """
 from __future__ import annotations
 
-import itertools
-import weakref
 from typing import Optional
 
 import torch
@@ -30,8 +28,16 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10
     return out.to(timesteps.dtype)
 
 
-_TAPES = {}
-_tape_ids = itertools.count()
+class _TapeHolder:
+    """Carries the backward tape from ``forward`` to ``setup_context``.  It travels as a (non-tensor) INPUT of the autograd
+    Function: ``setup_context`` receives the same input tuple however many times a functorch transform calls it, and the tape
+    lives exactly as long as something references the holder or the context -- no global table, no finalizers (a context of
+    a grad-disabled level can die between two ``setup_context`` calls of the same forward: seen under the reference's
+    ``torch.func.jacrev(log_p)`` with ``exact_grad=False``)."""
+    __slots__ = ("tape",)
+
+    def __init__(self):
+        self.tape = None
 
 
 class _ScoreUNetFn(torch.autograd.Function):
@@ -39,27 +45,24 @@ class _ScoreUNetFn(torch.autograd.Function):
     New-style (setup_context) so ``torch.func.jacrev`` / ``vjp`` can drive it (src/thor/score.py:28-33)."""
 
     @staticmethod
-    def forward(x, t, net, dt, *params):
+    def forward(x, t, net, dt, holder, *params):
         eng = net._get_engine()
         tape = Tape()
         y = eng.forward(x, t, dt, tape=tape, want_dx=True)
-        key = next(_tape_ids)
-        _TAPES[key] = tape
-        return y, key
+        holder.tape = tape
+        return y
 
     @staticmethod
     def setup_context(ctx, inputs, output):
-        x, t, net, dt = inputs[:4]
+        x, t, net, dt, holder = inputs[:5]
         ctx.net = net
-        key = output[1]
-        ctx.tape = _TAPES[key]
-        weakref.finalize(ctx, _TAPES.pop, key, None)
+        ctx.tape = holder.tape
         ctx.x_needs_grad = x.requires_grad
         ctx.set_materialize_grads(False)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gy, _gkey=None):
+    def backward(ctx, gy):
         from . import ops
         net = ctx.net
         eng: Engine = net._get_engine()
@@ -68,7 +71,7 @@ class _ScoreUNetFn(torch.autograd.Function):
         m = tape.meta
         n_params = len(lay.views)
         if gy is None:
-            return (None, None, None, None) + (None,) * n_params
+            return (None, None, None, None, None) + (None,) * n_params
         # gradients of this call only: use a private flat buffer so autograd's accumulation semantics hold
         saved = eng.flat_grad
         eng.flat_grad = torch.zeros_like(eng.flat)
@@ -82,7 +85,7 @@ class _ScoreUNetFn(torch.autograd.Function):
         finally:
             eng.flat_grad = saved
         grads = tuple(torch.as_strided(fg, shape, strides, off) for (off, shape, strides) in lay.views.values())
-        return (dx, None, None, None) + grads
+        return (dx, None, None, None, None) + grads
 
 
 class ScoreUNet(torch.nn.Module):
@@ -150,7 +153,7 @@ class ScoreUNet(torch.nn.Module):
         shape = x.shape
         x4 = x.reshape(-1, *shape[-3:]) if x.dim() != 4 else x
         if needs_grad or _in_functorch_transform(x):
-            y, _ = _ScoreUNetFn.apply(x4, t, self, dt, *params)
+            y = _ScoreUNetFn.apply(x4, t, self, dt, _TapeHolder(), *params)
         else:
             y = eng.forward(x4, t, dt)
         return y.reshape(shape).to(x.dtype)

@@ -1,0 +1,63 @@
+"""The seam the other way round: the REFERENCE's own sampler code (src/thor/score.py, src/thor/pipelines.py, loaded by path from
+/root/reference -- build container only, skipped elsewhere) driving THIS package's ScoreUNet, i.e. a user who changes nothing
+but `network_kwargs.class_name`.  HIP launchers are replaced by tests/emu_ops.py (CPU)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from climate2weather_amd import ops as c2w_ops
+from climate2weather_amd.score import ScoreUNet
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "thor")), reason="reference checkout not present")
+
+TINY = dict(embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_reference_sampler_drives_this_network(monkeypatch, golden_dir):
+    emu_ops.install(monkeypatch, c2w_ops)
+    ref_pipe = _load("ref_pipelines_seam", f"{REF}/src/thor/pipelines.py")
+    ref_score = _load("ref_score_seam", f"{REF}/src/thor/score.py")
+    s = {k: v for k, v in np.load(os.path.join(golden_dir, "sampler.npz"), allow_pickle=False).items()}
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).eval()
+    pipe = ref_pipe.SDAPipeline()
+    sf = ref_score.BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+    with torch.no_grad():
+        y = sf(torch.from_numpy(s["score_x"]), torch.tensor(0.7))
+    assert torch.allclose(y, torch.from_numpy(s["score_y"]), atol=2e-5)
+    # unconditioned trajectory (no corrector draws needed)
+    x = pipe.sample(sf, torch.from_numpy(s["uncond_c0.noise"]), steps=4, corrections=0, tau=0.5, show_progressbar=False)
+    ref = torch.from_numpy(s["uncond_c0.x"])
+    assert (x - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+    # guided trajectory: the reference's torch.func.jacrev wraps this network's forward (exact_grad False and True)
+    A = lambda z: torch.nn.functional.avg_pool2d(z[::2], 8)  # noqa: E731
+    for name, exact in (("cond_c0", False),):
+        sfc = ref_score.BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+        sfc.condition_on(A=A, y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=float(s["gamma"]), exact_grad=exact)
+        xc = pipe.sample(sfc, torch.from_numpy(s[name + ".noise"]), steps=4, corrections=0, tau=0.5, show_progressbar=False)
+        refc = torch.from_numpy(s[name + ".x"])
+        assert (xc - refc).abs().max().item() <= 3e-4 * refc.abs().max().item(), name
+    # exact_grad=True differentiates through the network inside jacrev: one guided score evaluation against this package's own
+    sfe = ref_score.BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+    sfe.condition_on(A=A, y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=float(s["gamma"]), exact_grad=True)
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score_fn import BatchedScoreFunction
+    mine = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=SDAPipeline())
+    mine.device_resident = False
+    mine.condition_on(A=A, y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=float(s["gamma"]), exact_grad=True)
+    xq = torch.from_numpy(s["score_x"])
+    e_ref = sfe(xq, torch.tensor(0.7))
+    e_mine = mine(xq, torch.tensor(0.7))
+    assert torch.allclose(e_ref, e_mine, rtol=1e-4, atol=1e-5)
