@@ -61,3 +61,46 @@ def test_reference_sampler_drives_this_network(monkeypatch, golden_dir):
     e_ref = sfe(xq, torch.tensor(0.7))
     e_mine = mine(xq, torch.tensor(0.7))
     assert torch.allclose(e_ref, e_mine, rtol=1e-4, atol=1e-5)
+
+
+def test_reference_loss_ema_and_default_score_function_with_this_network(monkeypatch, golden_dir):
+    """src/thor/pipelines.py::SDAPipeline.loss, src/thor/ema.py::StandardEMA (deep copies + zip over parameters()) and
+    src/thor/score.py::DefaultScoreFunction from the reference, over this package's ScoreUNet."""
+    emu_ops.install(monkeypatch, c2w_ops)
+    ref_pipe = _load("ref_pipelines_seam2", f"{REF}/src/thor/pipelines.py")
+    ref_score = _load("ref_score_seam2", f"{REF}/src/thor/score.py")
+    ref_ema = _load("ref_ema_seam2", f"{REF}/src/thor/ema.py")
+    g = {k: v for k, v in np.load(os.path.join(golden_dir, "tiny_net.npz"), allow_pickle=False).items()}
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY)
+    ema = ref_ema.StandardEMA(net, rates=[0.9, 0.999])
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-3)
+    pipe = ref_pipe.SDAPipeline()
+    x = torch.from_numpy(g["x"])
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss = pipe.loss(net, x).mean()  # draws t ~ U(0,1) and eps itself (src/thor/pipelines.py:27-35)
+        loss.backward()
+        opt.step()
+        ema.update()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    for (rate, m) in zip(ema.rates, ema.emas):
+        for n, p in m.named_parameters():
+            assert not torch.equal(p, before[n]) or p.numel() == 0, n
+    for m, tag in ema.get():
+        assert isinstance(m, ScoreUNet) and tag.startswith("-0.")
+    # the deep copies are independent networks with their own engines: same input, different (averaged) weights
+    xt, t = torch.from_numpy(g["xt"]), torch.from_numpy(g["t"])
+    with torch.no_grad():
+        assert not torch.allclose(net(xt, t), ema.emas[0](xt, t), atol=1e-7)
+    s = {k: v for k, v in np.load(os.path.join(golden_dir, "sampler.npz"), allow_pickle=False).items()}
+    torch.manual_seed(3)
+    fresh = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).eval()
+    dsf = ref_score.DefaultScoreFunction(fresh, markov_order=1, noise_process=pipe)
+    with torch.no_grad():
+        y = dsf(torch.from_numpy(s["score_x"]), torch.tensor(0.7))
+    assert torch.allclose(y, torch.from_numpy(s["score_y"]), atol=2e-5)
