@@ -157,3 +157,21 @@ def test_optimizer_created_before_first_forward_trains_the_engine_weights(emu, g
     with torch.no_grad():  # and the next forward uses the stepped weights (the engine sees the optimizer's in-place update)
         y1 = net(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]))
     assert (y1 - torch.from_numpy(g["y"])).abs().max().item() > 1e-5
+
+
+def test_fp16_snapshot_module_round_trip_runs(emu):
+    """training_loop.py:254-265 pickles ``deepcopy(ema).cpu().eval().requires_grad_(False).to(torch.float16)`` and
+    exp/downscaling.py:110-126 unpickles it and calls it: the half-precision module object itself must run (the engine keeps
+    fp32 master weights: the first forward upcasts the fp16 values)."""
+    import copy, pickle
+    net = _tiny()
+    x, t = torch.randn(1, 6, 16, 16), torch.tensor([0.3])
+    with torch.no_grad():
+        y0 = net(x, t)
+    snap = copy.deepcopy(net).cpu().eval().requires_grad_(False).to(torch.float16)
+    m = pickle.loads(pickle.dumps(dict(ema=snap)))["ema"]
+    assert next(m.parameters()).dtype == torch.float16 and not m.training
+    with torch.no_grad():
+        y1 = m(x, t)
+    assert y1.dtype == x.dtype
+    assert (y1 - y0).abs().max().item() <= 5e-3 * y0.abs().max().item()  # fp16 rounding of the weights only
