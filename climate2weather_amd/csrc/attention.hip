@@ -12,6 +12,8 @@
 bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype);
 int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st);
 int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, hipStream_t st);
+bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype);
+int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, hipStream_t st);
 
 namespace {
 
@@ -215,6 +217,8 @@ extern "C" int c2w_attention_forward(const void* qkv, void* o, float* lse, int B
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!qkv || !o || B <= 0 || Tn <= 0 || C <= 0 || C % P) return C2W_ERR_BAD_SHAPE;
     if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_forward(qkv, o, lse, B, C, (hipStream_t)stream);
+    if (c2w_attention_mfma_blocks_eligible(B, Tn, C, dtype))
+        return c2w_attention_mfma_blocks_forward(qkv, o, lse, B, Tn, C, (hipStream_t)stream);
     const int lds = (TR * C + TR * Tn) * 4;
     if (lds > 160 * 1024) return C2W_ERR_UNSUPPORTED;
     dim3 grid((Tn + TR - 1) / TR, B);

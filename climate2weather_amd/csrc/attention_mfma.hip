@@ -198,6 +198,92 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
     strip_times_lds(dbase + C, ld, a, B0, VP, C, w, li, lg);
 }
 
+// ---- forward for T = 64 * nb tokens (the 256^2 variant attends over 16 x 16 = 256): one workgroup per (image, block of 64
+// queries), key blocks of 64 walked with the online softmax (running row maximum m and sum l, output accumulators rescaled when
+// m grows), v_j staged in LDS per block, P_j through a wave-private LDS strip.  Same operand layouts as the T = 64 kernel.
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                                       float* __restrict__ lse, int Tn, int C, float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VP = C * 2 + 16;
+    char* const Vl = smem;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
+    char* const Pw = smem + T64 * VP + w * (16 * PP);  // this wave's 16 x 64 strip of P_j
+    const int ld = 3 * C, nb = Tn / T64, qb = blockIdx.x;
+    const bf16_t* base = qkv + (size_t)blockIdx.y * Tn * ld;
+    const bf16_t* qrow = base + (size_t)(qb * T64 + 16 * w + li) * ld + 8 * lg;
+
+    constexpr int MAXCT = 32;  // C <= 512
+    f32x4_t oacc[MAXCT];
+#pragma unroll
+    for (int ct = 0; ct < MAXCT; ++ct) oacc[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+
+    for (int j = 0; j < nb; ++j) {
+        __syncthreads();  // every wave is done with the previous v block
+        stage_rows(Vl, VP, base + (size_t)j * T64 * ld + 2 * C, ld, C);
+        f32x4_t s[4] = {};
+        {
+            const bf16_t* krow = base + (size_t)(j * T64 + li) * ld + C + 8 * lg;
+#pragma unroll 4
+            for (int ks = 0; ks < C / 32; ++ks) {
+                const bf16x8_t av = *(const bf16x8_t*)(qrow + 32 * ks);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const bf16x8_t bv = *(const bf16x8_t*)(krow + (size_t)(16 * n) * ld + 32 * ks);
+                    s[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, s[n], 0, 0, 0);
+                }
+            }
+        }
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                s[n][r] *= scale2;
+                mx = fmaxf(mx, s[n][r]);
+            }
+            mx = fmaxf(row16_max(mx), mrun[r]);
+            alpha[r] = __expf(mrun[r] - mx);  // exp(-inf) = 0 on the first block
+            float sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                s[n][r] = __expf(s[n][r] - mx);
+                sum += s[n][r];
+            }
+            lrun[r] = lrun[r] * alpha[r] + row16_sum(sum);
+            mrun[r] = mx;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) *(bf16_t*)(Pw + (4 * lg + r) * PP + (16 * n + li) * 2) = f32_to_bf16(s[n][r]);
+        }
+        __syncthreads();  // v_j staged (and this wave's P strip written)
+        bf16x8_t pa[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) pa[ks] = *(const bf16x8_t*)(Pw + li * PP + (32 * ks + 8 * lg) * 2);
+#pragma unroll
+        for (int ct = 0; ct < MAXCT; ++ct) {
+            if (ct * 16 < C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[ct][r] *= alpha[r];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], tr_frag(Vl, VP, 32 * ks, 16 * ct, li, lg), oacc[ct], 0, 0, 0);
+            }
+        }
+    }
+    bf16_t* ob = o + ((size_t)blockIdx.y * Tn + qb * T64 + 16 * w) * C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = 1.0f / lrun[r];
+#pragma unroll
+        for (int ct = 0; ct < MAXCT; ++ct)
+            if (ct * 16 < C) ob[(size_t)(4 * lg + r) * C + 16 * ct + li] = f32_to_bf16(oacc[ct][r] * inv);
+        if (lse != nullptr && li == 0) lse[(size_t)blockIdx.y * Tn + qb * T64 + 16 * w + 4 * lg + r] = mrun[r] + __logf(lrun[r]);
+    }
+}
+
 }  // namespace
 
 bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype) {
@@ -223,5 +309,22 @@ int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* l
         attr = true;
     }
     attn_mfma_bwd_kernel<<<B, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, (bf16_t*)dqkv, C, 1.0f / sqrtf((float)C));
+    return (int)hipGetLastError();
+}
+
+// forward only: T a multiple of 64 beyond 64 (the backward of those shapes stays on the fp32 VALU kernels)
+bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype) {
+    return dtype == C2W_DTYPE_BF16 && Tn > T64 && Tn % T64 == 0 && Tn <= 4096 && C % 32 == 0 && C <= 512 && B > 0 &&
+           getenv("C2W_ATTN_VALU") == nullptr;
+}
+
+int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, hipStream_t st) {
+    const int lds = T64 * (C * 2 + 16) + 4 * 16 * PP;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    attn_mfma_fwd_blocks_kernel<<<dim3(Tn / T64, B), 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, C, 1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }

@@ -440,7 +440,7 @@ def test_time_embedding_cast_transpose_adamw():
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("shape", [(2, 64, 512), (3, 16, 64), (1, 256, 128), (2, 4, 64), (5, 64, 128), (3, 64, 96)])  # T=64 bf16: matrix-core kernels
+@pytest.mark.parametrize("shape", [(2, 64, 512), (3, 16, 64), (1, 256, 128), (2, 4, 64), (5, 64, 128), (3, 64, 96), (2, 256, 512), (1, 192, 64)])  # bf16: T=64 and T=64n (online softmax over key blocks) on the matrix cores
 def test_attention(shape, dt):
     B, T, C = shape
     d = dev()
