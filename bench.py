@@ -37,7 +37,8 @@ def parse():
     p.add_argument("--vars", type=int, default=5, help="physical variables F (north_star: 5; reference recipe: 4)")
     p.add_argument("--markov-order", type=int, default=6)
     p.add_argument("--size", type=int, default=128)
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                   help="bf16 (default), fp16 (the reference's autocast type; dynamic loss scale on the device) or fp32 (parity mode)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--sample-steps", type=int, default=2, help="sampler steps timed after the headline run (0 = skip)")
     return p.parse_args()
@@ -164,7 +165,7 @@ def main():
         roof = None
         if k_ms:
             ach = flops_launch / (k_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="conv_patch_t3_kernel<16> (bf16) 128->128 @%dx%d (res-block conv fwd + dgrad, fused epilogues included)" % (a.size, a.size),
+            roof = dict(bound="mfma", kernel=f"conv_patch_t3_kernel<16> ({a.precision}) 128->128 @%dx%d (res-block conv fwd + dgrad, fused epilogues included)" % (a.size, a.size),
                         achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                         # HBM bytes per launch from the PMC passes of the same kernel and shape (FETCH_SIZE x2 gfx950 correction +
                         # WRITE_SIZE; profiles/r01g_pmc_conv_patch3_b128.md) -- equal to the algorithmic 537 MB in + 537 MB out

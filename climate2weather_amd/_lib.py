@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_long
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C2W_LIB") or os.path.join(HERE, "libc2w_hip.so")  # C2W_LIB: diagnostic builds only
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR = 0, 1, 2
 MUL_PLAIN, MUL_DSILU = 0, 1
@@ -51,6 +51,7 @@ _PROTOS = {
     "c2w_nchw_to_nhwc": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_nhwc_to_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_mse_loss_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "c2w_mse_loss_grad_scaled": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p],
     "c2w_timestep_embedding": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],
     "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
@@ -58,6 +59,11 @@ _PROTOS = {
     "c2w_weight_transpose_batched": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "c2w_adamw_ema": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
                       c_float, c_int, c_float, c_float, c_void_p],
+    "c2w_adamw_ema_scaled": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_float, c_float, c_float,
+                             c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p],
+    "c2w_grad_scaler_init": [c_void_p, c_float, c_void_p],
+    "c2w_grad_scaler_check": [c_void_p, c_longlong, c_void_p, c_void_p],
+    "c2w_grad_scaler_update": [c_void_p, c_float, c_float, c_int, c_void_p],
     "c2w_ema_update": [c_void_p, c_void_p, c_longlong, c_float, c_void_p],
     "c2w_attention_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_attention_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

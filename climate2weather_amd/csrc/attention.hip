@@ -10,10 +10,10 @@
 
 // matrix-core path for bf16, T = 64 (attention_mfma.hip)
 bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype);
-int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st);
-int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, hipStream_t st);
+int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, int dtype, hipStream_t st);
+int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, int dtype, hipStream_t st);
 bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype);
-int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, hipStream_t st);
+int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, hipStream_t st);
 
 namespace {
 
@@ -211,54 +211,54 @@ int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+template <typename T>
+int valu_forward(const void* qkv, void* o, float* lse, int Tn, int C, dim3 grid, int lds, hipStream_t st) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attn_fwd_kernel<T><<<grid, 256, lds, st>>>((const T*)qkv, (T*)o, lse, Tn, C);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int valu_backward(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv, int Tn, int C, long long rows,
+                  dim3 grid, int rgrid, int lds, hipStream_t st) {
+    rowdot_kernel<T><<<rgrid, 256, 0, st>>>((const T*)d_o, (const T*)o, delta_ws, rows, C);
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attn_bwd_kernel<T, 0><<<grid, 256, lds, st>>>((const T*)qkv, (const T*)d_o, lse, delta_ws, (T*)dqkv, Tn, C);
+    attn_bwd_kernel<T, 1><<<grid, 256, lds, st>>>((const T*)qkv, (const T*)d_o, lse, delta_ws, (T*)dqkv, Tn, C);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int c2w_attention_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, void* stream) {
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!qkv || !o || B <= 0 || Tn <= 0 || C <= 0 || C % P) return C2W_ERR_BAD_SHAPE;
-    if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_forward(qkv, o, lse, B, C, (hipStream_t)stream);
+    if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_forward(qkv, o, lse, B, C, dtype, (hipStream_t)stream);
     if (c2w_attention_mfma_blocks_eligible(B, Tn, C, dtype))
-        return c2w_attention_mfma_blocks_forward(qkv, o, lse, B, Tn, C, (hipStream_t)stream);
+        return c2w_attention_mfma_blocks_forward(qkv, o, lse, B, Tn, C, dtype, (hipStream_t)stream);
     const int lds = (TR * C + TR * Tn) * 4;
     if (lds > 160 * 1024) return C2W_ERR_UNSUPPORTED;
     dim3 grid((Tn + TR - 1) / TR, B);
-    if (dtype == C2W_DTYPE_F32) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attn_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)qkv, (float*)o, lse, Tn, C);
-    } else if (dtype == C2W_DTYPE_BF16) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attn_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, C);
-    } else {
-        return C2W_ERR_BAD_ARG;
-    }
-    return (int)hipGetLastError();
+    if (dtype == C2W_DTYPE_F32) return valu_forward<float>(qkv, o, lse, Tn, C, grid, lds, (hipStream_t)stream);
+    if (dtype == C2W_DTYPE_BF16) return valu_forward<bf16_t>(qkv, o, lse, Tn, C, grid, lds, (hipStream_t)stream);
+    if (dtype == C2W_DTYPE_F16) return valu_forward<f16_t>(qkv, o, lse, Tn, C, grid, lds, (hipStream_t)stream);
+    return C2W_ERR_BAD_ARG;
 }
 
 extern "C" int c2w_attention_backward(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv, int B,
                                       int Tn, int C, int dtype, void* stream) {
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!qkv || !o || !d_o || !lse || !delta_ws || !dqkv || B <= 0 || Tn <= 0 || C % P) return C2W_ERR_BAD_SHAPE;
-    if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_backward(qkv, d_o, lse, dqkv, B, C, (hipStream_t)stream);
+    if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_backward(qkv, d_o, lse, dqkv, B, C, dtype, (hipStream_t)stream);
     const int lds = (TR * C + 2 * TR * Tn) * 4;
     if (lds > 160 * 1024) return C2W_ERR_UNSUPPORTED;
     dim3 grid((Tn + TR - 1) / TR, B);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)B * Tn;
     const int rgrid = (int)((rows + 15) / 16 < 4096 ? (rows + 15) / 16 : 4096);
-    if (dtype == C2W_DTYPE_F32) {
-        rowdot_kernel<float><<<rgrid, 256, 0, st>>>((const float*)d_o, (const float*)o, delta_ws, rows, C);
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attn_bwd_kernel<float, 0><<<grid, 256, lds, st>>>((const float*)qkv, (const float*)d_o, lse, delta_ws, (float*)dqkv, Tn, C);
-        attn_bwd_kernel<float, 1><<<grid, 256, lds, st>>>((const float*)qkv, (const float*)d_o, lse, delta_ws, (float*)dqkv, Tn, C);
-    } else if (dtype == C2W_DTYPE_BF16) {
-        rowdot_kernel<bf16_t><<<rgrid, 256, 0, st>>>((const bf16_t*)d_o, (const bf16_t*)o, delta_ws, rows, C);
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attn_bwd_kernel<bf16_t, 0><<<grid, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws, (bf16_t*)dqkv, Tn, C);
-        attn_bwd_kernel<bf16_t, 1><<<grid, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws, (bf16_t*)dqkv, Tn, C);
-    } else {
-        return C2W_ERR_BAD_ARG;
-    }
-    return (int)hipGetLastError();
+    if (dtype == C2W_DTYPE_F32) return valu_backward<float>(qkv, o, d_o, lse, delta_ws, dqkv, Tn, C, rows, grid, rgrid, lds, st);
+    if (dtype == C2W_DTYPE_BF16) return valu_backward<bf16_t>(qkv, o, d_o, lse, delta_ws, dqkv, Tn, C, rows, grid, rgrid, lds, st);
+    if (dtype == C2W_DTYPE_F16) return valu_backward<f16_t>(qkv, o, d_o, lse, delta_ws, dqkv, Tn, C, rows, grid, rgrid, lds, st);
+    return C2W_ERR_BAD_ARG;
 }

@@ -61,6 +61,7 @@ __device__ __forceinline__ void stage_rows(char* dst, int pitch, const bf16_t* s
 }
 
 // acc[n] (+)= A-strip(16 rows of `a`, starting at row w*16) . B^T, both K-contiguous in HBM: the 16 x 64 strip of a b^T
+template <typename T>
 __device__ __forceinline__ void strip_abt(f32x4_t (&acc)[4], const bf16_t* a, const bf16_t* b, int ld, int C, int w, int li, int lg) {
     const bf16_t* ar = a + (size_t)(16 * w + li) * ld + 8 * lg;
     const bf16_t* br = b + (size_t)li * ld + 8 * lg;
@@ -70,23 +71,25 @@ __device__ __forceinline__ void strip_abt(f32x4_t (&acc)[4], const bf16_t* a, co
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ld + 32 * ks);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+            acc[n] = mfma16s<T>(av, bv, acc[n]);
         }
     }
 }
 
 // out strip (16 rows starting at 16 w) = A . M, K-dim 64:  A fragments a[ks] given, M[64][C] in LDS (pitch), all C/16 column tiles
+template <typename T>
 __device__ __forceinline__ void strip_times_lds(bf16_t* out, int ldo, const bf16x8_t (&a)[2], const char* M, int pitch, int C, int w, int li,
                                                 int lg) {
     for (int ct = 0; ct < C / 16; ++ct) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], tr_frag(M, pitch, 32 * ks, 16 * ct, li, lg), acc, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) acc = mfma16s<T>(a[ks], tr_frag(M, pitch, 32 * ks, 16 * ct, li, lg), acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(16 * w + 4 * lg + r) * ldo + 16 * ct + li] = f32_to_bf16(acc[r]);
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * w + 4 * lg + r) * ldo + 16 * ct + li] = f32_to_bits16<T>(acc[r]);
     }
 }
 
+template <typename T>  // T = bf16_t or f16_t: the operand format tag (pointers carry raw 16-bit patterns)
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                             int C, float scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const bf16_t* __rest
     stage_rows(Vl, VP, base + 2 * C, ld, C);
 
     f32x4_t s[4] = {};
-    strip_abt(s, base, base + C, ld, C, w, li, lg);
+    strip_abt<T>(s, base, base + C, ld, C, w, li, lg);
     // accumulator element s[n][r] = S[16 w + 4 lg + r][16 n + li]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -120,16 +123,17 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const bf16_t* __rest
         const float inv = 1.0f / sum;
         const int row = 16 * w + 4 * lg + r;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bf16(s[n][r] * inv);
+        for (int n = 0; n < 4; ++n) *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r] * inv);
         if (lse != nullptr && li == 0) lse[(size_t)blockIdx.x * T64 + row] = m + __logf(sum);
     }
     __syncthreads();
     bf16x8_t pa[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) pa[ks] = *(const bf16x8_t*)(Pl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
-    strip_times_lds(o + (size_t)blockIdx.x * T64 * C, C, pa, Vl, VP, C, w, li, lg);
+    strip_times_lds<T>(o + (size_t)blockIdx.x * T64 * C, C, pa, Vl, VP, C, w, li, lg);
 }
 
+template <typename T>  // T = bf16_t or f16_t: the operand format tag (pointers carry raw 16-bit patterns)
 __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int C, float scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
     stage_rows(B1, VP, dob, C, C);
 
     f32x4_t s[4] = {}, dp[4] = {};
-    strip_abt(s, base, base + C, ld, C, w, li, lg);  // q k^T
+    strip_abt<T>(s, base, base + C, ld, C, w, li, lg);  // q k^T
     {   // dO v^T: dO rows have pitch C, v rows pitch 3C -> two pointers, same loop shape as strip_abt
         const bf16_t* ar = dob + (size_t)(16 * w + li) * C + 8 * lg;
         const bf16_t* br = base + 2 * C + (size_t)li * ld + 8 * lg;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ld + 32 * ks);
-                dp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, dp[n], 0, 0, 0);
+                dp[n] = mfma16s<T>(av, bv, dp[n]);
             }
         }
     }
@@ -175,8 +179,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const float ds = s[n][r] * (dp[n][r] - delta) * scale2;
-            *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bf16(s[n][r]);
-            *(bf16_t*)(Sl + row * PP + (16 * n + li) * 2) = f32_to_bf16(ds);
+            *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r]);
+            *(bf16_t*)(Sl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(ds);
         }
     }
     __syncthreads();
@@ -184,23 +188,24 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
     // dq strip (query rows): dS . k
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a[ks] = *(const bf16x8_t*)(Sl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
-    strip_times_lds(dbase, ld, a, B0, VP, C, w, li, lg);
+    strip_times_lds<T>(dbase, ld, a, B0, VP, C, w, li, lg);
     // dv strip (key rows): P^T . dO  -- A[m = key][k = query] = P[query][key]: transposing read of the P tile
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Pl, PP, 32 * ks, 16 * w, li, lg);
-    strip_times_lds(dbase + 2 * C, ld, a, B1, VP, C, w, li, lg);
+    strip_times_lds<T>(dbase + 2 * C, ld, a, B1, VP, C, w, li, lg);
     __syncthreads();  // every wave is done with k before q replaces it
     stage_rows(B0, VP, base, ld, C);
     __syncthreads();
     // dk strip (key rows): dS^T . q
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Sl, PP, 32 * ks, 16 * w, li, lg);
-    strip_times_lds(dbase + C, ld, a, B0, VP, C, w, li, lg);
+    strip_times_lds<T>(dbase + C, ld, a, B0, VP, C, w, li, lg);
 }
 
 // ---- forward for T = 64 * nb tokens (the 256^2 variant attends over 16 x 16 = 256): one workgroup per (image, block of 64
 // queries), key blocks of 64 walked with the online softmax (running row maximum m and sum l, output accumulators rescaled when
 // m grows), v_j staged in LDS per block, P_j through a wave-private LDS strip.  Same operand layouts as the T = 64 kernel.
+template <typename T>  // T = bf16_t or f16_t: the operand format tag (pointers carry raw 16-bit patterns)
 __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                                        float* __restrict__ lse, int Tn, int C, float scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const bf16x8_t bv = *(const bf16x8_t*)(krow + (size_t)(16 * n) * ld + 32 * ks);
-                    s[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, s[n], 0, 0, 0);
+                    s[n] = mfma16s<T>(av, bv, s[n]);
                 }
             }
         }
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16
             lrun[r] = lrun[r] * alpha[r] + row16_sum(sum);
             mrun[r] = mx;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) *(bf16_t*)(Pw + (4 * lg + r) * PP + (16 * n + li) * 2) = f32_to_bf16(s[n][r]);
+            for (int n = 0; n < 4; ++n) *(bf16_t*)(Pw + (4 * lg + r) * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r]);
         }
         __syncthreads();  // v_j staged (and this wave's P strip written)
         bf16x8_t pa[2];
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16
                 for (int r = 0; r < 4; ++r) oacc[ct][r] *= alpha[r];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], tr_frag(Vl, VP, 32 * ks, 16 * ct, li, lg), oacc[ct], 0, 0, 0);
+                    oacc[ct] = mfma16s<T>(pa[ks], tr_frag(Vl, VP, 32 * ks, 16 * ct, li, lg), oacc[ct]);
             }
         }
     }
@@ -279,52 +284,68 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16
         const float inv = 1.0f / lrun[r];
 #pragma unroll
         for (int ct = 0; ct < MAXCT; ++ct)
-            if (ct * 16 < C) ob[(size_t)(4 * lg + r) * C + 16 * ct + li] = f32_to_bf16(oacc[ct][r] * inv);
+            if (ct * 16 < C) ob[(size_t)(4 * lg + r) * C + 16 * ct + li] = f32_to_bits16<T>(oacc[ct][r] * inv);
         if (lse != nullptr && li == 0) lse[(size_t)blockIdx.y * Tn + qb * T64 + 16 * w + 4 * lg + r] = mrun[r] + __logf(lrun[r]);
     }
 }
 
 }  // namespace
 
+static bool is16(int dtype) { return dtype == C2W_DTYPE_BF16 || dtype == C2W_DTYPE_F16; }
+
 bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype) {
-    return dtype == C2W_DTYPE_BF16 && Tn == T64 && C % 32 == 0 && C <= 512 && B > 0 && getenv("C2W_ATTN_VALU") == nullptr;
+    return is16(dtype) && Tn == T64 && C % 32 == 0 && C <= 512 && B > 0 && getenv("C2W_ATTN_VALU") == nullptr;
 }
 
-int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st) {
+namespace {
+template <typename T>
+int fwd_launch(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st) {
     const int lds = T64 * (C * 2 + 16) + T64 * PP;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    attn_mfma_fwd_kernel<<<B, 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, C, 1.0f / sqrtf((float)C));
+    attn_mfma_fwd_kernel<T><<<B, 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, C, 1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
-
-int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, hipStream_t st) {
+template <typename T>
+int bwd_launch(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, hipStream_t st) {
     const int lds = 2 * T64 * (C * 2 + 16) + 2 * T64 * PP;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    attn_mfma_bwd_kernel<<<B, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, (bf16_t*)dqkv, C, 1.0f / sqrtf((float)C));
+    attn_mfma_bwd_kernel<T><<<B, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, (bf16_t*)dqkv, C, 1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
+}
+template <typename T>
+int blocks_launch(const void* qkv, void* o, float* lse, int B, int Tn, int C, hipStream_t st) {
+    const int lds = T64 * (C * 2 + 16) + 4 * 16 * PP;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_blocks_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    attn_mfma_fwd_blocks_kernel<T><<<dim3(Tn / T64, B), 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, C, 1.0f / sqrtf((float)C));
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int C, int dtype, hipStream_t st) {
+    return dtype == C2W_DTYPE_F16 ? fwd_launch<f16_t>(qkv, o, lse, B, C, st) : fwd_launch<bf16_t>(qkv, o, lse, B, C, st);
+}
+
+int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, int dtype, hipStream_t st) {
+    return dtype == C2W_DTYPE_F16 ? bwd_launch<f16_t>(qkv, d_o, lse, dqkv, B, C, st) : bwd_launch<bf16_t>(qkv, d_o, lse, dqkv, B, C, st);
 }
 
 // forward only: T a multiple of 64 beyond 64 (the backward of those shapes stays on the fp32 VALU kernels)
 bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype) {
-    return dtype == C2W_DTYPE_BF16 && Tn > T64 && Tn % T64 == 0 && Tn <= 4096 && C % 32 == 0 && C <= 512 && B > 0 &&
-           getenv("C2W_ATTN_VALU") == nullptr;
+    return is16(dtype) && Tn > T64 && Tn % T64 == 0 && Tn <= 4096 && C % 32 == 0 && C <= 512 && B > 0 && getenv("C2W_ATTN_VALU") == nullptr;
 }
 
-int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, hipStream_t st) {
-    const int lds = T64 * (C * 2 + 16) + 4 * 16 * PP;
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    attn_mfma_fwd_blocks_kernel<<<dim3(Tn / T64, B), 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, C, 1.0f / sqrtf((float)C));
-    return (int)hipGetLastError();
+int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, hipStream_t st) {
+    return dtype == C2W_DTYPE_F16 ? blocks_launch<f16_t>(qkv, o, lse, B, Tn, C, st) : blocks_launch<bf16_t>(qkv, o, lse, B, Tn, C, st);
 }

@@ -1,7 +1,9 @@
 // Shared device helpers for the gfx950 (CDNA4) kernels of climate2weather_amd.
 // Wave = 64 lanes everywhere.  Activations are NHWC ("pixel rows" of C channels);
-// T is the storage type: float (parity mode) or bf16 (throughput mode); all
-// arithmetic outside the MFMA operands is fp32.
+// T is the storage type: float (parity mode), bf16 (throughput mode) or fp16 (the
+// reference's autocast type, train.py:98 "16-mixed"; 10 mantissa bits, narrow range:
+// training in it needs the loss scale of c2w_grad_scaler_*); all arithmetic outside
+// the MFMA operands is fp32.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,6 +14,9 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 typedef uint16_t bf16_t;  // raw bf16 bits
+typedef _Float16 f16_t;   // IEEE half: a distinct 2-byte type, so templates tell the two 16-bit formats apart
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 #define C2W_OOB 0x80000000u  // buffer voffset that is always out of range (-> loads return 0)
 
@@ -23,6 +28,45 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
+
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {  // RNE each (v_cvt_f16_f32), overflow -> inf
+    return __builtin_bit_cast(uint32_t, (f16x2_t){(_Float16)lo, (_Float16)hi});
+}
+// two 16-bit storage values in one dword <-> fp32
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t v, float& lo, float& hi) {
+    lo = __uint_as_float(v << 16);
+    hi = __uint_as_float(v & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t v, float& lo, float& hi) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, v);
+    lo = (float)h[0];
+    hi = (float)h[1];
+}
+// scalar store conversion of the 16-bit types (raw bits)
+template <typename T> __device__ __forceinline__ uint16_t f32_to_bits16(float f);
+template <> __device__ __forceinline__ uint16_t f32_to_bits16<bf16_t>(float f) { return f32_to_bf16(f); }
+template <> __device__ __forceinline__ uint16_t f32_to_bits16<f16_t>(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+
+// one matrix-core step on 16-bit operands: 16x16 tile, K = 32 (8 values per lane in 16 B)
+template <typename T> __device__ __forceinline__ f32x4_t mfma16(const u32x4_t& a, const u32x4_t& b, const f32x4_t& c);
+template <> __device__ __forceinline__ f32x4_t mfma16<bf16_t>(const u32x4_t& a, const u32x4_t& b, const f32x4_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma16<f16_t>(const u32x4_t& a, const u32x4_t& b, const f32x4_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// same on operands held as eight 16-bit patterns
+template <typename T> __device__ __forceinline__ f32x4_t mfma16s(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {
+    return mfma16<T>(__builtin_bit_cast(u32x4_t, a), __builtin_bit_cast(u32x4_t, b), c);
+}
+// operand of eight ones (column sums through the matrix core: the bias gradient)
+template <typename T> __device__ __forceinline__ u32x4_t ones16();
+template <> __device__ __forceinline__ u32x4_t ones16<bf16_t>() { return (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }
+template <> __device__ __forceinline__ u32x4_t ones16<f16_t>() { return (u32x4_t){0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -38,6 +82,13 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+template <> struct Elem<f16_t> {
+    static constexpr int SZ = 2;
+    static constexpr int PER16 = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (_Float16)v; }
+};
+
 // 16-byte vector <-> fp32 lanes
 template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& v, float* f);
 template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& v, float* f) {
@@ -51,6 +102,10 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& v, f
         f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
     }
 }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const u32x4_t& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2<f16_t>(v[i], f[2 * i], f[2 * i + 1]);
+}
 template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
 template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
     u32x4_t v;
@@ -62,6 +117,13 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
     u32x4_t v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+template <> __device__ __forceinline__ u32x4_t pack16<f16_t>(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_f16x2(f[2 * i], f[2 * i + 1]);
     return v;
 }
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ void epi_acc_to_lds_impl(char* O, int OS, const f32x4
             if constexpr (sizeof(T) == 4) {
                 *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
             } else {
-                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
             }
         }
     }
@@ -124,7 +124,7 @@ struct EpiStore {
     // Same arithmetic, in the same order, as ln_bwd_kernel (pointwise.hip): 16 lanes share a pixel row.
     // `red`: 128 floats of LDS outside O, zeroed by the caller before the barrier that precedes this call.
     __device__ __forceinline__ void finish_ln(const C2wConvArgs& p, const char* O, int OS, int tid, int img, float* red) {
-        static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN backward: bf16 tiles only");
+        static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN backward: 16-bit tiles only");
         typedef __attribute__((ext_vector_type(2))) float f2;  // pairs -> v_pk_{add,mul,fma}_f32: half the VALU issue slots
         const int cs = tid & (SEGS - 1);
         f2 m2[4];
@@ -142,7 +142,11 @@ struct EpiStore {
         for (int k = 0; k < 4; ++k) am[k] = (f2){0.f, 0.f};
         auto unpack2 = [](const u32x4_t& v, f2* f) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) f[k] = (f2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+            for (int k = 0; k < 4; ++k) {
+                float lo, hi;
+                ::unpack2<T>(v[k], lo, hi);
+                f[k] = (f2){lo, hi};
+            }
         };
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -186,7 +190,7 @@ struct EpiStore {
             }
             u32x4_t out;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(o[k][0], o[k][1]);
+            for (int k = 0; k < 4; ++k) out[k] = pack2<T>(o[k][0], o[k][1]);
             if (off[i] >= 0) *(u32x4_t*)((char*)p.y + off[i]) = out;
         }
         if (p.ln_dm != nullptr) {
@@ -207,7 +211,7 @@ struct EpiStore {
     // ---- fused LayerNorm FORWARD of the consumer (bf16 tile with whole 128-channel rows of one image `img`):
     //   y = O (+ res), stored; lnf_y = LN_C(y_as_stored + lnf_m[img])  -- the arithmetic of ln_fwd_kernel (two-pass variance)
     __device__ __forceinline__ void finish_lnf(const C2wConvArgs& p, const char* O, int OS, int tid, int img) {
-        static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN forward: bf16 tiles only");
+        static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN forward: 16-bit tiles only");
         typedef __attribute__((ext_vector_type(2))) float f2;
         const int cs = tid & (SEGS - 1);
         f2 m2[4];
@@ -222,7 +226,11 @@ struct EpiStore {
         const float inv_den = 1.0f / (float)(128 - (p.ln_unbiased ? 1 : 0));
         auto unpack2 = [](const u32x4_t& v, f2* f) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) f[k] = (f2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+            for (int k = 0; k < 4; ++k) {
+                float lo, hi;
+                ::unpack2<T>(v[k], lo, hi);
+                f[k] = (f2){lo, hi};
+            }
         };
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -237,7 +245,7 @@ struct EpiStore {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     u[k] += r[k];
-                    out[k] = pack_bf16x2(u[k][0], u[k][1]);
+                    out[k] = pack2<T>(u[k][0], u[k][1]);
                 }
             }
             if (off[i] >= 0) *(u32x4_t*)((char*)p.y + off[i]) = out;
@@ -258,7 +266,7 @@ struct EpiStore {
             const float rs = __builtin_amdgcn_rsqf(sub16(q2[0] + q2[1]) * inv_den + p.ln_eps);
             u32x4_t ln;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ln[k] = pack_bf16x2(u[k][0] * rs, u[k][1] * rs);
+            for (int k = 0; k < 4; ++k) ln[k] = pack2<T>(u[k][0] * rs, u[k][1] * rs);
             if (off[i] >= 0) *(u32x4_t*)((char*)p.lnf_y + off[i]) = ln;
         }
     }

@@ -38,7 +38,7 @@ bool c2w_conv_patch_eligible(const C2wConvArgs& a);
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st);
 // bf16 variant on 16x16-pixel tiles with a 32-channel weight ring (conv_patch3.hip)
 bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype);
-int c2w_conv_patch3(const C2wConvArgs& a, hipStream_t st);
+int c2w_conv_patch3(const C2wConvArgs& a, int dtype, hipStream_t st);
 
 // halo-patch weight-gradient kernel for the same convolutions (wgrad_patch.hip)
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a);

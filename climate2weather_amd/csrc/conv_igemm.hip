@@ -40,9 +40,10 @@ template <int NW> struct GCfg {
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    }
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) { c = mfma16<bf16_t>(a, b, c); }
+};
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) { c = mfma16<f16_t>(a, b, c); }
 };
 template <> struct Mma<float> {
     __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
@@ -342,7 +343,7 @@ extern "C" int c2w_conv_patch_supported(const C2wConvArgs* a, int dtype) {
 }
 
 extern "C" int c2w_conv_lnfwd_supported(const C2wConvArgs* a, int dtype) {
-    if (a == nullptr || dtype != C2W_DTYPE_BF16) return 0;
+    if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE || a->ln_x != nullptr) return 0;
     return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr &&
                    getenv("C2W_NO_LNF") == nullptr
@@ -351,7 +352,7 @@ extern "C" int c2w_conv_lnfwd_supported(const C2wConvArgs* a, int dtype) {
 }
 
 extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
-    if (a == nullptr || dtype != C2W_DTYPE_BF16) return 0;
+    if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE) return 0;
     return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr ? 1 : 0;
 }
@@ -371,5 +372,6 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, naive, st);
+    if (dtype == C2W_DTYPE_F16) return launch_dtype<f16_t>(*a, naive, st);
     return C2W_ERR_BAD_ARG;
 }

@@ -29,9 +29,10 @@ constexpr int LDS_MAIN = WBASE + 3 * WBYTES;  // 159,744 B of the CU's 163,840
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    }
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) { c = mfma16<bf16_t>(a, b, c); }
+};
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) { c = mfma16<f16_t>(a, b, c); }
 };
 template <> struct Mma<float> {
     __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
@@ -478,9 +479,10 @@ bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // images that 8 x 16-pixe
 }
 
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {
-    if (c2w_conv_patch3_wanted(a, dtype)) return c2w_conv_patch3(a, st);
+    if (c2w_conv_patch3_wanted(a, dtype)) return c2w_conv_patch3(a, dtype, st);
     if (dtype == C2W_DTYPE_F32) return launch<float>(a, st);
     if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, st);
+    if (dtype == C2W_DTYPE_F16) return launch<f16_t>(a, st);
     return C2W_ERR_BAD_ARG;
 }
 

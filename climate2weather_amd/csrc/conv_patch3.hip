@@ -68,9 +68,9 @@ __device__ __forceinline__ void t3_wait(int outstanding) {
     }
 }
 
-template <int TR>
+template <int TR, typename T = bf16_t>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
 __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch_t3_kernel(const C2wConvArgs p) {
-    typedef bf16_t T;
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
     typedef T3Cfg<TR> CF;
     constexpr int ESZ = 2;
     constexpr int NB = CF::NB;
@@ -197,8 +197,7 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if constexpr ((C2W_EXP & 1) == 0) {
-                    acc[n >> 2][m][n & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[m]),
-                                                                                     __builtin_bit_cast(bf16x8_t, bq[n]), acc[n >> 2][m][n & 3], 0, 0, 0);
+                    acc[n >> 2][m][n & 3] = mfma16<T>(a[m], bq[n], acc[n >> 2][m][n & 3]);
                 } else {
                     asm volatile("" ::"v"(a[m]), "v"(bq[n]));
                 }
@@ -248,17 +247,17 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
     }
 }
 
-template <int TR>
+template <int TR, typename T>
 int t3_launch(const C2wConvArgs& a, hipStream_t st) {
     typedef T3Cfg<TR> CF;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr = true;
     }
     const int nN = (a.Cout + 127) / 128;
     const int nM = a.B * (a.Hin / TR) * (a.Win >> 4);
-    conv_patch_t3_kernel<TR><<<nM * nN, T3_NTHR, CF::LDS, st>>>(a);
+    conv_patch_t3_kernel<TR, T><<<nM * nN, T3_NTHR, CF::LDS, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -270,9 +269,11 @@ int t3_launch(const C2wConvArgs& a, hipStream_t st) {
 // workgroups per CU) measured no faster than conv_patch_half_kernel and is not dispatched.
 bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype) {
     static const int mode = getenv("C2W_CONV_T3") ? atoi(getenv("C2W_CONV_T3")) : -1;
-    if (dtype != C2W_DTYPE_BF16 || mode == 0 || (a.Hin & 15) != 0 || (a.Win & 15) != 0) return false;
+    if ((dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16) || mode == 0 || (a.Hin & 15) != 0 || (a.Win & 15) != 0) return false;
     const long long wgs = (long long)a.B * (a.Hin >> 4) * (a.Win >> 4) * ((a.Cout + 127) / 128);
     return mode == 16 || wgs >= 1024;
 }
 
-int c2w_conv_patch3(const C2wConvArgs& a, hipStream_t st) { return t3_launch<16>(a, st); }
+int c2w_conv_patch3(const C2wConvArgs& a, int dtype, hipStream_t st) {
+    return dtype == C2W_DTYPE_F16 ? t3_launch<16, f16_t>(a, st) : t3_launch<16, bf16_t>(a, st);
+}

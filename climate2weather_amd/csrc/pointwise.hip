@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 //   dy[b][pix][c] = 2 (y - eps) * scale / N   (NHWC T, padded channels = 0);  loss_sum += sum (y-eps)^2 (fp32 atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void mse_loss_grad_kernel(const T* __restrict__ y, const float* __restrict__ eps, T* __restrict__ dy,
-                                                            float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale) {
+                                                            float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale,
+                                                            const float* __restrict__ dscale) {
+    if (dscale != nullptr) gscale *= dscale[0];  // dynamic loss scale (c2w_grad_scaler_*), read on the device
     constexpr int P = Elem<T>::PER16;
     const int nvec = ldc / P;
     const long long total = (long long)B * HW * nvec;
@@ -426,7 +428,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __
 
 template <typename T>
 __global__ __launch_bounds__(256) void mse_loss_grad_tiled_kernel(const T* __restrict__ y, const float* __restrict__ eps, T* __restrict__ dy,
-                                                                  float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale) {
+                                                                  float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale,
+                                                                  const float* __restrict__ dscale) {
+    if (dscale != nullptr) gscale *= dscale[0];
     constexpr int P = Elem<T>::PER16;
     extern __shared__ float lt_tile[];
     const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
@@ -573,10 +577,29 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const flo
 }
 
 // Fused AdamW (torch.optim.AdamW, train.py:176-181) + EMA (src/thor/ema.py:23-27) + low-precision shadow refresh.
+// With a scaler state (c2w_grad_scaler_*): gradients are divided by the loss scale; a step whose gradients held inf/nan changes
+// nothing but the EMA (GradScaler.step skips optimizer.step, the reference still calls ema.update: training_loop.py:383-389);
+// the bias corrections count the steps actually taken (state[3], on the device -- the host never learns about a skip).
+template <typename TS>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ shadow,
+                                                        float* __restrict__ v, float* __restrict__ ema, TS* __restrict__ shadow,
                                                         long long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                                        float bc2_sqrt, float ema_rate, float grad_scale) {
+                                                        float bc2_sqrt, float ema_rate, float grad_scale,
+                                                        const float* __restrict__ scaler) {
+    bool skip = false;
+    if (scaler != nullptr) {
+        grad_scale /= scaler[0];
+        skip = scaler[2] != 0.f;
+        const double step = (double)scaler[3] + 1.0;
+        bc1 = (float)(1.0 - pow((double)beta1, step));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    }
+    if (skip) {
+        if (ema)
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+                ema[i] = ema_rate * ema[i] + (1.f - ema_rate) * p[i];
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
         float pi = p[i] * (1.f - lr * wd);
@@ -588,8 +611,44 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
         m[i] = mi;
         v[i] = vi;
         if (ema) ema[i] = ema_rate * ema[i] + (1.f - ema_rate) * pi;
-        if (shadow) shadow[i] = f32_to_bf16(pi);
+        if (shadow) Elem<TS>::st(shadow + i, pi);
     }
+}
+
+// ---- dynamic loss scale, device resident.  state = {scale, growth tracker, found_inf, optimizer steps taken}
+__global__ __launch_bounds__(256) void scaler_check_kernel(const float* __restrict__ g, long long n, float* __restrict__ state) {
+    bool bad = false;
+    const long long nv = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4_t q = *(const f32x4_t*)(g + 4 * i);
+        // finite <=> exponent field not all ones
+        bad |= ((__float_as_uint(q[0]) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(q[1]) & 0x7f800000u) == 0x7f800000u) |
+               ((__float_as_uint(q[2]) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(q[3]) & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= (__float_as_uint(g[(nv << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.f;  // benign race: every writer stores the same value
+}
+
+__global__ void scaler_init_kernel(float* __restrict__ state, float init_scale) {
+    if (threadIdx.x < 4) state[threadIdx.x] = threadIdx.x == 0 ? init_scale : 0.f;
+}
+
+__global__ void scaler_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[2] != 0.f) {
+        state[0] *= backoff;
+        state[1] = 0.f;
+    } else {
+        state[3] += 1.f;
+        const float tr = state[1] + 1.f;
+        if (tr >= (float)interval) {
+            state[0] *= growth;
+            state[1] = 0.f;
+        } else {
+            state[1] = tr;
+        }
+    }
+    state[2] = 0.f;
 }
 
 // src/thor/ema.py:23-27 over a flat buffer
@@ -610,6 +669,7 @@ inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
     do {                                                                                \
         if ((dtype) == C2W_DTYPE_F32) { using T = float; CALL; }                        \
         else if ((dtype) == C2W_DTYPE_BF16) { using T = bf16_t; CALL; }                 \
+        else if ((dtype) == C2W_DTYPE_F16) { using T = f16_t; CALL; }                   \
         else return C2W_ERR_BAD_ARG;                                                    \
     } while (0)
 
@@ -726,20 +786,25 @@ extern "C" int c2w_nhwc_to_nchw(const void* y, float* out, int B, int C, int HW,
     return (int)hipGetLastError();
 }
 
-extern "C" int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc, float gscale,
-                                 int dtype, void* stream) {
+extern "C" int c2w_mse_loss_grad_scaled(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc, float gscale,
+                                        const float* scaler_state, int dtype, void* stream) {
     if (!y || !eps || !dy || !loss_sum || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
     if (lds <= 64 * 1024) {
         const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 2048);
         DISPATCH_T(dtype, (mse_loss_grad_tiled_kernel<T><<<nblk, 256, lds, (hipStream_t)stream>>>((const T*)y, eps, (T*)dy, loss_sum, B, C, HW,
-                                                                                                  ldc, gscale)));
+                                                                                                  ldc, gscale, scaler_state)));
         return (int)hipGetLastError();
     }
     DISPATCH_T(dtype, (mse_loss_grad_kernel<T><<<grid_for((long long)B * HW * (ldc / P), 256, 2048), 256, 0, (hipStream_t)stream>>>(
-                          (const T*)y, eps, (T*)dy, loss_sum, B, C, HW, ldc, gscale)));
+                          (const T*)y, eps, (T*)dy, loss_sum, B, C, HW, ldc, gscale, scaler_state)));
     return (int)hipGetLastError();
+}
+
+extern "C" int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc, float gscale,
+                                 int dtype, void* stream) {
+    return c2w_mse_loss_grad_scaled(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, nullptr, dtype, stream);
 }
 
 extern "C" int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {
@@ -774,13 +839,44 @@ extern "C" int c2w_weight_transpose_batched(const float* flat, void* out, const 
     return (int)hipGetLastError();
 }
 
-extern "C" int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int step, float ema_rate, float grad_scale, void* stream) {
+extern "C" int c2w_adamw_ema_scaled(float* p, const float* g, float* m, float* v, float* ema, void* shadow, int shadow_dtype, long long n,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float ema_rate,
+                                    float grad_scale, const float* scaler_state, void* stream) {
     if (!p || !g || !m || !v || step < 1) return C2W_ERR_BAD_ARG;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    adamw_ema_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps,
-                                                                   weight_decay, bc1, bc2_sqrt, ema_rate, grad_scale);
+    if (shadow != nullptr && shadow_dtype == C2W_DTYPE_F16)
+        adamw_ema_kernel<f16_t><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (f16_t*)shadow, n, lr, beta1, beta2, eps,
+                                                                              weight_decay, bc1, bc2_sqrt, ema_rate, grad_scale, scaler_state);
+    else if (shadow == nullptr || shadow_dtype == C2W_DTYPE_BF16)
+        adamw_ema_kernel<bf16_t><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, ema, (bf16_t*)shadow, n, lr, beta1, beta2, eps,
+                                                                               weight_decay, bc1, bc2_sqrt, ema_rate, grad_scale, scaler_state);
+    else
+        return C2W_ERR_BAD_ARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float ema_rate, float grad_scale, void* stream) {
+    return c2w_adamw_ema_scaled(p, g, m, v, ema, shadow_bf16, C2W_DTYPE_BF16, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate,
+                                grad_scale, nullptr, stream);
+}
+
+extern "C" int c2w_grad_scaler_init(float* state, float init_scale, void* stream) {
+    if (!state || !(init_scale > 0.f)) return C2W_ERR_BAD_ARG;
+    scaler_init_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, init_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_grad_scaler_check(const float* g, long long n, float* state, void* stream) {
+    if (!g || !state || n <= 0 || ((uintptr_t)g & 15) != 0) return C2W_ERR_BAD_ARG;
+    scaler_check_kernel<<<grid_for(n / 4 + 1, 256, 4096), 256, 0, (hipStream_t)stream>>>(g, n, state);
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, void* stream) {
+    if (!state || growth_interval < 1) return C2W_ERR_BAD_ARG;
+    scaler_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, growth, backoff, growth_interval);
     return (int)hipGetLastError();
 }
 

@@ -185,6 +185,8 @@ extern "C" int c2w_window_gather(const float* x, void* y, int nw, int F, int HW,
         window_gather_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (float*)y, nw, CW, HW, (long long)F * HW, i0, ldc);
     else if (dtype == C2W_DTYPE_BF16)
         window_gather_kernel<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, nw, CW, HW, (long long)F * HW, i0, ldc);
+    else if (dtype == C2W_DTYPE_F16)
+        window_gather_kernel<f16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, (f16_t*)y, nw, CW, HW, (long long)F * HW, i0, ldc);
     else
         return C2W_ERR_BAD_ARG;
     return (int)hipGetLastError();
@@ -198,6 +200,8 @@ extern "C" int c2w_window_scatter(const void* y, float* eps, int nw, int F, int 
         window_scatter_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const float*)y, eps, nw, F, HW, k, i0, nwin_total, ldc);
     else if (dtype == C2W_DTYPE_BF16)
         window_scatter_kernel<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const bf16_t*)y, eps, nw, F, HW, k, i0, nwin_total, ldc);
+    else if (dtype == C2W_DTYPE_F16)
+        window_scatter_kernel<f16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const f16_t*)y, eps, nw, F, HW, k, i0, nwin_total, ldc);
     else
         return C2W_ERR_BAD_ARG;
     return (int)hipGetLastError();

@@ -206,11 +206,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < NTL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NTL; ++n) acc[m][n] = mfma16s<T>(a[m], b[n], acc[m][n]);
                 if (do_bias) {
-                    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+                    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m) accb[m] = mfma16s<T>(a[m], ones, accb[m]);
                 }
             }
         } else {
@@ -394,5 +394,6 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, int
     if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch(*a, dw, dbias, dtype, st);
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, dbias, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, dbias, st);
+    if (dtype == C2W_DTYPE_F16) return launch_dtype<f16_t>(*a, dw, dbias, st);
     return C2W_ERR_BAD_ARG;
 }

@@ -189,16 +189,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) {
                         if constexpr ((C2W_EXP & 1) == 0) {
-                            acc[tp][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bfr, acc[tp][m], 0, 0, 0);
+                            acc[tp][m] = mfma16s<T>(a[m], bfr, acc[tp][m]);
                         } else {
                             asm volatile("" ::"v"(a[m]), "v"(bfr));
                         }
                     }
                 }
                 if (do_bias) {
-                    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+                    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+                    for (int m = 0; m < MTW; ++m) accb[m] = mfma16s<T>(a[m], ones, accb[m]);
                 }
             }
         } else {
@@ -340,6 +340,7 @@ bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
 int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st) {
     if (dtype == C2W_DTYPE_F32) return launch<float>(a, dw, db, st);
     if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, dw, db, st);
+    if (dtype == C2W_DTYPE_F16) return launch<f16_t>(a, dw, db, st);
     return C2W_ERR_BAD_ARG;
 }
 

@@ -8,7 +8,7 @@ Data layout in HBM
   * parameters: ONE flat fp32 buffer; every nn.Parameter is a strided view into it.  Conv2d weights are stored
     [Cout][kh][kw][Cin] (a channels_last view of the reference's OIHW tensor) which is exactly the K-contiguous
     operand the implicit GEMM wants; the 30 modulation Linears sit back to back so that one GEMM produces every
-    block's modulation vector.  bf16 mode keeps a bf16 shadow of the same buffer (same offsets).
+    block's modulation vector.  The 16-bit modes (bf16, fp16) keep a shadow of the same buffer in their format (same offsets).
   * gradients: one flat fp32 buffer with the same offsets (a single RCCL all-reduce covers all 228 tensors).
   * activations: NHWC rows [B*H*W][C] in the compute dtype (fp32 or bf16); the reference's NCHW fp32 tensors only
     exist at the module boundary.
@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 from .nn import BlockSpec, LevelSpec
-from .ops import (ACT_NONE, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F32, MUL_DSILU, MUL_PLAIN, TORCH_DTYPE)
+from .ops import (ACT_NONE, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F16, DTYPE_F32, MUL_DSILU, MUL_PLAIN, TORCH_DTYPE)
 
 LN_EPS = 1e-5
 ALIGN = 64  # elements; keeps every region 256-B aligned in fp32 and 128-B aligned in the bf16 shadow
@@ -181,8 +181,8 @@ class Engine:
         self.ln_unbiased = bool(getattr(net, "ln_unbiased", True))
         self.flat: Optional[torch.Tensor] = None
         self.flat_grad: Optional[torch.Tensor] = None
-        self.shadow: Optional[torch.Tensor] = None
-        self._shadow_ver = -1
+        self.shadows: Dict[int, torch.Tensor] = {}   # 16-bit dtype -> copy of the flat buffer in that format
+        self._shadow_ver: Dict[int, object] = {}
         self.dg: Dict[int, torch.Tensor] = {}
         self.dg_lin: Optional[torch.Tensor] = None
         self._dg_ver: Dict[object, int] = {}
@@ -211,10 +211,10 @@ class Engine:
                 params[name].data = view
         self.flat = flat
         self.flat_grad = None
-        self.shadow = None
+        self.shadows.clear()
         self.dg.clear()
         self.dg_lin = None
-        self._shadow_ver = -1
+        self._shadow_ver.clear()
         self._dg_ver.clear()
         self._dg_desc.clear()
         self._wpad.clear()
@@ -247,12 +247,22 @@ class Engine:
     def _version(self):
         return (self.flat._version, self._manual_ver)
 
-    def weights_changed(self, shadow_fresh: bool = False) -> None:
+    def weights_changed(self, shadow_fresh: Optional[int] = None) -> None:
         """Call after the flat buffer was rewritten through raw pointers (fused optimizer): torch's version counter
-        does not see those writes.  ``shadow_fresh``: the writer also refreshed the bf16 shadow."""
+        does not see those writes.  ``shadow_fresh``: the 16-bit dtype whose shadow the writer also refreshed."""
         self._manual_ver += 1
-        if shadow_fresh and self.shadow is not None:
-            self._shadow_ver = self._version()
+        if shadow_fresh is not None and shadow_fresh in self.shadows:
+            self._shadow_ver[shadow_fresh] = self._version()
+
+    def shadow_for(self, dt: int) -> torch.Tensor:
+        """The flat parameter buffer in the 16-bit format ``dt``, refreshed if the weights changed since the last cast."""
+        sh = self.shadows.get(dt)
+        if sh is None:
+            sh = self.shadows[dt] = torch.empty(self.layout.numel, dtype=TORCH_DTYPE[dt], device=self.flat.device)
+        if self._shadow_ver.get(dt) != self._version():
+            ops.cast_f32(self.flat, sh, self.layout.numel, dt)
+            self._shadow_ver[dt] = self._version()
+        return sh
 
     def _w(self, rec: ConvRec, dt: int) -> torch.Tensor:
         if rec.kstride != rec.cin:  # network-input conv: the kernels want K in whole 128-byte chunks -> zero-padded operand copy
@@ -267,12 +277,7 @@ class Engine:
             return ent[1]
         if rec.lin or dt == DTYPE_F32:
             return self.flat[rec.w_off:]
-        if self.shadow is None:
-            self.shadow = torch.empty(self.layout.numel, dtype=torch.bfloat16, device=self.flat.device)
-        if self._shadow_ver != self._version():
-            ops.cast_f32(self.flat, self.shadow, self.layout.numel, DTYPE_BF16)
-            self._shadow_ver = self._version()
-        return self.shadow[rec.w_off:]
+        return self.shadow_for(dt)[rec.w_off:]
 
     def _b(self, rec: ConvRec) -> torch.Tensor:
         return self.flat[rec.b_off:]

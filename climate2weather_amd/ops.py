@@ -12,12 +12,12 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F32, MUL_DSILU,  # noqa: F401
+from ._lib import (ACT_NONE, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F16, DTYPE_F32, MUL_DSILU,  # noqa: F401
                    MUL_PLAIN, ConvArgs, check)
 
-TORCH_DTYPE = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
-ESZ = {DTYPE_F32: 4, DTYPE_BF16: 2}
-CK = {DTYPE_F32: 32, DTYPE_BF16: 64}  # channels per 128-byte K chunk
+TORCH_DTYPE = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16, DTYPE_F16: torch.float16}
+ESZ = {DTYPE_F32: 4, DTYPE_BF16: 2, DTYPE_F16: 2}
+CK = {DTYPE_F32: 32, DTYPE_BF16: 64, DTYPE_F16: 64}  # channels per 128-byte K chunk
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -137,8 +137,9 @@ def nhwc_to_nchw(y, out, B, C, HW, ldc, dtype):
     check(_lib.load().c2w_nhwc_to_nchw(_p(y), _p(out), B, C, HW, ldc, dtype, _stream()), "c2w_nhwc_to_nchw")
 
 
-def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype):
-    check(_lib.load().c2w_mse_loss_grad(_p(y), _p(eps), _p(dy), _p(loss_sum), B, C, HW, ldc, gscale, dtype, _stream()),
+def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=None):
+    """``scaler``: the 4-float device state of the dynamic loss scale (fp16 training) or None."""
+    check(_lib.load().c2w_mse_loss_grad_scaled(_p(y), _p(eps), _p(dy), _p(loss_sum), B, C, HW, ldc, gscale, _p(scaler), dtype, _stream()),
           "c2w_mse_loss_grad")
 
 
@@ -162,9 +163,23 @@ def weight_transpose_batched(flat, out, desc, nconv, dtype):
     check(_lib.load().c2w_weight_transpose_batched(_p(flat), _p(out), _p(desc), nconv, dtype, _stream()), "c2w_weight_transpose_batched")
 
 
-def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale):
-    check(_lib.load().c2w_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(shadow), n, lr, beta1, beta2, eps, weight_decay, step,
-                                    ema_rate, grad_scale, _stream()), "c2w_adamw_ema")
+def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale, scaler=None):
+    """``shadow``: None or the 16-bit weight copy (bf16 / fp16 tensor) to refresh; ``scaler``: loss-scale state or None."""
+    sdt = DTYPE_F16 if shadow is not None and shadow.dtype == torch.float16 else DTYPE_BF16
+    check(_lib.load().c2w_adamw_ema_scaled(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(shadow), sdt, n, lr, beta1, beta2, eps, weight_decay,
+                                           step, ema_rate, grad_scale, _p(scaler), _stream()), "c2w_adamw_ema")
+
+
+def grad_scaler_init(state, init_scale):
+    check(_lib.load().c2w_grad_scaler_init(_p(state), init_scale, _stream()), "c2w_grad_scaler_init")
+
+
+def grad_scaler_check(g, n, state):
+    check(_lib.load().c2w_grad_scaler_check(_p(g), n, _p(state), _stream()), "c2w_grad_scaler_check")
+
+
+def grad_scaler_update(state, growth, backoff, interval):
+    check(_lib.load().c2w_grad_scaler_update(_p(state), growth, backoff, interval, _stream()), "c2w_grad_scaler_update")
 
 
 def ema_update(ema, p, n, rate):

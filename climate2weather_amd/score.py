@@ -5,8 +5,9 @@ Point ``network_kwargs.class_name`` (train.py:164-173, util.py:117-127) at
 keywords, same 228 state_dict keys and creation-order initialisation, same ``forward(x, t, forcing=None)``.
 
 Precision follows the caller the way the reference's modules do: fp32 arithmetic unless ``torch.autocast`` is
-active (the reference hard-codes Fabric ``precision="16-mixed"``, train.py:98), in which case the bf16 MFMA
-path runs.  ``net.precision = "fp32" | "bf16"`` pins it.
+active (the reference hard-codes Fabric ``precision="16-mixed"`` = fp16 autocast, train.py:98), in which case the
+16-bit MFMA path of the autocast dtype runs (``torch.autocast("cuda", dtype=torch.float16)`` -> fp16, the reference's
+own arithmetic type; the default / bfloat16 -> bf16).  ``net.precision = "fp32" | "bf16" | "fp16"`` pins it.
 """
 from __future__ import annotations
 
@@ -16,7 +17,7 @@ import torch
 
 from .engine import Engine, Tape
 from .nn import UNet
-from .ops import DTYPE_BF16, DTYPE_F32, TORCH_DTYPE
+from .ops import DTYPE_BF16, DTYPE_F16, DTYPE_F32, TORCH_DTYPE
 
 
 def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
@@ -105,7 +106,7 @@ class ScoreUNet(torch.nn.Module):
         self.unet = UNet(channels, channels, embedding_dim, **kwargs)
         self.map_layer0 = torch.nn.Linear(self.noise_features, embedding_dim)
         self.map_layer1 = torch.nn.Linear(embedding_dim, embedding_dim)
-        self.precision = "auto"  # "auto" (bf16 under torch.autocast, else fp32) | "fp32" | "bf16"
+        self.precision = "auto"  # "auto" (the autocast dtype under torch.autocast, else fp32) | "fp32" | "bf16" | "fp16"
         self.ln_unbiased = True  # zuko.nn.LayerNorm uses torch.var_mean's default; see oracle/_shim/zuko/nn.py
         self.__dict__["_engine"] = None
 
@@ -142,7 +143,13 @@ class ScoreUNet(torch.nn.Module):
             return DTYPE_F32
         if self.precision == "bf16":
             return DTYPE_BF16
-        return DTYPE_BF16 if torch.is_autocast_enabled() else DTYPE_F32
+        if self.precision == "fp16":
+            return DTYPE_F16
+        if self.precision != "auto":
+            raise ValueError(f"precision must be auto / fp32 / bf16 / fp16, got {self.precision!r}")
+        if not torch.is_autocast_enabled():
+            return DTYPE_F32
+        return DTYPE_F16 if torch.get_autocast_dtype("cuda") == torch.float16 else DTYPE_BF16
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, forcing: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert forcing is None, "forcing_dim == 0"

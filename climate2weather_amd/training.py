@@ -8,7 +8,10 @@ the API:
   * gradients live in ONE flat fp32 buffer laid out in reverse finalisation order; while backward is still running,
     finished buckets of it are all-reduced over xGMI on RCCL's stream (replaces Lightning Fabric's DDP wrapper,
     training_loop.py:116,375-378) -- a sum; the 1/world_size mean is folded into the optimizer kernel;
-  * AdamW (train.py:176-181) + EMA (src/thor/ema.py:23-27) + the bf16 weight shadow refresh are one fused kernel.
+  * AdamW (train.py:176-181) + EMA (src/thor/ema.py:23-27) + the 16-bit weight shadow refresh are one fused kernel;
+  * precision "fp16" (the reference's own: Fabric "16-mixed", train.py:98) trains under a dynamic loss scale with
+    torch.cuda.amp.GradScaler's rule (init 2^16, x2 every 2000 clean steps, /2 and skip the step on inf/nan) -- kept in
+    device memory and applied by the kernels themselves, so a skipped step costs no host synchronisation.
 """
 from __future__ import annotations
 
@@ -21,7 +24,7 @@ import torch.distributed as dist
 
 from . import ops
 from .engine import Tape
-from .ops import DTYPE_BF16, DTYPE_F32, TORCH_DTYPE
+from .ops import DTYPE_BF16, DTYPE_F16, DTYPE_F32, TORCH_DTYPE
 from .pipelines import SDAPipeline
 
 
@@ -29,13 +32,17 @@ class Trainer:
     def __init__(self, net, pipeline: Optional[SDAPipeline] = None, *, lr: float = 1e-4, lr_fn: Optional[Callable[[int], float]] = None,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-3, ema_rates: Sequence[float] = (0.9999,),
                  precision: str = "bf16", batch_size: Optional[int] = None, loss_scaling: float = 1.0,
-                 process_group=None, bucket_mb: float = 25.0):
+                 process_group=None, bucket_mb: float = 25.0, init_scale: float = 65536.0, growth_factor: float = 2.0,
+                 backoff_factor: float = 0.5, growth_interval: int = 2000):
         self.net = net
         self.pipeline = pipeline or SDAPipeline()
         self.lr, self.lr_fn = lr, lr_fn
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.ema_rates = list(ema_rates)
-        self.dt = DTYPE_BF16 if precision == "bf16" else DTYPE_F32
+        if precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"precision must be fp32 / bf16 / fp16, got {precision!r}")
+        self.dt = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}[precision]
+        self.scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
         self.loss_scaling = loss_scaling
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -52,6 +59,11 @@ class Trainer:
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ema_flats = [eng.flat.clone() for _ in self.ema_rates]
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        # dynamic loss scale {scale, growth tracker, found_inf, optimizer steps taken}: fp16 only (GradScaler is a no-op otherwise)
+        self.scaler: Optional[torch.Tensor] = None
+        if self.dt == DTYPE_F16:
+            self.scaler = torch.zeros(4, dtype=torch.float32, device=dev)
+            ops.grad_scaler_init(self.scaler, float(init_scale))
         if self.sync_grads:  # same initial weights everywhere (DDP's initial broadcast)
             dist.broadcast(eng.flat, src=0, group=self.pg)
             eng.weights_changed()
@@ -102,16 +114,17 @@ class Trainer:
         lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
         self.step_count += 1
         n = eng.layout.numel
-        shadow = eng.shadow if self.dt == DTYPE_BF16 else None
-        if self.dt == DTYPE_BF16 and shadow is None:
-            eng._w(next(iter(r for r in eng.layout.convs.values() if not r.lin)), DTYPE_BF16)
-            shadow = eng.shadow
+        shadow = eng.shadow_for(self.dt) if self.dt != DTYPE_F32 else None
+        if self.scaler is not None:  # after the all-reduce: inf/nan survive the sum, so every rank takes the same decision
+            ops.grad_scaler_check(eng.flat_grad, n, self.scaler)
         ops.adamw_ema(eng.flat, eng.flat_grad, self.m, self.v, self.ema_flats[0] if self.ema_flats else None, shadow, n, float(lr),
                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
-                      float(self.ema_rates[0]) if self.ema_rates else 0.0, 1.0 / self.world)
+                      float(self.ema_rates[0]) if self.ema_rates else 0.0, 1.0 / self.world, scaler=self.scaler)
+        if self.scaler is not None:
+            ops.grad_scaler_update(self.scaler, *self.scaler_cfg)
         for rate, e in zip(self.ema_rates[1:], self.ema_flats[1:]):
             ops.ema_update(e, eng.flat, n, float(rate))
-        eng.weights_changed(shadow_fresh=shadow is not None)
+        eng.weights_changed(shadow_fresh=self.dt if shadow is not None else None)
         B = sum(b.shape[0] for b in batches)
         self.cur_ndata += self.batch_size if self.batch_size is not None else B * self.world
         return loss
@@ -135,9 +148,17 @@ class Trainer:
         dy = torch.empty_like(y)
         self.loss_sum.zero_()
         n = B * C * H * W
-        ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, 2.0 * self.loss_scaling / n, self.dt)
+        ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, 2.0 * self.loss_scaling / n, self.dt, scaler=self.scaler)
         eng.backward(tape, dy)
         return self.loss_sum[0] * (self.loss_scaling / n)
+
+    def optimizer_steps_taken(self) -> int:
+        """AdamW steps actually applied: under the fp16 loss scale, steps whose gradients overflowed were skipped on the
+        device (this read synchronises; the training loop itself never does)."""
+        return int(self.scaler[3].item()) if self.scaler is not None else self.step_count
+
+    def loss_scale(self) -> float:
+        return float(self.scaler[0].item()) if self.scaler is not None else 1.0
 
     # ------------------------------------------------------------------ EMA access / state
     def ema_state_dicts(self):
@@ -161,9 +182,10 @@ class Trainer:
         (src/thor/checkpoint.py:13-35 saves ``optimizer`` through Fabric = its state_dict)."""
         ms, vs = self._per_param(self.m), self._per_param(self.v)
         state = {}
-        if self.step_count > 0:
+        steps = self.optimizer_steps_taken()
+        if steps > 0:
             for i, ((_, m), (_, v)) in enumerate(zip(ms, vs)):
-                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m.clone(), exp_avg_sq=v.clone())
+                state[i] = dict(step=torch.tensor(float(steps)), exp_avg=m.clone(), exp_avg_sq=v.clone())
         lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
         group = dict(lr=float(lr), betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False, maximize=False,
                      foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(ms))))
@@ -179,6 +201,8 @@ class Trainer:
             vs[int(i)][1].copy_(st["exp_avg_sq"])
             step = max(step, int(float(st["step"])))
         self.step_count = step
+        if self.scaler is not None:
+            self.scaler[3] = float(step)
         if osd.get("param_groups"):
             g = osd["param_groups"][0]
             self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]

@@ -8,8 +8,10 @@
  *     allocated, freed or synchronised inside; work is enqueued on `stream` (a hipStream_t);
  *   - activations are NHWC: [B][H][W][ld] with `ld` the channel stride in elements;
  *   - `dtype` selects the storage/MFMA-operand type: C2W_DTYPE_F32 (exact fp32 matrix-core
- *     path, the <=1e-4 parity mode) or C2W_DTYPE_BF16 (throughput mode); accumulation and all
- *     pointwise math are fp32 in both;
+ *     path, the <=1e-4 parity mode), C2W_DTYPE_BF16 (throughput mode) or C2W_DTYPE_F16 (IEEE half, the type the
+ *     reference's Fabric "16-mixed" autocast computes in, train.py:98: same kernels and layouts as bf16 with the f16
+ *     matrix-core opcode; its narrow range needs the loss scale of c2w_grad_scaler_* in training); accumulation and all
+ *     pointwise math are fp32 in all three;
  *   - return value: 0 on success, a positive hipError_t, or a negative C2W_ERR_* code.
  *     Nothing throws across this boundary.
  */
@@ -22,7 +24,7 @@
 extern "C" {
 #endif
 
-enum { C2W_DTYPE_F32 = 0, C2W_DTYPE_BF16 = 1 };
+enum { C2W_DTYPE_F32 = 0, C2W_DTYPE_BF16 = 1, C2W_DTYPE_F16 = 2 };
 enum { C2W_ERR_BAD_ARG = -1, C2W_ERR_BAD_SHAPE = -2, C2W_ERR_UNSUPPORTED = -3 };
 
 /* geometry of the implicit GEMM */
@@ -128,6 +130,9 @@ int c2w_nhwc_to_nchw(const void* y, float* out, int B, int C, int HW, int ldc, i
 /* loss tail (src/thor/pipelines.py:35, training_loop.py:377): loss_sum += sum (y-eps)^2 ; dy = (y-eps) * gscale */
 int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
                       float gscale, int dtype, void* stream);
+/* same with dy additionally multiplied by the device-resident loss scale scaler_state[0] (NULL = 1): fp16 training */
+int c2w_mse_loss_grad_scaled(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
+                             float gscale, const float* scaler_state, int dtype, void* stream);
 /* model/score.py:14-34 */
 int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream);
 /* src/thor/pipelines.py:13-20: musig[i] = {mu(t_i), sigma(t_i)} */
@@ -145,6 +150,25 @@ int c2w_weight_transpose_batched(const float* flat, void* out, const long long* 
 int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float ema_rate, float grad_scale,
                   void* stream);
+
+/* The same step with a 16-bit weight shadow of either format (shadow_dtype = C2W_DTYPE_BF16 / C2W_DTYPE_F16) and, when
+ * scaler_state != NULL, under the dynamic loss scale: g is divided by scaler_state[0]; if scaler_state[2] (found_inf) is
+ * set the step changes nothing but the EMA; the Adam bias corrections use scaler_state[3] + 1 (steps actually taken)
+ * instead of `step`. */
+int c2w_adamw_ema_scaled(float* p, const float* g, float* m, float* v, float* ema, void* shadow, int shadow_dtype,
+                         long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float ema_rate, float grad_scale, const float* scaler_state, void* stream);
+
+/* Dynamic loss scale for fp16 training, resident on the device: torch.cuda.amp.GradScaler's rule, which Fabric's
+ * precision="16-mixed" (train.py:98) wraps around fabric.backward / optimizer.step (training_loop.py:378,383).
+ * state: 4 floats in device memory {scale, growth tracker, found_inf, optimizer steps taken}.  One step =
+ *   loss gradient x state[0] (c2w_mse_loss_grad_scaled) -> backward -> [all-reduce] -> c2w_grad_scaler_check (found_inf = any
+ *   non-finite gradient; identical on every rank after the all-reduce) -> c2w_adamw_ema_scaled -> c2w_grad_scaler_update
+ *   (overflow: scale *= backoff, tracker = 0; else steps += 1, tracker += 1, and scale *= growth every growth_interval
+ *   clean steps).  No host synchronisation anywhere; the host may read the state whenever it likes. */
+int c2w_grad_scaler_init(float* state, float init_scale, void* stream);
+int c2w_grad_scaler_check(const float* g, long long n, float* state, void* stream);
+int c2w_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, void* stream);
 
 /* p_ema = rate * p_ema + (1 - rate) * p over a flat buffer (src/thor/ema.py:23-27) */
 int c2w_ema_update(float* ema, const float* p, long long n, float rate, void* stream);

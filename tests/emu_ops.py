@@ -13,11 +13,11 @@ import math
 import torch
 import torch.nn.functional as F
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR = 0, 1, 2
 MUL_PLAIN, MUL_DSILU = 0, 1
-TD = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
+TD = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16, DTYPE_F16: torch.float16}
 
 
 def _rows(t, n, ld):
@@ -197,7 +197,9 @@ def nhwc_to_nchw(y, out, B, C, HW, ldc, dtype):
     out.reshape(-1)[: B * C * HW] = Y.reshape(-1)
 
 
-def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype):
+def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=None):
+    if scaler is not None:
+        gscale = gscale * float(scaler[0])
     Y = _rows(y, B * HW, ldc)[:, :C].float()
     E = eps.reshape(-1)[: B * C * HW].view(B, C, HW).permute(0, 2, 1).reshape(B * HW, C).float()
     d = Y - E
@@ -241,8 +243,15 @@ def weight_transpose_batched(flat, out, desc, nconv, dtype):
         weight_transpose(flat.reshape(-1)[w_off:], out.reshape(-1)[o_off:], R, NT, K, ldk, ldr, flip, dtype)
 
 
-def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale):
+def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, step, ema_rate, grad_scale, scaler=None):
     P, G, M, V = (a.reshape(-1)[:n] for a in (p, g, m, v))
+    if scaler is not None:  # torch.cuda.amp.GradScaler: unscale, skip the step on inf/nan (the EMA still moves)
+        grad_scale = grad_scale / float(scaler[0])
+        step = int(scaler[3]) + 1
+        if float(scaler[2]) != 0:
+            if ema is not None:
+                ema.reshape(-1)[:n].mul_(ema_rate).add_(P, alpha=1 - ema_rate)
+            return
     gi = G * grad_scale
     P.mul_(1 - lr * weight_decay)
     M.mul_(beta1).add_(gi, alpha=1 - beta1)
@@ -253,7 +262,30 @@ def adamw_ema(p, g, m, v, ema, shadow, n, lr, beta1, beta2, eps, weight_decay, s
     if ema is not None:
         ema.reshape(-1)[:n].mul_(ema_rate).add_(P, alpha=1 - ema_rate)
     if shadow is not None:
-        shadow.reshape(-1)[:n] = P.to(torch.bfloat16)
+        shadow.reshape(-1)[:n] = P.to(shadow.dtype)
+
+
+def grad_scaler_init(state, init_scale):
+    state.reshape(-1)[:4] = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=state.device)
+
+
+def grad_scaler_check(g, n, state):
+    if not bool(torch.isfinite(g.reshape(-1)[:n]).all()):
+        state[2] = 1.0
+
+
+def grad_scaler_update(state, growth, backoff, interval):
+    if float(state[2]) != 0:
+        state[0] *= backoff
+        state[1] = 0.0
+    else:
+        state[3] += 1
+        if float(state[1]) + 1 >= interval:
+            state[0] *= growth
+            state[1] = 0.0
+        else:
+            state[1] += 1
+    state[2] = 0.0
 
 
 def ema_update(ema, p, n, rate):

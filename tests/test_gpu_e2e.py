@@ -1,6 +1,7 @@
 """End-to-end GPU parity of the HIP ScoreUNet against (a) the golden vectors generated from the imported reference
 and (b) the CPU oracle on fresh seeded inputs.  fp32 mode: <= 1e-4 relative (BASELINE.json north_star);
-bf16 mode: <= 3e-2 of the output scale (stated tolerance for the throughput mode)."""
+bf16 mode: <= 3e-2 of the output scale (stated tolerance for the throughput mode); fp16 mode (the reference's autocast type): <= 5e-3
+(three more significand bits than bf16).  fp16 gradients are taken of a scaled loss, as under the reference's GradScaler."""
 import json
 import os
 
@@ -94,16 +95,16 @@ def test_small_net_bf16_vs_oracle(per_sample_t):
     yo = ou.score_unet_forward(sdo, x, t, cfg["hidden_blocks"], cfg["attention_levels"])
     lo = ((yo - eps) ** 2).mean()
     go = torch.autograd.grad(lo, list(sdo.values()))
-    for prec, tol_y, tol_g in (("fp32", 1e-4, 3e-4), ("bf16", 3e-2, 8e-2)):
+    for prec, tol_y, tol_g, S in (("fp32", 1e-4, 3e-4, 1.0), ("bf16", 3e-2, 8e-2, 1.0), ("fp16", 5e-3, 1.5e-2, 4096.0)):
         net.precision = prec
         net.zero_grad(set_to_none=True)
         y = net(x.cuda(), t.cuda())
         assert _rel(y, yo.detach()) <= tol_y, (prec, _rel(y, yo.detach()))
         l = ((y - eps.cuda()) ** 2).mean()
-        l.backward()
+        (l * S).backward()  # fp16: scaled loss (GradScaler), else the 1/N gradients underflow half precision
         named = dict(net.named_parameters())
         for (k, _), gr in zip(sdo.items(), go):
-            r = _rel(named[k].grad, gr)
+            r = _rel(named[k].grad / S, gr)
             assert r <= tol_g, (prec, k, r)
 
 
@@ -117,8 +118,13 @@ def test_autocast_selects_bf16_and_matches():
         y32 = net(x, t)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y16 = net(x, t)
+            assert net.compute_dtype() == 1
+        with torch.autocast("cuda", dtype=torch.float16):  # the reference's Fabric precision="16-mixed" (train.py:98)
+            yh = net(x, t)
+            assert net.compute_dtype() == 2
         assert net.compute_dtype() == 0
     assert _rel(y16, y32) <= 3e-2 and not torch.equal(y16, y32)
+    assert _rel(yh, y32) <= 5e-3 and not torch.equal(yh, y32) and not torch.equal(yh, y16)
 
 
 def test_full_size_net_fp32_vs_reference_fingerprint(golden_dir):
@@ -138,6 +144,10 @@ def test_full_size_net_fp32_vs_reference_fingerprint(golden_dir):
     with torch.no_grad():
         yb = net(x.cuda(), torch.tensor([0.3], device="cuda")).cpu()
     assert _rel(yb[:, :, ::16, ::16], ref) <= 3e-2
+    net.precision = "fp16"
+    with torch.no_grad():
+        yh = net(x.cuda(), torch.tensor([0.3], device="cuda")).cpu()
+    assert _rel(yh[:, :, ::16, ::16], ref) <= 5e-3
 
 
 def test_full_size_bf16_large_batch_matches_fp32_path():
@@ -151,19 +161,23 @@ def test_full_size_bf16_large_batch_matches_fp32_path():
     t = torch.rand(16, generator=g).cuda()
     eps = torch.randn(16, 52, 128, 128, generator=g).cuda()
     outs, grads = {}, {}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16", "fp16"):
         net.precision = mode
         for p in net.parameters():
             p.grad = None
+        S = 65536.0 if mode == "fp16" else 1.0  # GradScaler's initial scale
         y = net(x, t)
         loss = ((y - eps) ** 2).mean()
-        loss.backward()
+        (loss * S).backward()
         torch.cuda.synchronize()
         outs[mode] = y.detach().float().clone()
-        grads[mode] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        grads[mode] = {n: p.grad.detach().clone() / S for n, p in net.named_parameters()}
     assert _rel(outs["bf16"], outs["fp32"]) <= 3e-2
     worst = max((_rel(grads["bf16"][n], grads["fp32"][n]), n) for n in grads["fp32"] if n.endswith("weight"))
     assert worst[0] <= 6e-2, worst  # gradients pass through ~100 bf16 layers: twice the forward tolerance
+    assert _rel(outs["fp16"], outs["fp32"]) <= 5e-3
+    worst = max((_rel(grads["fp16"][n], grads["fp32"][n]), n) for n in grads["fp32"] if n.endswith("weight"))
+    assert worst[0] <= 1.5e-2, worst
 
 
 @pytest.mark.parametrize("B,H,W,channels,cfg", [

@@ -2,7 +2,8 @@
 restatement of the same op (tests/emu_ops.py) on the same seeded inputs.
 
 Tolerances (written here, per SURVEY 8d / BASELINE.json): fp32 mode <= 1e-4 of the output scale (the parity gate);
-bf16 mode <= 2e-2 of the output scale (bf16 has 8 significand bits; K up to 4608 products are accumulated in fp32).
+bf16 mode <= 2e-2 of the output scale (bf16 has 8 significand bits; K up to 4608 products are accumulated in fp32);
+fp16 mode (the reference's autocast type; 11 significand bits) <= 4e-3.
 """
 import math
 
@@ -15,9 +16,9 @@ from climate2weather_amd import ops
 
 pytestmark = pytest.mark.gpu
 
-F32, BF16 = ops.DTYPE_F32, ops.DTYPE_BF16
+F32, BF16, F16 = ops.DTYPE_F32, ops.DTYPE_BF16, ops.DTYPE_F16
 TD = ops.TORCH_DTYPE
-TOL = {F32: 1e-4, BF16: 2e-2}
+TOL = {F32: 1e-4, BF16: 2e-2, F16: 4e-3}
 
 
 def dev():
@@ -70,7 +71,7 @@ def _out_hw(mode, Hin, Win):
     return Hin, Win
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("naive", [0, 1, 2])
 def test_conv_forward(case, dt, naive):
@@ -98,10 +99,11 @@ def test_conv_forward(case, dt, naive):
             close(y2, y2_ref, dt, f"conv second output mode={mode} naive={naive}")
 
 
-def test_conv_16x16_tile_kernel_all_epilogues():
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_conv_16x16_tile_kernel_all_epilogues(dt):
     """Launches with >= 1024 workgroups take conv_patch_t3_kernel<16> (conv_patch3.hip); every epilogue variant of it against the
     PyTorch restatement at a size that dispatches there (B = 16, 128x128, 128 -> 128: 1024 tiles), 2 K-chunks."""
-    dt, B, H, W, C = BF16, 16, 128, 128, 128
+    B, H, W, C = 16, 128, 128, 128
     g = geom(B, H, W, C, H, W, C, C, C, ops.CONV_S1)
     npix = B * H * W
     x = rnd((npix, C), dt, 1)
@@ -137,7 +139,7 @@ def test_conv_16x16_tile_kernel_all_epilogues():
     close(y2, y2_ref, dt, "16x16 tile kernel, fused LN forward output")
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("naive", [0, 1, 2])
 @pytest.mark.parametrize("case", [(ops.CONV_S1, 2, 16, 16, 64, 128, 128, 128), (ops.CONV_S1, 3, 8, 8, 128, 192, 192, 192),
                                   (ops.CONV_S1, 1, 24, 32, 64, 128, 128, 128)])
@@ -164,12 +166,13 @@ def test_conv_silu_pair_outputs(case, dt, naive):
     close(dx, dx_ref, dt, "plain multiplier epilogue")
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("unbiased", [True, False])
 @pytest.mark.parametrize("B,H,W,Cin,per_sample,use_res", [(2, 32, 48, 128, True, True), (3, 8, 16, 192, True, False), (1, 16, 32, 64, False, True)])
-def test_conv_with_fused_ln_forward_output(B, H, W, Cin, per_sample, use_res, unbiased):
+def test_conv_with_fused_ln_forward_output(B, H, W, Cin, per_sample, use_res, unbiased, dt):
     """Second output of the conv epilogue: the consumer's LayerNorm input LN(y + m) (C2wConvArgs.lnf_*), against conv
     followed by ln_forward on the stored result."""
-    dt, C = BF16, 128
+    C = 128
     g = geom(B, H, W, Cin, H, W, C, C, C, ops.CONV_S1)
     assert ops.conv_lnfwd_supported(g, dt) and not ops.conv_lnfwd_supported(g, F32)
     npix = B * H * W
@@ -190,12 +193,13 @@ def test_conv_with_fused_ln_forward_output(B, H, W, Cin, per_sample, use_res, un
         close(hn, hn_ref, dt, "fused LN forward output")
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("unbiased", [True, False])
 @pytest.mark.parametrize("B,H,W,Cin,per_sample", [(2, 32, 48, 128, True), (3, 16, 16, 192, True), (1, 16, 32, 64, False)])
-def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased):
+def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased, dt):
     """The input-gradient conv of a res-block's first conv with LayerNorm's backward in its epilogue
     (C2wConvArgs.ln_*): y = res + dLN(conv(x); ln_x + m), dm += column sums -- against conv followed by ln_backward."""
-    dt, C = BF16, 128
+    C = 128
     g = geom(B, H, W, Cin, H, W, C, C, C, ops.CONV_S1)
     assert ops.conv_lnbwd_supported(g, dt)
     assert not ops.conv_lnbwd_supported(g, F32)
@@ -223,7 +227,7 @@ def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased):
     close(y, y_ref, dt, "fused ln bwd dx (no m, no res)")
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("force_gather", [False, True, "workspace"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] != ops.CONV_TS2])
 def test_conv_wgrad(case, dt, force_gather, monkeypatch):
@@ -258,7 +262,7 @@ def test_conv_wgrad(case, dt, force_gather, monkeypatch):
     close(dw, 2 * dw_ref, dt, "wgrad accumulate", tol=1e-4 if dt == F32 else 1e-2)
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("shape", [(2, 64, 128, True), (3, 16, 256, True), (1, 1024, 384, False), (2, 64, 512, True), (4, 4, 64, True)])
 def test_layernorm_fwd_bwd(shape, dt):
     B, HW, C, per_sample = shape
@@ -294,7 +298,7 @@ def test_layernorm_fwd_bwd(shape, dt):
     close(y, y_ref, dt, "ln fwd biased")
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 def test_weight_transpose_batched(dt):
     """all input-gradient operands of a network in one launch == one launch per matrix"""
     specs = [(64, 9, 40, 64, 72, 1), (128, 1, 128, 128, 128, 0), (33, 9, 64, 64, 40, 1)]  # (R, NT, K, ldk, ldr, flip)
@@ -311,7 +315,7 @@ def test_weight_transpose_batched(dt):
     assert torch.equal(out, out_ref)
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 def test_upsample2(dt):
     B, H, W, C = 3, 5, 7, 64
     x = rnd((B * H * W, C), dt, 1)
@@ -325,7 +329,7 @@ def test_upsample2(dt):
     assert not ops.conv_patch_supported(geom(2, 16, 16, 64, 8, 8, 128, 128, 128, ops.CONV_S2), dt)
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 def test_pointwise_family(dt):
     d = dev()
     rows, C, lda = 1000, 128, 192
@@ -360,7 +364,7 @@ def test_pointwise_family(dt):
     close(p, p_ref, dt, "sumpool2")
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 def test_layout_noise_loss(dt):
     d = dev()
     B, C, H, W, ldc = 3, 52, 16, 16, 64
@@ -400,7 +404,7 @@ def test_time_embedding_cast_transpose_adamw():
     close(o, o_ref, F32, "timestep_embedding", tol=1e-6)
     assert abs(o[2, 0].item() - 0.87758255) < 1e-6 and abs(o[2, 16].item() - 0.47942555) < 1e-6  # SURVEY a1 KAT
     src = rnd((10000,), F32, 1)
-    for dt in (F32, BF16):
+    for dt in (F32, BF16, F16):
         dst, dst_ref = torch.empty(10000, dtype=TD[dt], device=d), torch.empty(10000, dtype=TD[dt], device=d)
         ops.cast_f32(src, dst, 10000, dt)
         E.cast_f32(src, dst_ref, 10000, dt)
@@ -439,7 +443,49 @@ def test_time_embedding_cast_transpose_adamw():
     close(p2, q.detach(), F32, "adamw vs torch.optim.AdamW", tol=1e-6)
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
+def test_grad_scaler_and_fp16_shadow():
+    """Device-resident dynamic loss scale (torch.cuda.amp.GradScaler's rule; Fabric "16-mixed", train.py:98) around the fused
+    AdamW: unscaling, skip on inf/nan (EMA still moves), growth after `interval` clean steps, bias corrections that count
+    only the steps taken -- against torch.optim.AdamW + torch's GradScaler arithmetic restated on the host."""
+    d = dev()
+    n = 4099  # not a multiple of 4: the check kernel's tail
+    p = rnd((n,), F32, 1)
+    m, v = torch.zeros(n, device=d), torch.zeros(n, device=d)
+    ema = p.clone()
+    sh = torch.empty(n, dtype=torch.float16, device=d)
+    q = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([q], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    ema_ref = p.clone()
+    st = torch.zeros(4, device=d)
+    ops.grad_scaler_init(st, 1024.0)
+    scale, tracker, taken = 1024.0, 0, 0
+    for step in range(1, 8):
+        g = rnd((n,), F32, 10 + step)
+        bad = step in (2, 5)
+        gs = g * scale
+        if bad:
+            gs[n - 1 if step == 2 else 17] = float("inf") if step == 2 else float("nan")
+        ops.grad_scaler_check(gs, n, st)
+        assert st[2].item() == (1.0 if bad else 0.0)
+        ops.adamw_ema(p, gs, m, v, ema, sh, n, 1e-3, 0.9, 0.999, 1e-8, 1e-3, step, 0.99, 1.0, scaler=st)
+        ops.grad_scaler_update(st, 2.0, 0.5, 3)
+        if bad:
+            scale, tracker = scale * 0.5, 0
+        else:
+            q.grad = g.clone()
+            opt.step()
+            taken += 1
+            tracker += 1
+            if tracker == 3:
+                scale, tracker = scale * 2.0, 0
+        ema_ref.mul_(0.99).add_(q.detach(), alpha=0.01)
+        assert st.tolist() == [scale, float(tracker), 0.0, float(taken)], (step, st.tolist())
+        close(p, q.detach(), F32, f"scaled adamw step {step}", tol=2e-6)
+        close(ema, ema_ref, F32, f"ema step {step}", tol=2e-6)
+    assert torch.equal(sh, p.to(torch.float16))
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("shape", [(2, 64, 512), (3, 16, 64), (1, 256, 128), (2, 4, 64), (5, 64, 128), (3, 64, 96), (2, 256, 512), (1, 192, 64)])  # bf16: T=64 and T=64n (online softmax over key blocks) on the matrix cores
 def test_attention(shape, dt):
     B, T, C = shape
@@ -468,11 +514,13 @@ def test_conv_random_shapes_product_vs_direct_kernel():
     for it in range(48):
         mode = modes[rs.randint(len(modes))]
         dt = [F32, BF16][rs.randint(2)]
+        if dt == BF16 and it % 2:
+            dt = F16  # same byte layout, other matrix-core opcode and conversions
         B = int(rs.randint(1, 4))
         Hin, Win = int(rs.choice([4, 8, 12, 16, 24, 32, 40])), int(rs.choice([4, 8, 16, 32, 48]))
         if mode == ops.CONV_S2:
             Hin, Win = Hin * 2, Win * 2
-        Cin = int(rs.choice([64, 128, 192])) if dt == BF16 else int(rs.choice([32, 64, 96]))
+        Cin = int(rs.choice([64, 128, 192])) if dt != F32 else int(rs.choice([32, 64, 96]))
         ldy = int(rs.choice([8, 64, 72, 128, 136, 200]))
         Cout = ldy if rs.rand() < 0.7 else max(8, ldy - 8 * int(rs.randint(0, 3)))
         wrows = Cout if rs.rand() < 0.7 else max(1, Cout - int(rs.randint(1, 8)))
@@ -507,6 +555,8 @@ def test_wgrad_random_shapes_vs_restatement():
     for it in range(24):
         mode = modes[rs.randint(len(modes))]
         dt = [F32, BF16][rs.randint(2)]
+        if dt == BF16 and it % 2:
+            dt = F16  # same byte layout, other matrix-core opcode and conversions
         if rs.rand() < 0.5:
             ops.ensure_workspace(dev())
         else:
@@ -515,7 +565,7 @@ def test_wgrad_random_shapes_vs_restatement():
         Hin, Win = int(rs.choice([4, 8, 16, 24])), int(rs.choice([8, 16, 32]))
         if mode == ops.CONV_S2:
             Hin, Win = Hin * 2, Win * 2
-        Cin = int(rs.choice([64, 128, 192])) if dt == BF16 else int(rs.choice([32, 64, 96]))
+        Cin = int(rs.choice([64, 128, 192])) if dt != F32 else int(rs.choice([32, 64, 96]))
         ldy = int(rs.choice([8, 64, 72, 128, 200]))
         Cw = ldy if rs.rand() < 0.6 else max(1, ldy - int(rs.randint(1, 9)))
         Hout, Wout = _out_hw(mode, Hin, Win)

@@ -113,6 +113,41 @@ def _free_port():
     return port
 
 
+def test_fp16_training_step_runs_under_the_dynamic_loss_scale(emu):
+    """precision="fp16" (the reference's Fabric "16-mixed", train.py:98): the step multiplies the loss gradient by the device-held
+    scale, unscales inside the optimizer, skips the update (but not the EMA) when a gradient is non-finite and halves the scale;
+    after `growth_interval` clean steps the scale doubles.  Host logic only -- the launchers are the PyTorch test double."""
+    cfg = dict(TINY, hidden_channels=[64, 64])  # 16-bit modes: channel counts in whole 128-byte K chunks
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg)
+    torch.manual_seed(3)
+    ref = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg)
+    tr = Trainer(net, lr=1e-3, precision="fp16", ema_rates=[0.9], init_scale=256.0, growth_interval=2)
+    tr32 = Trainer(ref, lr=1e-3, precision="fp32", ema_rates=[0.9])
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, 16, 16, generator=gen)
+    t, eps = torch.rand(2, generator=gen), torch.randn(2, 6, 16, 16, generator=gen)
+    assert tr.scaler.tolist() == [256.0, 0.0, 0.0, 0.0]
+    l16, l32 = tr.step(x, t=t, eps=eps), tr32.step(x, t=t, eps=eps)
+    assert abs(float(l16) - float(l32)) <= 5e-3 * float(l32)
+    assert tr.scaler.tolist() == [256.0, 1.0, 0.0, 1.0] and tr.optimizer_steps_taken() == 1
+    for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+        assert (a - b).abs().max().item() <= 2.1e-3, k  # Adam's first step is +-lr: a flipped sign of a ~0 gradient costs 2 lr
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    ema_before = tr.ema_flats[0].clone()
+    # poison one activation-gradient path: an inf input makes every gradient non-finite -> step skipped, scale halved
+    tr.step(torch.full_like(x, float("inf")), t=t, eps=eps)
+    assert tr.scaler.tolist() == [128.0, 0.0, 0.0, 1.0] and tr.optimizer_steps_taken() == 1 and tr.step_count == 3 - 1
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert not torch.equal(tr.ema_flats[0], ema_before)  # ema.update still ran (training_loop.py:387-389)
+    tr.step(x, t=t, eps=eps)
+    tr.step(x, t=t, eps=eps)
+    assert tr.scaler.tolist() == [256.0, 0.0, 0.0, 3.0] and tr.loss_scale() == 256.0
+    osd = tr.optimizer_state_dict()
+    assert float(osd["state"][0]["step"]) == 3.0
+
+
 @pytest.mark.parametrize("bucket_mb", [48.0, 0.05])
 def test_ddp_two_ranks_gloo_equals_single_process(golden_dir, tmp_path, bucket_mb):
     import torch.multiprocessing as mp

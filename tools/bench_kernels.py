@@ -39,9 +39,9 @@ SHAPES = [  # (mode, H, Cin, Cout)
     (ops.CONV_S1, 8, 512, 512), (ops.CONV_S2, 128, 128, 128), (ops.CONV_UP, 64, 128, 128), (ops.CONV_S1, 128, 64, 128),
 ]
 for dname in a.dtypes.split(","):
-    dt = ops.DTYPE_BF16 if dname == "bf16" else ops.DTYPE_F32
+    dt = {"bf16": ops.DTYPE_BF16, "fp16": ops.DTYPE_F16, "fp32": ops.DTYPE_F32}[dname]
     T = ops.TORCH_DTYPE[dt]
-    B = a.batch if dt == ops.DTYPE_BF16 else max(1, a.batch // 8)
+    B = a.batch if dt != ops.DTYPE_F32 else max(1, a.batch // 8)
     for si, (mode, H, Cin, Cout) in enumerate(SHAPES):
         if a.only >= 0 and si != a.only:
             continue

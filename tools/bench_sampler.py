@@ -12,12 +12,13 @@ p.add_argument("--lengths", default="49,121")
 p.add_argument("--steps", type=int, default=16)
 p.add_argument("--batch", type=int, default=128)
 p.add_argument("--graph", type=int, default=0)
+p.add_argument("--precision", default="bf16", help="bf16 | fp16 (BASELINE configs[4]) | fp32")
 a = p.parse_args()
 dev = torch.device("cuda:0")
 CFG = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3, padding_mode="zeros", attention_levels=[4])
 torch.manual_seed(0)
 net = ScoreUNet(channels=52, spatial=2, activation=torch.nn.SiLU, **CFG).to(dev).eval()
-net.precision = "bf16"
+net.precision = a.precision
 pipe = SDAPipeline()
 for L in [int(v) for v in a.lengths.split(",")]:
     sf = BatchedScoreFunction(net, markov_order=6, batch_size=a.batch, device=dev, noise_process=pipe)
