@@ -11,13 +11,17 @@
 //     index, 45 LDS-DMA pieces of 1 KiB);
 //   * a stage is one tap x HALF a K chunk (32 channels): the weight ring is 3 x 8 KiB ([128 co][64 B] rows, XOR-swizzled
 //     on the source address so that every ds_read_b128 lane group covers all 64 banks); 70.7 KB of LDS and
-//     247 VGPRs => two workgroups per CU, one barrier per 32 MFMAs per wave.
+//     253 VGPRs => two workgroups per CU, one barrier per 32 MFMAs per wave;
+//   * stages run kernel-column-major (half, kw, kh): the three taps of a column read the same pixel columns one row apart, so
+//     the pixel fragments stay in registers across kh -- 22 fragment reads per three stages instead of 36 (A/B on one box,
+//     128->128 @128^2: 0.606 vs 0.635 ms; the bias is loaded after the loop to make room: 16 VGPRs, no measurable cost).
 // MFMA shape and the epilogue (conv_epilogue.h: bias / SiLU / pair / multiplier / residual / fused LayerNorm forward and
 // backward, in two passes of 8 tile rows) are those of conv_patch_half_kernel; A = weights, B = pixels.
 // Tried and abandoned: a persistent variant (workgroup walks tiles, next tile's first patch chunk requested during the epilogue,
 // output staged behind the patch region): 141 spilled SGPRs -> 400-700 spilled VGPRs; the scalar state of two tiles plus the
 // argument block does not fit.
-// Measured and rejected on this kernel: a 4-slot weight ring (three stages of prefetch, 78.8 KB LDS) -1 %; pixel-fragment reads
+// Measured and rejected on this kernel (C2W_T3V bits 1, 4): the LDS-DMA of stage s + 2 issued behind the fragment reads, or behind
+// half of the stage's MFMAs, instead of right after the barrier: no change (0.636 / 0.639 vs 0.635 ms).  Also: a 4-slot weight ring (three stages of prefetch, 78.8 KB LDS) -1 %; pixel-fragment reads
 // hoisted above the barrier -0.7 %; residual rows prefetched for both 8-row blocks right after staging -0.5 %; prefetching them
 // next to live accumulators spills.
 // Lesson kept in the code below: nothing may spill -- scratch loads return out of order with the LDS-DMA loads and break the
@@ -26,6 +30,9 @@
 
 #include "conv_epilogue.h"
 
+#ifndef C2W_T3V
+#define C2W_T3V 10  // stage order / LDS-DMA placement / bias placement of conv_patch_t3_kernel (bits: see `stage` below); 10 = measured best
+#endif
 #ifndef C2W_EXP
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA
 #endif             // in the loop, 32 no epilogue (accumulators reduced to one store per lane)
@@ -155,61 +162,85 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
     const int NS = nchunk * 18;
 
     float bv[4][4];
-    if constexpr (TR == 16) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);  // two per CU: registers to spare, latency hidden by the loop
+    if constexpr (TR == 16 && (C2W_T3V & 8) == 0) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);  // latency hidden by the loop; 16 VGPRs
     issue_patch(0);
-    issue_w(0, 0, 0, 0);
-    issue_w(0, 0, 1, 1);
+    issue_w(0, 0, 0, 0);  // stage 0 = (tap 0, half 0) in both stage orders
+    if constexpr ((C2W_T3V & 2) != 0) issue_w(0, 3, 0, 1);  // kw-major: stage 1 = (kh 1, kw 0) = tap 3, half 0
+    else issue_w(0, 0, 1, 1);
 
-    // stage s = (chunk c, tap, half): weights of stage s live in ring slot s % 3 (18 stages per chunk: slot = (2 tap + half) % 3)
-    auto stage = [&](auto TAPc, auto HALFc, int c) {
-        constexpr int TAP = decltype(TAPc)::value, HALF = decltype(HALFc)::value;
-        constexpr int KH = TAP / 3, KW = TAP % 3, IDX = 2 * TAP + HALF, WS = IDX % 3;
+    // stage s = chunk c x 18 + IDX; IDX -> (tap, half): weights of stage s live in ring slot s % 3 (18 % 3 == 0).
+    //   C2W_T3V & 2 == 0: tap-major, IDX = 2 tap + half.
+    //   C2W_T3V & 2     : IDX = half * 9 + kw * 3 + kh.  The three taps of one kernel column read the SAME pixel columns (li + kw)
+    //     at rows n + kh, so the pixel fragments stay in registers across kh: 8 rows at kh = 0, one new row each at kh = 1, 2 --
+    //     22 ds_read_b128 per three stages instead of 36 (LDS bytes read per MFMA 0.23 KB instead of 0.375 KB).
+    //   C2W_T3V & 1: the LDS-DMA of stage s + 2 is issued behind the stage's fragment reads instead of in front of them;
+    //   C2W_T3V & 4: behind the first half of the stage's MFMAs (the ring slot it fills was released by the stage's barrier).
+    u32x4_t bq[4 * NB + 2];
+    auto stage = [&](auto IDXc, int c) {
+        constexpr int IDX = decltype(IDXc)::value;
+        constexpr bool KWM = (C2W_T3V & 2) != 0;
+        constexpr int HALF = KWM ? IDX / 9 : IDX % 2;
+        constexpr int KW = KWM ? (IDX % 9) / 3 : (IDX / 2) % 3;
+        constexpr int KH = KWM ? IDX % 3 : (IDX / 2) / 3;
+        constexpr int WS = IDX % 3;
         const int s = c * 18 + IDX;
+        auto issue_ahead = [&]() {  // weights of stage s + 2
+            constexpr int I2 = (IDX + 2) % 18;
+            constexpr int H2 = KWM ? I2 / 9 : I2 % 2;
+            constexpr int T2 = KWM ? (I2 % 3) * 3 + (I2 % 9) / 3 : I2 / 2;
+            issue_w(IDX + 2 < 18 ? c : c + 1, T2, H2, I2 % 3);
+        };
         t3_wait(s + 1 < NS ? 2 : 0);  // everything but the next stage's two weight pieces has landed
         __builtin_amdgcn_s_barrier();
+        bool ahead = s + 2 < NS;
         if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
             issue_patch(c);
-            if (s + 2 < NS) issue_w(c, 1, 0, 2);  // stage s + 2 = (c, tap 1, half 0) -> slot (s + 2) % 3 = 2
+            if (ahead) issue_ahead();
+            ahead = false;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // patch landed (once per chunk: no counting games here)
             __builtin_amdgcn_s_barrier();
-        } else if (s + 2 < NS) {
-            constexpr int I2 = IDX + 2;
-            if constexpr (I2 < 18) {
-                issue_w(c, I2 / 2, I2 % 2, I2 % 3);
-            } else {
-                issue_w(c + 1, (I2 - 18) / 2, (I2 - 18) % 2, I2 % 3);
-            }
+        } else if ((C2W_T3V & 5) == 0 && ahead) {
+            issue_ahead();
+            ahead = false;
         }
-        u32x4_t a[4], bq[4 * NB];
+        u32x4_t a[4];
         if constexpr ((C2W_EXP & 2) == 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[m] = *(const u32x4_t*)(smem + offA + m * 1024 + WS * T3_WBYTES);
+            if constexpr (!KWM || KH == 0) {
 #pragma unroll
-            for (int n = 0; n < 4 * NB; ++n) bq[n] = *(const u32x4_t*)(smem + (offB[KW] ^ (HALF * 64)) + (n + KH) * T3_PW * 128);
+                for (int n = 0; n < 4 * NB; ++n) bq[n + KH] = *(const u32x4_t*)(smem + (offB[KW] ^ (HALF * 64)) + (n + KH) * T3_PW * 128);
+            } else {
+                bq[4 * NB - 1 + KH] = *(const u32x4_t*)(smem + (offB[KW] ^ (HALF * 64)) + (4 * NB - 1 + KH) * T3_PW * 128);
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[m] = (u32x4_t){offA, (uint32_t)s, 3u, 4u};
 #pragma unroll
-            for (int n = 0; n < 4 * NB; ++n) bq[n] = (u32x4_t){offB[KW], (uint32_t)s, 5u, 6u};
+            for (int n = 0; n < 4 * NB; ++n) bq[n + KH] = (u32x4_t){offB[KW], (uint32_t)s, 5u, 6u};
+        }
+        if ((C2W_T3V & 1) != 0 && ahead) {
+            issue_ahead();
+            ahead = false;
         }
 #pragma unroll
-        for (int n = 0; n < 4 * NB; ++n)
+        for (int n = 0; n < 4 * NB; ++n) {
+            if ((C2W_T3V & 4) != 0 && n == 2 * NB && ahead) issue_ahead();
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if constexpr ((C2W_EXP & 1) == 0) {
-                    acc[n >> 2][m][n & 3] = mfma16<T>(a[m], bq[n], acc[n >> 2][m][n & 3]);
+                    acc[n >> 2][m][n & 3] = mfma16<T>(a[m], bq[n + KH], acc[n >> 2][m][n & 3]);
                 } else {
-                    asm volatile("" ::"v"(a[m]), "v"(bq[n]));
+                    asm volatile("" ::"v"(a[m]), "v"(bq[n + KH]));
                 }
             }
+        }
     };
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
-        stage(IC3<0>{}, IC3<0>{}, c); stage(IC3<0>{}, IC3<1>{}, c); stage(IC3<1>{}, IC3<0>{}, c); stage(IC3<1>{}, IC3<1>{}, c);
-        stage(IC3<2>{}, IC3<0>{}, c); stage(IC3<2>{}, IC3<1>{}, c); stage(IC3<3>{}, IC3<0>{}, c); stage(IC3<3>{}, IC3<1>{}, c);
-        stage(IC3<4>{}, IC3<0>{}, c); stage(IC3<4>{}, IC3<1>{}, c); stage(IC3<5>{}, IC3<0>{}, c); stage(IC3<5>{}, IC3<1>{}, c);
-        stage(IC3<6>{}, IC3<0>{}, c); stage(IC3<6>{}, IC3<1>{}, c); stage(IC3<7>{}, IC3<0>{}, c); stage(IC3<7>{}, IC3<1>{}, c);
-        stage(IC3<8>{}, IC3<0>{}, c); stage(IC3<8>{}, IC3<1>{}, c);
+        stage(IC3<0>{}, c); stage(IC3<1>{}, c); stage(IC3<2>{}, c); stage(IC3<3>{}, c); stage(IC3<4>{}, c); stage(IC3<5>{}, c);
+        stage(IC3<6>{}, c); stage(IC3<7>{}, c); stage(IC3<8>{}, c); stage(IC3<9>{}, c); stage(IC3<10>{}, c); stage(IC3<11>{}, c);
+        stage(IC3<12>{}, c); stage(IC3<13>{}, c); stage(IC3<14>{}, c); stage(IC3<15>{}, c); stage(IC3<16>{}, c); stage(IC3<17>{}, c);
     }
 
     if constexpr ((C2W_EXP & 32) != 0) {
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
     // epilogue: the residual / multiplier rows are fetched AFTER the accumulators have left the registers (the half-tile
     // kernel prefetches them next to live accumulators; that does not fit here) -- the co-resident workgroups cover the
     // exposed latency.  Output rows go through LDS in blocks of 128 (= 8 tile rows), one EpiStore pass each.
-    if constexpr (TR == 8) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    if constexpr (TR == 8 || (C2W_T3V & 8) != 0) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
     __syncthreads();
     char* const O = smem;
     float* const red = (float*)(smem + TR * 16 * T3_OS);
