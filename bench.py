@@ -59,13 +59,13 @@ class KernelTimer:
                 e0.record()
                 self._orig(x, w, bias, y, g, dtype, **kw)
                 e1.record()
-                self.events.append((e0, e1))
+                self.events.append((e0, e1, bias is not None))  # forward launches carry a bias, input-gradient launches do not
             else:
                 self._orig(x, w, bias, y, g, dtype, **kw)
         self.ops.conv = conv
 
-    def mean_ms(self):
-        ts = [a.elapsed_time(b) for a, b in self.events]
+    def mean_ms(self, forward_only=False):
+        ts = [a.elapsed_time(b) for a, b, fwd in self.events if fwd or not forward_only]
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
 
 
@@ -173,6 +173,13 @@ def main():
                         traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01g_pmc_conv_patch3_b128.md",
                         mfma_busy_pmc=0.556, clock_ghz_under_load_pmc=1.85,
                         launches_timed=k_n, avg_launch_ms=round(k_ms, 4), flops_per_launch=flops_launch)
+            # The input-gradient launches share the chip with the weight-gradient stream (engine.grad_stream): their durations
+            # include that interference.  The forward launches run alone: the kernel's own rate.
+            f_ms, f_n = timer.mean_ms(forward_only=True)
+            if f_ms:
+                roof["forward_launches_only"] = dict(launches_timed=f_n, avg_launch_ms=round(f_ms, 4),
+                                                     achieved=round(flops_launch / (f_ms * 1e-3) / 1e12, 1),
+                                                     frac=round(flops_launch / (f_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
         out = dict(metric="UNet denoise steps/sec (train fwd+bwd+allreduce+AdamW+EMA windows/s)", value=round(value, 2), unit="windows/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * elapsed / a.steps, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=a.precision, data="synthetic",

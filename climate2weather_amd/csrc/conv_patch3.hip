@@ -204,14 +204,31 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
             ahead = false;
         }
         u32x4_t a[4];
+        // C2W_T3V & 16 (with the column-major order): the pixel fragments do not depend on the stage's barrier (the patch is
+        // static for the whole chunk), so the rows the NEXT stage needs are read during THIS stage's MFMAs, into the registers
+        // of rows that have just died: only the four weight fragments are read between a barrier and its MFMAs.
+        constexpr bool ROLL = KWM && (C2W_T3V & 16) != 0;
+        constexpr int NXT = (IDX + 1) % 18, HALF_N = NXT / 9, KW_N = (NXT % 9) / 3;  // next stage (column-major order)
+        auto rowp = [&](int kw, int half, int row) { return (const u32x4_t*)(smem + (offB[kw] ^ (half * 64)) + row * T3_PW * 128); };
         if constexpr ((C2W_EXP & 2) == 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[m] = *(const u32x4_t*)(smem + offA + m * 1024 + WS * T3_WBYTES);
-            if constexpr (!KWM || KH == 0) {
+            if constexpr (!KWM) {
 #pragma unroll
-                for (int n = 0; n < 4 * NB; ++n) bq[n + KH] = *(const u32x4_t*)(smem + (offB[KW] ^ (HALF * 64)) + (n + KH) * T3_PW * 128);
+                for (int n = 0; n < 4 * NB; ++n) bq[n + KH] = *rowp(KW, HALF, n + KH);
+            } else if constexpr (!ROLL) {
+                if constexpr (KH == 0) {
+#pragma unroll
+                    for (int n = 0; n < 4 * NB; ++n) bq[n] = *rowp(KW, HALF, n);
+                } else {
+                    bq[4 * NB - 1 + KH] = *rowp(KW, HALF, 4 * NB - 1 + KH);
+                }
             } else {
-                bq[4 * NB - 1 + KH] = *(const u32x4_t*)(smem + (offB[KW] ^ (HALF * 64)) + (4 * NB - 1 + KH) * T3_PW * 128);
+                if constexpr (IDX == 0) {  // first stage of a chunk: nothing was prefetched (the patch has only just landed)
+#pragma unroll
+                    for (int n = 0; n < 4 * NB; ++n) bq[n] = *rowp(KW, HALF, n);
+                }
+                if constexpr (KH < 2) bq[4 * NB + KH] = *rowp(KW, HALF, 4 * NB + KH);  // the one new row of stage kh + 1
             }
         } else {
 #pragma unroll
@@ -222,6 +239,12 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
         if ((C2W_T3V & 1) != 0 && ahead) {
             issue_ahead();
             ahead = false;
+        }
+        u32x4_t bn[4 * NB];
+        constexpr bool PREF = ROLL && KH == 2 && IDX != 17 && (C2W_EXP & 2) == 0;  // next stage = first of the next kernel column
+        if constexpr (PREF) {  // rows 0 and 1 died with stage kh = 1
+            bn[0] = *rowp(KW_N, HALF_N, 0);
+            bn[1] = *rowp(KW_N, HALF_N, 1);
         }
 #pragma unroll
         for (int n = 0; n < 4 * NB; ++n) {
@@ -234,6 +257,13 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
                     asm volatile("" ::"v"(a[m]), "v"(bq[n + KH]));
                 }
             }
+            if constexpr (PREF) {
+                if (n + 2 < 4 * NB) bn[n + 2] = *rowp(KW_N, HALF_N, n + 2);  // row n + 2 of this column has just been used last
+            }
+        }
+        if constexpr (PREF) {
+#pragma unroll
+            for (int n = 0; n < 4 * NB; ++n) bq[n] = bn[n];
         }
     };
 #pragma unroll 1

@@ -190,6 +190,7 @@ class Engine:
         self._wpad: Dict[object, tuple] = {}   # (name, dtype) -> (version, zero-padded operand copy)
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
+        self._wg_stream = None  # second HIP stream for the weight-gradient launches (see _wg)
         self.attach(net)
 
     # ------------------------------------------------------------------ parameter storage
@@ -311,20 +312,60 @@ class Engine:
     def _gb(self, rec: ConvRec) -> torch.Tensor:
         return self.flat_grad[rec.b_off:]
 
+    # ------------------------------------------------------------------ weight gradients on a second stream
+    def grad_stream(self):
+        """The stream every write into ``flat_grad`` is enqueued on, or None (CPU tensors / C2W_WGRAD_STREAM=0: the current
+        stream).  A layer's weight gradient and its input gradient both depend only on the layer's output gradient; on one
+        stream they run back to back and the chip idles through every kernel's last round of workgroups, the 27-us split-K
+        reduction launches and the launch gaps.  On two streams the hardware dispatcher fills those holes with the other
+        stream's workgroups (the LDS footprints forbid real co-residency: 127 KB + 2 x 70.7 KB > 160 KB)."""
+        if self.flat is None or not self.flat.is_cuda or os.environ.get("C2W_WGRAD_STREAM") == "0":
+            return None
+        if self._wg_stream is None or self._wg_stream.device != self.flat.device:
+            self._wg_stream = torch.cuda.Stream(device=self.flat.device)
+        return self._wg_stream
+
+    def _on_grad_stream(self, fn, *tensors) -> None:
+        """Run ``fn`` (launches that read ``tensors`` and write gradient memory) on the gradient stream, behind everything
+        enqueued so far on the current stream.  The tensors were allocated on the current stream and may be dropped by the
+        caller before the gradient stream has read them: record_stream defers the reuse of their memory."""
+        side = self.grad_stream()
+        if side is None:
+            fn()
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            fn()
+
+    def join_grad_stream(self) -> None:
+        """Make the current stream wait for every gradient launch enqueued so far."""
+        side = self.grad_stream()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+
+    def _wg(self, x: torch.Tensor, gy: torch.Tensor, rec: ConvRec, g: dict, dt: int) -> None:
+        """dW, dbias of ``rec`` (dense operand) into the flat gradient buffer, on the gradient stream."""
+        self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec)), x, gy)
+
     def _wgrad(self, rec: ConvRec, x: torch.Tensor, gy: torch.Tensor, g: dict, dt: int) -> None:
         """dW (+ dbias) of ``rec`` into the flat gradient buffer; a padded-operand layer goes through a padded scratch."""
         if rec.kstride == rec.cin:
-            ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
+            self._wg(x, gy, rec, g, dt)
             return
-        n = rec.rows * rec.taps * rec.kstride
-        buf = self._gwpad.get(rec.name)
-        if buf is None or buf.device != self.flat.device:
-            buf = self._gwpad[rec.name] = torch.zeros(n, dtype=torch.float32, device=self.flat.device)
-        else:
-            buf.zero_()
-        ops.conv_wgrad(x, gy, buf, g, dt, dbias=self._gb(rec))
-        self.flat_grad[rec.w_off: rec.w_off + rec.rows * rec.taps * rec.cin].view(rec.rows, rec.taps, rec.cin).add_(
-            buf.view(rec.rows, rec.taps, rec.kstride)[:, :, : rec.cin])
+
+        def run():
+            n = rec.rows * rec.taps * rec.kstride
+            buf = self._gwpad.get(rec.name)
+            if buf is None or buf.device != self.flat.device:
+                buf = self._gwpad[rec.name] = torch.zeros(n, dtype=torch.float32, device=self.flat.device)
+            else:
+                buf.zero_()
+            ops.conv_wgrad(x, gy, buf, g, dt, dbias=self._gb(rec))
+            self.flat_grad[rec.w_off: rec.w_off + rec.rows * rec.taps * rec.cin].view(rec.rows, rec.taps, rec.cin).add_(
+                buf.view(rec.rows, rec.taps, rec.kstride)[:, :, : rec.cin])
+        self._on_grad_stream(run, x, gy)
 
     # ------------------------------------------------------------------ small helpers
     @staticmethod
@@ -340,7 +381,7 @@ class Engine:
         ops.conv(x, self._w(rec, DTYPE_F32), self._b(rec), y, g, DTYPE_F32, act=act)
         if tape is not None:
             def bw(gy: torch.Tensor) -> Optional[torch.Tensor]:
-                ops.conv_wgrad(x, gy, self._gw(rec), g, DTYPE_F32, dbias=self._gb(rec))
+                self._wg(x, gy, rec, g, DTYPE_F32)
                 tape.done(rec.w_off)
                 if not need_dx:
                     return None
@@ -353,7 +394,10 @@ class Engine:
                     gyT[:, :rows] = gy.reshape(-1)[: rows * rec.rows].view(rows, rec.rows).t()
                     dx = torch.zeros((rows, rec.cin), dtype=torch.float32, device=x.device)
                     gt = self._geom(rec.rows, 1, 1, rec.cin, 1, 1, rows, ld, rows, CONV_1X1)
-                    ops.conv_wgrad(self._w(rec, DTYPE_F32), gyT, dx, gt, DTYPE_F32)
+                    # same kernels, same split-K workspace as the weight gradients: same stream, then wait for the result
+                    wmat = self._w(rec, DTYPE_F32)
+                    self._on_grad_stream(lambda: ops.conv_wgrad(wmat, gyT, dx, gt, DTYPE_F32), gyT, dx)
+                    self.join_grad_stream()
                     return dx
                 dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
                 gd = self._geom(rows, 1, 1, rec.dg_ld, 1, 1, rec.cin, rec.cin, rec.cin, CONV_1X1)
@@ -465,9 +509,9 @@ class Engine:
                 (out, g2, r2), hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin), None
             if train:
                 def bw(gy):
-                    ops.conv_wgrad(h1, gy, self._gw(r2), g2, dt, dbias=self._gb(r2))
+                    self._wg(h1, gy, r2, g2, dt)
                     da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=d1, mulmode=mulmode)
-                    ops.conv_wgrad(h0, da1, self._gw(r1), g1, dt, dbias=self._gb(r1))
+                    self._wg(h0, da1, r1, g1, dt)
                     tape.done(r1.w_off)
                     dm = dm_all.view(-1)[b.mod_offset:]
                     # conv1's input gradient feeds LN's backward directly: fused into the conv epilogue where the kernel
@@ -501,13 +545,13 @@ class Engine:
             ops.conv(o, self._w(rp, dt), self._b(rp), out, gp, dt, res=xin)
             if train:
                 def bw(gy):
-                    ops.conv_wgrad(o, gy, self._gw(rp), gp, dt, dbias=self._gb(rp))
+                    self._wg(o, gy, rp, gp, dt)
                     do = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(gy, self._wT(rp, dt), None, do, self._geom(npix, 1, 1, Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
                     dqkv = torch.empty_like(qkv)
                     delta = torch.empty((npix,), dtype=torch.float32, device=dev)
                     ops.attention_backward(qkv, o, do, lse, delta, dqkv, B, Tn, Cc, dt)
-                    ops.conv_wgrad(hl, dqkv, self._gw(rq), gq, dt, dbias=self._gb(rq))
+                    self._wg(hl, dqkv, rq, gq, dt)
                     tape.done(rq.w_off)
                     dhl = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(dqkv, self._wT(rq, dt), None, dhl, self._geom(npix, 1, 1, 3 * Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
@@ -555,7 +599,7 @@ class Engine:
                 cur, g_h, r_h = conv3("unet." + lv.head_key, xin, Hp, Wp, Hc, Wc, CONV_S2)
                 if train:
                     def bw_head(gy, xin=xin, g=g_h, rec=r_h, Hp=Hp, Wp=Wp, Hc=Hc, Wc=Wc, lvl=i - 1):
-                        ops.conv_wgrad(xin, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
+                        self._wg(xin, gy, rec, g, dt)
                         tape.done(rec.w_off)
                         # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
                         return dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
@@ -597,7 +641,7 @@ class Engine:
                 if train:
                     def bw_tail(gy, xin=xin, hl=hl, g=g_t, rec=r_t, Hl=Hl, Wl=Wl, Hu=Hc, Wu=Wc, Cc=Cc, lvl=i - 1):
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient
-                        ops.conv_wgrad(hl, gy, self._gw(rec), g, dt, dbias=self._gb(rec))
+                        self._wg(hl, gy, rec, g, dt)
                         tape.done(rec.w_off)
                         gu = dgrad(rec, gy, Hu, Wu, Hu, Wu, CONV_S1, Cc)  # gradient w.r.t. the upsampled map
                         gl = torch.empty((B * Hl * Wl, Cc), dtype=T, device=dev)
@@ -613,7 +657,7 @@ class Engine:
                     def bw_tail0(gy, xin=xin, g=g_t, rec=r_t, Hc=Hc, Wc=Wc, Cc=lv.channels):
                         gw = dict(g)
                         gw["Cout"] = rec.rows
-                        ops.conv_wgrad(xin, gy, self._gw(rec), gw, dt, dbias=self._gb(rec))
+                        self._wg(xin, gy, rec, gw, dt)
                         tape.done(rec.w_off)
                         return dgrad(rec, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                     tape.steps.append(bw_tail0)
@@ -638,7 +682,7 @@ class Engine:
         def bw(gh: torch.Tensor) -> Optional[torch.Tensor]:
             gz = torch.empty_like(z)
             ops.silu_backward(z, gh, gz, z.numel(), DTYPE_F32)
-            ops.conv_wgrad(x, gz, self._gw(rec), g, DTYPE_F32, dbias=self._gb(rec))
+            self._wg(x, gz, rec, g, DTYPE_F32)
             tape.done(rec.w_off)
             if not need_dx:
                 return None
@@ -665,6 +709,7 @@ class Engine:
         gm = tape.meta["dm_all"]
         for bw in reversed(steps[:n_mlp]):
             gm = bw(gm)
+        self.join_grad_stream()  # every gradient is in flat_grad for whoever runs next on this stream (optimizer, autograd)
         tape.steps = []
         tape.gskip.clear()
         if not want_dx or dx0 is None:

@@ -15,6 +15,7 @@ the API:
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import re
 from typing import Callable, List, Optional, Sequence
@@ -84,7 +85,13 @@ class Trainer:
     def _on_progress(self, off: int) -> None:
         while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off:
             s, e = self.buckets[self._next_bucket]
-            self._works.append(dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            # issued from the stream the gradients are written on (engine.grad_stream): RCCL orders the collective behind the
+            # weight-gradient launches of this bucket without stalling the input-gradient chain on the main stream
+            side = self.eng.grad_stream()
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                self._works.append(dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             self._next_bucket += 1
 
     def _finish_allreduce(self) -> None:
