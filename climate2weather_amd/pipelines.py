@@ -61,7 +61,9 @@ class SDAPipeline:
                show_progressbar: bool = True, z_draws=None):
         """Same contract as the reference.  ``device=None`` follows the reference's default (CPU-resident state) unless the
         score function is device-resident, in which case the state stays on its GPU.  ``z_draws`` (extension, tests):
-        iterable of corrector normals to use instead of drawing them."""
+        iterable of corrector normals to use instead of drawing them.  ``noise`` of shape (M, L, F, H, W) (extension) co-samples
+        M ensemble members: every member evolves exactly as it would alone (the corrector's step size uses the member's own
+        mean(eps^2)), but their windows share the network batches."""
         fused = getattr(score_fn, "device_resident", False) and proc_x0 is None
         if device is None:
             device = score_fn.device if fused else torch.device("cpu")
@@ -102,9 +104,16 @@ class SDAPipeline:
                         else:
                             z.normal_()
                         eps = score_fn(x, t - dt)
-                        sumsq.zero_()
-                        ops.sumsq(eps, sumsq, n)
-                        ops.sampler_correct(x, eps, z, sumsq, nan_flag, n, tau, sg_n)
+                        if x.dim() == 5:  # co-sampled members: delta = tau / mean(eps^2) per member (src/thor/pipelines.py:84 on each)
+                            nm = n // x.shape[0]
+                            for m in range(x.shape[0]):
+                                sumsq.zero_()
+                                ops.sumsq(eps[m], sumsq, nm)
+                                ops.sampler_correct(x[m], eps[m], z[m], sumsq, nan_flag, nm, tau, sg_n)
+                        else:
+                            sumsq.zero_()
+                            ops.sumsq(eps, sumsq, n)
+                            ops.sampler_correct(x, eps, z, sumsq, nan_flag, n, tau, sg_n)
                 else:
                     x = self._sample_step(score_fn, x, t, dt, proc_x0=proc_x0)
                     for _ in range(corrections):
@@ -113,7 +122,8 @@ class SDAPipeline:
                         else:
                             z.normal_()
                         eps = score_fn(x, t - dt)
-                        delta = tau / eps.square().mean(dim=tuple(range(-len(shape), 0)), keepdim=True)
+                        red = tuple(range(-len(shape), 0)) if len(shape) != 5 else (-4, -3, -2, -1)  # co-sampled members: per member
+                        delta = tau / eps.square().mean(dim=red, keepdim=True)
                         x = x - (delta * eps + torch.sqrt(2 * delta) * z) * self.sigma(t - dt)
                         del eps
                     if torch.isnan(x).any():

@@ -1,6 +1,10 @@
 """Ensemble sampling driver: the inner loops of ``exp/downscaling.py:208-265`` without the xarray/netCDF I/O around
 them.  Members are sharded across ranks exactly as the reference does (``num_samples % world == 0``; rank r generates
-members ``r*n .. (r+1)*n - 1``; no collective); every member's trajectory lives in HBM for the whole run."""
+members ``r*n .. (r+1)*n - 1``; no collective); every member's trajectory lives in HBM for the whole run.
+``members_per_batch`` > 1 co-samples that many of a rank's members: their windows share the network batches, which is
+what fills an MI355X at the shipped trajectory lengths (L = 49: 37 windows per member; 288 GB of HBM hold hundreds of
+members' states and activations).  With ``corrections == 0`` (the shipped configuration) the members are the ones the
+one-by-one loop produces from the same seed; with corrections the corrector normals are drawn in another order."""
 from __future__ import annotations
 
 import os
@@ -17,7 +21,8 @@ def run_ensemble(net, pipeline: Optional[SDAPipeline] = None, *, length: int, n_
                  num_samples: int, steps: int = 256, corrections: int = 0, tau: float = 0.5, batch_size: int = 128,
                  A=None, y=None, std=None, gamma: float = 1e-2, exact_grad: bool = False, seed: int = 0, rank: Optional[int] = None,
                  world: Optional[int] = None, device=None, precision: Optional[str] = "bf16",
-                 on_sample: Optional[Callable[[int, torch.Tensor], None]] = None, show_progressbar: bool = False) -> List[Tuple[int, torch.Tensor]]:
+                 on_sample: Optional[Callable[[int, torch.Tensor], None]] = None, show_progressbar: bool = False,
+                 members_per_batch: int = 1) -> List[Tuple[int, torch.Tensor]]:
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     assert num_samples % world == 0, "Number of samples must be divisible by the number of devices."  # exp/downscaling.py:96-98
@@ -32,13 +37,19 @@ def run_ensemble(net, pipeline: Optional[SDAPipeline] = None, *, length: int, n_
     if A is not None:
         score_fn.condition_on(A=A, y=y, std=std, gamma=gamma, exact_grad=exact_grad)
     out = []
-    for i in range(per_gpu):
-        sample_id = rank * per_gpu + i
-        noise = torch.randn(length, n_vars, height, width, device=device)
-        x = pipeline.sample(score_fn, noise, steps=steps, corrections=corrections, tau=tau, device=device,
-                            show_progressbar=show_progressbar)
-        if on_sample is not None:
-            on_sample(sample_id, x)
+    group = max(1, int(members_per_batch))
+    for i0 in range(0, per_gpu, group):
+        ids = [rank * per_gpu + i for i in range(i0, min(i0 + group, per_gpu))]
+        noises = [torch.randn(length, n_vars, height, width, device=device) for _ in ids]  # one draw per member, in member order
+        if len(ids) == 1:
+            xs = [pipeline.sample(score_fn, noises[0], steps=steps, corrections=corrections, tau=tau, device=device,
+                                  show_progressbar=show_progressbar)]
         else:
-            out.append((sample_id, x))
+            xs = list(pipeline.sample(score_fn, torch.stack(noises, 0), steps=steps, corrections=corrections, tau=tau, device=device,
+                                      show_progressbar=show_progressbar))
+        for sample_id, x in zip(ids, xs):
+            if on_sample is not None:
+                on_sample(sample_id, x)
+            else:
+                out.append((sample_id, x))
     return out

@@ -61,6 +61,8 @@ class AbstractScoreFunction:
             return self.score_fn(x, t)
         if self._fused_guidance is not None:
             return self._guided_fused(x, t)
+        if x.dim() == 5:  # co-sampled members: log p sums over members, its gradient is per member -- member by member
+            return torch.stack([self(xm, t) for xm in x], 0)
         # eps - sigma * d(log p)/dx  (src/thor/score.py:24-35).  log p is a scalar, so its Jacobian is one reverse pass:
         # plain autograd gives what the reference's jacrev(chunk_size=1) gives.
         with torch.enable_grad():
@@ -98,7 +100,7 @@ class AbstractScoreFunction:
         g = self._fused_guidance
         dev = getattr(self, "device", x.device)
         xd = x.to(device=dev, dtype=torch.float32).contiguous()
-        L, F, H, W = xd.shape
+        L, F, H, W = xd.shape[-4:]
         if g.get("dev") != dev:
             g["y_dev"] = g["y"].to(device=dev, dtype=torch.float32).contiguous()
             std = g["std"].to(dev)
@@ -107,7 +109,11 @@ class AbstractScoreFunction:
         eps = self.score_fn(xd, t)
         mu, sigma = self.noise_process._mu_sigma_f(float(t))
         nobs = g["y_dev"].shape[0]
-        ops.guidance(xd, eps, g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma"])
+        if xd.dim() == 5:  # co-sampled ensemble members: the same observation guides every member, frame-locally
+            for m in range(xd.shape[0]):
+                ops.guidance(xd[m], eps[m], g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma"])
+        else:
+            ops.guidance(xd, eps, g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma"])
         return eps if x.device == dev else eps.to(x.device)
 
 
@@ -134,14 +140,20 @@ class _WindowScore(AbstractScoreFunction):
         return torch.cat((x[0, :k], x[:, k], x[-1, -k:]), dim=0)
 
     def score_fn(self, x, t):
-        """eps(x, t) over the whole trajectory x: (L, F, H, W)."""
+        """eps(x, t) over the whole trajectory x: (L, F, H, W) -- or over M co-sampled ensemble members (M, L, F, H, W):
+        the windows of all members form one list that is fed to the network ``batch_size`` at a time, so short
+        trajectories (37 windows at L = 49) still fill the chip (an extension: the reference samples members one by one,
+        exp/downscaling.py:248-265)."""
         if not _engine_ready(self.unet) or torch.is_grad_enabled() and x.requires_grad or _wrapped(x):
+            if x.dim() == 5:
+                return torch.stack([self._score_generic(xm, t) for xm in x], 0)
             return self._score_generic(x, t)  # differentiable / foreign-network path: same math through the module call
         k = self.markov_order
         w = 2 * k + 1
         src_dev = x.device
         xd = x.to(device=self.device, dtype=torch.float32).contiguous()
-        L, F, H, W = xd.shape
+        M = xd.shape[0] if xd.dim() == 5 else 1
+        L, F, H, W = xd.shape[-4:]
         nwin = L - w + 1
         if nwin < 1:
             raise ValueError(f"trajectory of {L} frames is shorter than the window {w}")
@@ -150,17 +162,29 @@ class _WindowScore(AbstractScoreFunction):
         lay = eng.layout
         if lay.in_channels != w * F:
             raise ValueError(f"network expects {lay.in_channels} channels, window gives {w * F}")
-        bs = self.batch_size or nwin
-        if self.use_graphs and xd.is_cuda and src_dev == self.device:
+        total = M * nwin
+        bs = self.batch_size or total
+        if xd.dim() == 5:  # co-sampled members: equal batches instead of full ones and a ragged tail (148 windows: 2 x 74, not 128 + 20)
+            bs = -(-total // -(-total // bs))
+        if self.use_graphs and xd.is_cuda and src_dev == self.device and xd.dim() == 4:
             return self._score_graphed(xd, t, eng, dt, lay, k, w, nwin, bs)
         eps = torch.empty_like(xd)
+        xs, es = xd.view(M, L, F, H, W), eps.view(M, L, F, H, W)
         td = torch.as_tensor(t).to(self.device)
-        for i0 in range(0, nwin, bs):
-            nw = min(bs, nwin - i0)
-            xin = torch.empty((nw * H * W, lay.cin_pad), dtype=TORCH_DTYPE[dt], device=self.device)
-            ops.window_gather(xd, xin, nw, F, H * W, k, i0, lay.cin_pad, dt)
-            y = eng.forward(None, td, dt, x_nhwc=xin, shape=(nw, w * F, H, W), nhwc_out=True)
-            ops.window_scatter(y, eps, nw, F, H * W, k, i0, nwin, lay.cout_pad, dt)
+        HW = H * W
+        for g0 in range(0, total, bs):
+            ng = min(bs, total - g0)
+            xin = torch.empty((ng * HW, lay.cin_pad), dtype=TORCH_DTYPE[dt], device=self.device)
+            segs, pos = [], 0
+            while pos < ng:  # the batch's windows, member by member: (member, first window, count, row offset in the batch)
+                m, i0 = divmod(g0 + pos, nwin)
+                nw = min(nwin - i0, ng - pos)
+                ops.window_gather(xs[m], xin[pos * HW:], nw, F, HW, k, i0, lay.cin_pad, dt)
+                segs.append((m, i0, nw, pos))
+                pos += nw
+            y = eng.forward(None, td, dt, x_nhwc=xin, shape=(ng, w * F, H, W), nhwc_out=True)
+            for m, i0, nw, pos in segs:
+                ops.window_scatter(y[pos * HW:], es[m], nw, F, HW, k, i0, nwin, lay.cout_pad, dt)
         return eps if src_dev == self.device else eps.to(src_dev)
 
     # hipGraph replay of the launch sequence (BASELINE.json configs[4]: "hipGraph-captured sampler step").  A score evaluation

@@ -372,6 +372,24 @@ def test_ensemble_driver_on_device():
         assert x.is_cuda and x.shape == (9, 2, 32, 32) and torch.isfinite(x).all()
     again = run_ensemble(net, world=2, rank=1, **kw)
     assert all(torch.equal(a[1], b[1]) for a, b in zip(out, again))
+    # co-sampled members (device-resident predictor + fused guidance, windows of both members in shared batches): the same
+    # members as one by one; fp32 so that a different kernel choice at another batch size cannot show (<= 1e-4), with a corrector
+    one = run_ensemble(net, world=1, rank=0, **dict(kw, precision="fp32", corrections=0))
+    co = run_ensemble(net, world=1, rank=0, members_per_batch=3, **dict(kw, precision="fp32", corrections=0, batch_size=5))
+    assert [i for i, _ in co] == [0, 1, 2, 3]
+    for (_, a_), (_, b_) in zip(one, co):
+        assert (a_ - b_).abs().max().item() <= 1e-4 * a_.abs().max().item()
+    pipe = SDAPipeline()
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=6, device=torch.device("cuda", 0), noise_process=pipe)
+    sf.condition_on(A=A, y=y, std=kw["std"], gamma=1e-2, exact_grad=False)
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(2, 9, 2, 32, 32, generator=g).cuda()
+    zs = [torch.randn(2, 9, 2, 32, 32, generator=g).cuda() for _ in range(3)]
+    net.precision = "fp32"
+    both = pipe.sample(sf, noise, steps=3, corrections=1, tau=0.4, show_progressbar=False, z_draws=zs)
+    for m in range(2):
+        alone = pipe.sample(sf, noise[m], steps=3, corrections=1, tau=0.4, show_progressbar=False, z_draws=[z[m] for z in zs])
+        assert (both[m] - alone).abs().max().item() <= 1e-4 * alone.abs().max().item()
 
 
 def test_reference_style_training_loop_on_the_module_api(golden_dir, tmp_path):

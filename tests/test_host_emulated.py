@@ -461,6 +461,43 @@ def test_ensemble_driver_shards_members_by_rank(emu):
     assert rc[0][1].shape == (5, 2, 16, 16)
 
 
+@pytest.mark.parametrize("cond", [False, True])
+def test_co_sampled_members_equal_members_sampled_one_by_one(emu, cond):
+    """members_per_batch > 1 (extension for short trajectories: the members' windows share the network batches) changes
+    nothing a member can see: same seed -> the same members as the reference's one-by-one loop (exp/downscaling.py:248-265),
+    unconditioned and under the experiment's operator; with a corrector, given the same normals, each member's step size
+    comes from its own mean(eps^2) (src/thor/pipelines.py:84)."""
+    from climate2weather_amd.sampling import run_ensemble
+    net = _tiny().eval()
+    kw = dict(length=6, n_vars=2, height=16, width=16, markov_order=1, num_samples=3, steps=3, batch_size=5, seed=11,
+              device=torch.device("cpu"), precision="fp32", world=1, rank=0)
+    if cond:
+        A = PoolStrideOperator(8, 2)
+        kw.update(A=A, y=A(torch.rand(6, 2, 16, 16, generator=torch.Generator().manual_seed(2))),
+                  std=torch.tensor([0.5, 0.3]).view(1, 2, 1, 1), gamma=1e-2, exact_grad=False)
+    one = run_ensemble(net, **kw)
+    for group in (2, 3, 8):
+        co = run_ensemble(net, members_per_batch=group, **kw)
+        assert [i for i, _ in co] == [0, 1, 2]
+        for (_, a), (_, b) in zip(one, co):
+            assert a.shape == b.shape == (6, 2, 16, 16)
+            assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    # corrector: same normals -> same members
+    pipe = SDAPipeline()
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+    if cond:
+        sf.condition_on(A=kw["A"], y=kw["y"], std=kw["std"], gamma=1e-2, exact_grad=False)
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(2, 6, 2, 16, 16, generator=g)
+    zs = [torch.randn(2, 6, 2, 16, 16, generator=g) for _ in range(2)]
+    both = pipe.sample(sf, noise, steps=2, corrections=1, tau=0.4, device=torch.device("cpu"), show_progressbar=False, z_draws=zs)
+    assert both.shape == (2, 6, 2, 16, 16)
+    for m in range(2):
+        alone = pipe.sample(sf, noise[m], steps=2, corrections=1, tau=0.4, device=torch.device("cpu"), show_progressbar=False,
+                            z_draws=[z[m] for z in zs])
+        assert torch.allclose(both[m], alone, atol=1e-5, rtol=1e-5)
+
+
 def test_module_under_torch_ddp_matches_golden_gradients(golden_dir, tmp_path):
     """INTEGRATION.md section 1, "nothing else changes": ScoreUNet wrapped in torch's DistributedDataParallel (what
     fabric.setup_module does, training_loop.py:116), autograd backward, torch.optim.AdamW.  Two gloo ranks, one item each:

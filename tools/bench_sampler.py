@@ -12,6 +12,7 @@ p.add_argument("--lengths", default="49,121")
 p.add_argument("--steps", type=int, default=16)
 p.add_argument("--batch", type=int, default=128)
 p.add_argument("--graph", type=int, default=0)
+p.add_argument("--members", type=int, default=1, help="co-sampled ensemble members (their windows share the network batches)")
 p.add_argument("--precision", default="bf16", help="bf16 | fp16 (BASELINE configs[4]) | fp32")
 a = p.parse_args()
 dev = torch.device("cuda:0")
@@ -24,7 +25,7 @@ for L in [int(v) for v in a.lengths.split(",")]:
     sf = BatchedScoreFunction(net, markov_order=6, batch_size=a.batch, device=dev, noise_process=pipe)
     if a.graph:
         sf.use_graphs = True
-    noise = torch.randn(L, 4, 128, 128, device=dev)
+    noise = torch.randn(L, 4, 128, 128, device=dev) if a.members == 1 else torch.randn(a.members, L, 4, 128, 128, device=dev)
     with contextlib.redirect_stdout(io.StringIO()):
         pipe.sample(sf, noise, steps=2, show_progressbar=False)
         torch.cuda.synchronize()
@@ -32,5 +33,5 @@ for L in [int(v) for v in a.lengths.split(",")]:
         pipe.sample(sf, noise, steps=a.steps, show_progressbar=False)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    nwin = L - 12
-    print(f"L={L} windows={nwin} graph={a.graph}: {a.steps / dt:8.2f} sampler steps/s  {nwin * a.steps / dt:9.1f} window-forwards/s  {1e3 * dt / a.steps:7.2f} ms/step", flush=True)
+    nwin = (L - 12) * a.members
+    print(f"L={L} members={a.members} windows={nwin} graph={a.graph}: {a.steps / dt:8.2f} sampler steps/s  {nwin * a.steps / dt:9.1f} window-forwards/s  {1e3 * dt / a.steps:7.2f} ms/step", flush=True)
