@@ -280,6 +280,12 @@ class Engine:
             return self.flat[rec.w_off:]
         return self.shadow_for(dt)[rec.w_off:]
 
+    def prepare_forward(self, dt: int) -> None:
+        """Build every lazily cached forward operand (16-bit weight shadow, padded input-conv weights) on the current stream,
+        so that forwards issued afterwards on other streams only read them."""
+        for rec in self.layout.convs.values():
+            self._w(rec, DTYPE_F32 if rec.lin else dt)
+
     def _b(self, rec: ConvRec) -> torch.Tensor:
         return self.flat[rec.b_off:]
 

@@ -11,6 +11,8 @@ term is one fused kernel instead of ``torch.func.jacrev``.
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import Optional
 
 import torch
@@ -172,19 +174,31 @@ class _WindowScore(AbstractScoreFunction):
         xs, es = xd.view(M, L, F, H, W), eps.view(M, L, F, H, W)
         td = torch.as_tensor(t).to(self.device)
         HW = H * W
-        for g0 in range(0, total, bs):
-            ng = min(bs, total - g0)
-            xin = torch.empty((ng * HW, lay.cin_pad), dtype=TORCH_DTYPE[dt], device=self.device)
-            segs, pos = [], 0
-            while pos < ng:  # the batch's windows, member by member: (member, first window, count, row offset in the batch)
-                m, i0 = divmod(g0 + pos, nwin)
-                nw = min(nwin - i0, ng - pos)
-                ops.window_gather(xs[m], xin[pos * HW:], nw, F, HW, k, i0, lay.cin_pad, dt)
-                segs.append((m, i0, nw, pos))
-                pos += nw
-            y = eng.forward(None, td, dt, x_nhwc=xin, shape=(ng, w * F, H, W), nhwc_out=True)
-            for m, i0, nw, pos in segs:
-                ops.window_scatter(y[pos * HW:], es[m], nw, F, HW, k, i0, nwin, lay.cout_pad, dt)
+        # Window batches are independent: with more than one they alternate between HIP streams, so that one batch's low-resolution
+        # levels (8x8: one workgroup per CU), HBM-bound passes and last rounds of workgroups overlap the other's full-chip
+        # convolutions.  Everything the batches share is read-only and prepared on the caller's stream first.
+        batches = [(g0, min(bs, total - g0)) for g0 in range(0, total, bs)]
+        streams = self._side_streams(len(batches)) if xd.is_cuda else []
+        if streams:
+            eng.prepare_forward(dt)
+            main = torch.cuda.current_stream()
+            for st in streams:
+                st.wait_stream(main)
+        for bi, (g0, ng) in enumerate(batches):
+            with (torch.cuda.stream(streams[bi % len(streams)]) if streams else contextlib.nullcontext()):
+                xin = torch.empty((ng * HW, lay.cin_pad), dtype=TORCH_DTYPE[dt], device=self.device)
+                segs, pos = [], 0
+                while pos < ng:  # the batch's windows, member by member: (member, first window, count, row offset in the batch)
+                    m, i0 = divmod(g0 + pos, nwin)
+                    nw = min(nwin - i0, ng - pos)
+                    ops.window_gather(xs[m], xin[pos * HW:], nw, F, HW, k, i0, lay.cin_pad, dt)
+                    segs.append((m, i0, nw, pos))
+                    pos += nw
+                y = eng.forward(None, td, dt, x_nhwc=xin, shape=(ng, w * F, H, W), nhwc_out=True)
+                for m, i0, nw, pos in segs:
+                    ops.window_scatter(y[pos * HW:], es[m], nw, F, HW, k, i0, nwin, lay.cout_pad, dt)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
         return eps if src_dev == self.device else eps.to(src_dev)
 
     # hipGraph replay of the launch sequence (BASELINE.json configs[4]: "hipGraph-captured sampler step").  A score evaluation
@@ -192,6 +206,16 @@ class _WindowScore(AbstractScoreFunction):
     # not the GPU, sets the step time.  Everything the kernels read is at fixed addresses: the trajectory tensor the sampler
     # updates in place, a persistent eps buffer and a one-element time buffer that is overwritten before each replay.
     use_graphs = False
+    num_streams = 4  # window batches of one score evaluation alternate between this many HIP streams (1: the caller's stream only)
+
+    def _side_streams(self, nbatches: int):
+        n = min(int(os.environ.get("C2W_SCORE_STREAMS", self.num_streams)), nbatches)  # env: diagnostic A/B
+        if n < 2:
+            return []
+        pool = self.__dict__.setdefault("_streams", [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=self.device))
+        return pool[:n]
 
     def _score_graphed(self, xd, t, eng, dt, lay, k, w, nwin, bs):
         L, F, H, W = xd.shape
