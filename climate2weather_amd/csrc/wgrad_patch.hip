@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include "conv_geom.h"
 
+#ifndef C2W_WPV
+#define C2W_WPV 0  // bit 0: patch fragments of the kh = 2 taps carried to the next K step (see the main loop): spills (252 + 12 VGPRs), off
+#endif
 #ifndef C2W_EXP
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA after the
 #endif             // first tile, 32 no epilogue
@@ -178,6 +181,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o1));
                 return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             };
+            // A K step covers two pixel rows, so the patch fragment of tap (kh = 2, kw) at step ks is the fragment of tap (kh = 0, kw)
+            // at step ks + 1 (same LDS addresses: the swizzle ignores the bits 2 * PPITCH pixels change): with C2W_WPV & 1 it is kept in
+            // registers -- 27 patch fragments per K tile instead of 36.  Not enabled: the kernel sits at 252 VGPRs and the 12 more spill.
+            bf16x8_t keep[3];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8_t a[MTW];
@@ -185,7 +192,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 for (int m = 0; m < MTW; ++m) a[m] = tr8(offA[m][0] + ks * 32 * 256, offA[m][1] + ks * 32 * 256);
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
-                    const bf16x8_t bfr = tr8(offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
+                    bf16x8_t bfr;
+                    if ((C2W_WPV & 1) != 0 && tp < 3 && ks > 0) bfr = keep[tp];
+                    else bfr = tr8(offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
+                    if ((C2W_WPV & 1) != 0 && tp >= 6) keep[tp - 6] = bfr;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) {
                         if constexpr ((C2W_EXP & 1) == 0) {
