@@ -104,6 +104,22 @@ struct EpiStore {
         issue_prefetch(p);
     }
 
+    // The same for a pass of conv_patch_t4_kernel: LDS row R = 32 g + col holds the pixel 4 g image rows below pix0's row, column
+    // col of a 32-pixel-wide tile (row j of each of the four waves).  R = r0 + 16 i  ->  g = i >> 1, col = 16 (i & 1) + r0.
+    __device__ __forceinline__ void prefetch_rows32(const C2wConvArgs& p, int tid, int co0, long long pix0, int W) {
+        static_assert(NTHR / SEGS == 16 && NROWS == 128, "16-bit tiles, 256 threads, 128 rows per pass");
+        const int r0 = tid / SEGS, cs = tid - r0 * SEGS;
+        const int c = co0 + cs * PER16;
+        const long long pitch = (long long)p.ldy * ESZ;
+        const long long off0 = c < p.Cout ? ((pix0 + r0) * p.ldy + c) * ESZ : -1;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const long long d = ((long long)(i >> 1) * 4 * W + 16 * (i & 1)) * pitch;
+            off[i] = off0 >= 0 ? off0 + d : -1;
+        }
+        issue_prefetch(p);
+    }
+
     __device__ __forceinline__ void issue_prefetch(const C2wConvArgs& p) {
         if constexpr (EARLY) {
             if (p.res != nullptr) {
