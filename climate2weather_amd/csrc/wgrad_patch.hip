@@ -326,7 +326,9 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     p.B = a.B; p.H = a.Hin; p.W = a.Win; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
     p.ktiles = a.B * (a.Hin >> 3) * (a.Win >> 4);
     const int tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
-    int nsplit = (256 + tilesMN - 1) / tilesMN;  // one resident workgroup per CU, one round: every extra workgroup costs 295 KB of atomics
+    // one resident workgroup per CU and ONE round: tilesMN * nsplit <= 256 (rounding up gave 270 workgroups for 384 -> 384 -- a
+    // second round for 14 of them: 155 us instead of one round's ~90 at 16x16); every workgroup costs 295 KB of partial sums
+    int nsplit = 256 / tilesMN;
     if (nsplit > p.ktiles) nsplit = p.ktiles;
     if (nsplit < 1) nsplit = 1;
     p.ktiles_per_split = (p.ktiles + nsplit - 1) / nsplit;
