@@ -104,6 +104,21 @@ struct EpiStore {
         issue_prefetch(p);
     }
 
+    // Tile of conv_patch_half_kernel<T, PAIR>: LDS row R = 16 * tile row + column; columns 0..7 are image `pixA`'s row, 8..15 the
+    // same row of the next image (HW pixels further), which is missing when nimg == 1.
+    __device__ __forceinline__ void prefetch_pair8(const C2wConvArgs& p, int tid, int co0, long long pixA, int HW, int nimg) {
+        constexpr int RS = NTHR / SEGS;
+        const int r0 = tid / SEGS, cs = tid - r0 * SEGS;
+        const int c = co0 + cs * PER16;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int R = r0 + RS * i, trow = R >> 4, col = R & 15, img = col >> 3;
+            const long long pix = pixA + (long long)img * HW + trow * 8 + (col & 7);
+            off[i] = (c < p.Cout && img < nimg) ? (pix * p.ldy + c) * ESZ : -1;
+        }
+        issue_prefetch(p);
+    }
+
     // The same for a pass of conv_patch_t4_kernel: LDS row R = 32 g + col holds the pixel 4 g image rows below pix0's row, column
     // col of a 32-pixel-wide tile (row j of each of the four waves).  R = r0 + 16 i  ->  g = i >> 1, col = 16 (i & 1) + r0.
     __device__ __forceinline__ void prefetch_rows32(const C2wConvArgs& p, int tid, int co0, long long pix0, int W) {

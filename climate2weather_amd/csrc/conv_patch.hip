@@ -262,7 +262,11 @@ __device__ __forceinline__ void wait_vm4(int n) {  // wave-uniform n in {0, 4}
     }
 }
 
-template <typename T>
+// PAIR: 8-pixel-wide images (the 8x8 bottleneck level): the 8x16 tile is TWO images side by side (b, b + 1), each with its own
+// zero halo -- patch columns 0..9 belong to image b, 10..19 to image b + 1; tile column c >= 8 reads patch column c + 2 + kw.
+// Replaces the per-tap gather kernel at that level (585 -> ~1000 TFLOP/s class); the fused LayerNorm epilogues (one image per
+// tile) are not available in this mode.
+template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wConvArgs p) {
     constexpr int ESZ = sizeof(T);
     constexpr int CK = 128 / ESZ;
@@ -283,13 +287,14 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     const int tn = L % nN, tm = L / nN;
     const int co0 = tn * 128;
     const int H = p.Hin, W = p.Win;
-    const int tw = W >> 4, tpi = (H >> 3) * tw;
-    const int b = tm / tpi, tt = tm - b * tpi;
+    const int tw = PAIR ? 1 : W >> 4, tpi = (H >> 3) * tw;
+    const int b = PAIR ? 2 * (tm / tpi) : tm / tpi, tt = tm - (tm / tpi) * tpi;
     const int ty = tt / tw, tx = tt - ty * tw;
     const int oh0 = ty << 3, ow0 = tx << 4;
 
     const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const int nimg = PAIR ? (b + 1 < p.B ? 2 : 1) : 1;  // images under the descriptor: a missing partner reads as zeros (out of range)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)(img_bytes * nimg));
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
 
     // patch pieces: 30 pieces over 4 waves = 8 rounds (pieces past the end repeat the last one)
@@ -301,10 +306,11 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         pc = pc < H_NPIECE ? pc : H_NPIECE - 1;
         const int pr = pc / 3, pg = pc - pr * 3;
         const int px = pg * 8 + (lane >> 3);
-        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
-        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+        const int pimg = PAIR && px >= 10 ? 1 : 0;  // PAIR: patch columns 10..19 = image b + 1
+        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px - 10 * pimg;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < (PAIR ? 20 : 18);
         const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
-        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)img_bytes + (lc << 4) : C2W_OOB;
         pdst[r] = pc * 1024;
     }
     uint32_t wvo[4];  // weight tile: 128 rows x 8 chunks = 4 rounds of 256 threads
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int px = li + kw;
+                const int px = li + kw + (PAIR && li >= 8 ? 2 : 0);
                 preB[ks][kw][n] = (uint32_t)(((wn * 4 + n) * PW + px) * 128 + (((ks * 4 + lg) ^ (px & 7)) << 4));
             }
     }
@@ -414,7 +420,8 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     C2W_STAMP(st2);
     unsigned long long sa = 0, sb = 0, sc = 0;
     EpiStore<T, 128, H_NTHR> est;
-    est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    if constexpr (PAIR) est.prefetch_pair8(p, tid, co0, ((long long)b * H + oh0) * W, H * W, nimg);
+    else est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
     C2W_STAMP(sa);
     __syncthreads();
     C2W_STAMP(sb);
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     C2W_STAMP(sc);
     __syncthreads();
     C2W_STAMP(st3);
-    if constexpr (ESZ == 2) {
+    if constexpr (ESZ == 2 && !PAIR) {
         if (p.ln_x != nullptr) est.finish_ln(p, O, OS, tid, b, red);
         else if (p.lnf_y != nullptr) est.finish_lnf(p, O, OS, tid, b);
         else est.finish(p, O, OS, tid);
@@ -472,6 +479,35 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace {
+template <typename T>
+int launch_pair(const C2wConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    const int nN = (a.Cout + 127) / 128;
+    const int nM = ((a.B + 1) >> 1) * (a.Hin >> 3);
+    conv_patch_half_kernel<T, true><<<nM * nN, H_NTHR, H_LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+// 8-pixel-wide images: two of them per 8x16 tile (conv_patch_half_kernel<T, PAIR>); no fused LayerNorm epilogues in that mode
+bool c2w_conv_pair_eligible(const C2wConvArgs& a) {
+    static const bool off = getenv("C2W_CONV_PAIR") != nullptr && atoi(getenv("C2W_CONV_PAIR")) == 0;
+    return !off && a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && a.Win == 8 && (a.Hin & 7) == 0 && a.ln_x == nullptr &&
+           a.lnf_y == nullptr && (long long)((a.B + 1) >> 1) * (a.Hin >> 3) * ((a.Cout + 127) / 128) < (1ll << 31);
+}
+
+int c2w_conv_patch_pair(const C2wConvArgs& a, int dtype, hipStream_t st) {
+    if (dtype == C2W_DTYPE_F32) return launch_pair<float>(a, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_pair<bf16_t>(a, st);
+    if (dtype == C2W_DTYPE_F16) return launch_pair<f16_t>(a, st);
+    return C2W_ERR_BAD_ARG;
+}
 
 bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // images that 8 x 16-pixel tiles cover exactly
     return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && (a.Win & 15) == 0 &&
