@@ -59,7 +59,9 @@ struct WpArgs {
 __device__ __forceinline__ uint32_t swzA(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
 __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2)); }
 
-template <typename T>
+// PAIR: 8-pixel-wide images (the 8x8 level): a K tile is the same 8 rows of TWO images side by side (tile columns 0..7 = image b,
+// 8..15 = image b + 1), each with its own zero halo -- patch columns 0..9 / 10..19, as in conv_patch_half_kernel<T, PAIR>.
+template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p) {
     constexpr int ESZ = sizeof(T);
     constexpr bool BF = ESZ == 2;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     const int tm = mn / ncib, cb = mn - tm * ncib;
     const int co0 = tm * COT, ci0 = cb * CIB;
     const int H = p.H, W = p.W;
-    const int tw = W >> 4, tpi = (H >> 3) * tw;
+    const int tw = PAIR ? 1 : W >> 4, tpi = (H >> 3) * tw;
     const int t0 = split * p.ktiles_per_split;
     const int t1 = (t0 + p.ktiles_per_split < p.ktiles) ? t0 + p.ktiles_per_split : p.ktiles;
 
@@ -97,7 +99,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
         const int s = tid + NTHREADS * i, row = s >> 4, pc = s & 15;
         const uint32_t lc = (uint32_t)pc ^ swzA(row);
         const int c = co0 + (int)lc * (16 / ESZ);
-        avo[i] = (c < p.Cout) ? (uint32_t)((((row >> 4) * W + (row & 15)) * p.ldy + c) * ESZ) : C2W_OOB;
+        if constexpr (PAIR) {  // tile column >= 8: the same row of the next image
+            avo[i] = (c < p.Cout) ? (uint32_t)((((row >> 4) * 8 + (row & 7)) * p.ldy + c) * ESZ) + (uint32_t)((row >> 3) & 1) * (uint32_t)((size_t)H * W * p.ldy * ESZ)
+                                  : C2W_OOB;
+        } else {
+            avo[i] = (c < p.Cout) ? (uint32_t)((((row >> 4) * W + (row & 15)) * p.ldy + c) * ESZ) : C2W_OOB;
+        }
     }
     // ---- patch pieces of this wave (4 rounds; pieces past the end repeat the last one)
     int ppr[4], ppx[4], pdst[4];
@@ -112,25 +119,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
         ppx[r] = px;
         pdst[r] = pc * 1024;
         plc[r] = (uint32_t)(((lane & 7) ^ swzP(pr * PPITCH + px)) << 4) + (uint32_t)ci0 * ESZ;
+        if constexpr (PAIR) {  // 8x8 images: one K tile per image pair, so the whole source offset is tile-independent -> kept in plc[r]
+            const int pimg = px >= 10 ? 1 : 0;
+            const int ih = pr - 1, iw = px - 1 - 10 * pimg;
+            const bool ok = (unsigned)ih < 8u && (unsigned)iw < 8u && px < 20;
+            plc[r] = ok ? (uint32_t)((ih * 8 + iw) * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)(64 * p.Cin * ESZ) + plc[r] : C2W_OOB;
+        }
     }
     const size_t ximg = (size_t)H * W * p.Cin * ESZ;
     const size_t yimg = (size_t)H * W * p.ldy * ESZ;
 
     auto issue = [&](int t, int slot) {
-        const int b = t / tpi, tt = t - b * tpi;
+        const int b = PAIR ? 2 * t : t / tpi, tt = PAIR ? 0 : t - (t / tpi) * tpi;  // PAIR: 8x8 images, one K tile per pair
         const int ty = tt / tw, tx = tt - ty * tw;
         const int oh0 = ty << 3, ow0 = tx << 4;
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.dy + (size_t)b * yimg, (uint32_t)yimg);
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg);
+        const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;  // a missing partner image reads as zeros (out of the descriptor's range)
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.dy + (size_t)b * yimg, (uint32_t)yimg * nimg);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg * nimg);
         char* const base = smem + slot * SLOT;
         const uint32_t aso = (uint32_t)((oh0 * W + ow0) * p.ldy) * ESZ;
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(ra, base + wid * 1024 + i * 8192, avo[i], aso);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ih = oh0 - 1 + ppr[r], iw = ow0 - 1 + ppx[r];
-            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && ppx[r] < 18;
-            const uint32_t voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + plc[r] : C2W_OOB;
+            uint32_t voff;
+            if constexpr (PAIR) {
+                voff = plc[r];
+            } else {
+                const int ih = oh0 - 1 + ppr[r], iw = ow0 - 1 + ppx[r];
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && ppx[r] < 18;
+                voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + plc[r] : C2W_OOB;
+            }
             glds16(rx, base + ABYTES + pdst[r], voff, 0);
         }
     };
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
             const int r = lg >> 1, c = 8 * (lg & 1) + qq + 4 * h;  // pixel (r + 2*ks, c) of the K tile
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int pix = (r + t / 3) * PPITCH + c + t % 3;
+                const int pix = (r + t / 3) * PPITCH + c + t % 3 + (PAIR ? 2 * (lg & 1) : 0);
                 offB[t][h] = (uint32_t)(ABYTES + pix * 128 + (((uint32_t)(nt * 2 + (pp >> 1)) ^ swzP(pix)) << 4) + 8 * (pp & 1));
             }
         }
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 const int r = kk >> 2, c = 4 * (kk & 3) + lg;
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
-                    const int pix = (r + tp / 3) * PPITCH + c + tp % 3;
+                    const int pix = (r + tp / 3) * PPITCH + c + tp % 3 + (PAIR && (kk & 2) ? 2 : 0);
                     const float bv = *(const float*)(S + ABYTES + pix * 128 + ((((uint32_t)(nt * 4 + (li >> 2))) ^ swzP(pix)) << 4) + (li & 3) * 4);
                     acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[tp][0], 0, 0, 0);
                 }
@@ -317,14 +336,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-template <typename T>
+template <typename T, bool PAIR>
 int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
     WpArgs p;
     p.dy = a.y; p.x = a.x; p.dw = dw; p.db = db;
     p.B = a.B; p.H = a.Hin; p.W = a.Win; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
-    p.ktiles = a.B * (a.Hin >> 3) * (a.Win >> 4);
+    p.ktiles = PAIR ? ((a.B + 1) >> 1) * (a.Hin >> 3) : a.B * (a.Hin >> 3) * (a.Win >> 4);
     const int tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
     // one resident workgroup per CU and ONE round: tilesMN * nsplit <= 256 (rounding up gave 270 workgroups for 384 -> 384 -- a
     // second round for 14 of them: 155 us instead of one round's ~90 at 16x16); every workgroup costs 295 KB of partial sums
@@ -335,12 +354,12 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
     nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
     p.ws = (c2w_g_ws != nullptr && need <= c2w_g_ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? c2w_g_ws : nullptr;
-    wgrad_patch_kernel<T><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
+    wgrad_patch_kernel<T, PAIR><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
         const int grid = (int)std::min<size_t>((per_split / 4 + C2W_RED_COLS - 1) / C2W_RED_COLS, 8192);
@@ -351,14 +370,25 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
 
 }  // namespace
 
+static bool wgrad_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per K tile
+    static const bool off = getenv("C2W_CONV_PAIR") != nullptr && atoi(getenv("C2W_CONV_PAIR")) == 0;
+    return !off && a.Win == 8 && a.Hin == 8;
+}
+
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
-    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && (a.Win & 15) == 0;
+    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && ((a.Win & 15) == 0 || wgrad_pair(a));
 }
 
 int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st) {
-    if (dtype == C2W_DTYPE_F32) return launch<float>(a, dw, db, st);
-    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t>(a, dw, db, st);
-    if (dtype == C2W_DTYPE_F16) return launch<f16_t>(a, dw, db, st);
+    if (wgrad_pair(a)) {
+        if (dtype == C2W_DTYPE_F32) return launch<float, true>(a, dw, db, st);
+        if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, true>(a, dw, db, st);
+        if (dtype == C2W_DTYPE_F16) return launch<f16_t, true>(a, dw, db, st);
+        return C2W_ERR_BAD_ARG;
+    }
+    if (dtype == C2W_DTYPE_F32) return launch<float, false>(a, dw, db, st);
+    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, false>(a, dw, db, st);
+    if (dtype == C2W_DTYPE_F16) return launch<f16_t, false>(a, dw, db, st);
     return C2W_ERR_BAD_ARG;
 }
 
