@@ -99,6 +99,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly one line, the JSON: everything else written to file descriptor 1 -- RCCL prints its version banner
+    # there from C, flushed at exit, i.e. AFTER the JSON -- goes to stderr; the JSON is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 or os.environ.get("C2W_FORCE_DIST"):  # C2W_FORCE_DIST: exercise the RCCL path with a single rank
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -219,7 +224,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(C, a.size, DEFAULT_CFG)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
