@@ -104,6 +104,23 @@ struct EpiStore {
         issue_prefetch(p);
     }
 
+    // 16-pixel-wide tile whose pixels are stored with stride 2 in both directions (one output-parity class of the stride-2
+    // input gradient): pix0 = NHWC index of the tile's first OUTPUT pixel, Wo = output image width.
+    __device__ __forceinline__ void prefetch_tile16_s2(const C2wConvArgs& p, int tid, int co0, long long pix0, int Wo) {
+        constexpr int RS = NTHR / SEGS;
+        static_assert(RS % 16 == 0 || 16 % RS == 0, "row step and tile width must nest");
+        const int r0 = tid / SEGS, cs = tid - r0 * SEGS;
+        const int c = co0 + cs * PER16;
+        const long long pitch = (long long)p.ldy * ESZ;
+        const long long off0 = c < p.Cout ? ((pix0 + (long long)(r0 >> 4) * 2 * Wo + (r0 & 15) * 2) * p.ldy + c) * ESZ : -1;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const long long d = (long long)((RS * i) >> 4) * 2 * Wo * pitch + (long long)((RS * i) & 15) * 2 * pitch;
+            off[i] = off0 >= 0 ? off0 + d : -1;
+        }
+        issue_prefetch(p);
+    }
+
     // Tile of conv_patch_half_kernel<T, PAIR>: LDS row R = 16 * tile row + column; columns 0..7 are image `pixA`'s row, 8..15 the
     // same row of the next image (HW pixels further), which is missing when nimg == 1.
     __device__ __forceinline__ void prefetch_pair8(const C2wConvArgs& p, int tid, int co0, long long pixA, int HW, int nimg) {

@@ -370,6 +370,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if (naive == 0 && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_s1(*a, dtype, st);
     if (naive == 0 && c2w_conv_pair_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_pair(*a, dtype, st);
+    if (naive == 0 && c2w_conv_ts2_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_ts2(*a, dtype, st);
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, naive, st);

@@ -450,6 +450,218 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Input gradient of the stride-2 convolutions (C2W_CONV_TS2) on the halo patch.  Output pixel (2i + py, 2j + px) of parity class
+// (py, px) receives   sum over kh in K(py), kw in K(px) of  w[.][kh*3 + kw][.] . dy[i + a(kh)][j + a(kw)],   K(0) = {1}, K(1) = {0, 2},
+// a(0) = 1, a(1) = a(2) = 0  (conv_geom.h::src_pixel, TS2) -- a stride-1 convolution over dy with 1 / 2 / 2 / 4 taps whose result
+// is stored with stride 2.  One workgroup = one class of one 8x16 tile of the dy grid: the same patch (origin (oh0 - 1, ow0 - 1),
+// as for the forward conv: offset a reads patch tap a + 1), the same 3-slot weight ring and MFMA tiling as
+// conv_patch_half_kernel; one launch per class.
+// Replaces the gather kernel's per-tap pixel gathers (295-440 TFLOP/s at B = 128).
+struct Ts2Tap { int t9, khp, kwp; };
+template <int CLS> struct Ts2Class;
+template <> struct Ts2Class<0> { static constexpr int NT = 1; static constexpr Ts2Tap taps[1] = {{4, 1, 1}}; };
+template <> struct Ts2Class<1> { static constexpr int NT = 2; static constexpr Ts2Tap taps[2] = {{3, 1, 2}, {5, 1, 1}}; };
+template <> struct Ts2Class<2> { static constexpr int NT = 2; static constexpr Ts2Tap taps[2] = {{1, 2, 1}, {7, 1, 1}}; };
+template <> struct Ts2Class<3> { static constexpr int NT = 4; static constexpr Ts2Tap taps[4] = {{0, 2, 2}, {2, 2, 1}, {6, 1, 2}, {8, 1, 1}}; };
+
+template <typename T, int CLS>
+__device__ __forceinline__ void conv_patch_ts2_class(const C2wConvArgs& p, char* smem, int L) {
+    typedef Ts2Class<CLS> TC;
+    constexpr int NT = TC::NT;
+    constexpr int PY = CLS >> 1, PX = CLS & 1;
+    constexpr int ESZ = sizeof(T);
+    constexpr int CK = 128 / ESZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int nN = (p.Cout + 127) / 128;
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hin, W = p.Win;  // the dy grid; the output grid is 2H x 2W
+    const int tw = W >> 4, tpi = (H >> 3) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 3, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    uint32_t pvo[8];
+    int pdst[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int pc = r * 4 + wid;
+        pc = pc < H_NPIECE ? pc : H_NPIECE - 1;
+        const int pr = pc / 3, pg = pc - pr * 3;
+        const int px = pg * 8 + (lane >> 3);
+        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+        const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+        pdst[r] = pc * 1024;
+    }
+    uint32_t wvo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * NT;
+    auto issue_stage_w = [&](int st) {  // weights of global stage st = chunk * NT + idx into ring slot st % 3
+        const int c2 = st / NT, i2 = st - c2 * NT;
+        int t9 = TC::taps[0].t9;
+#pragma unroll
+        for (int k = 1; k < NT; ++k) t9 = i2 == k ? TC::taps[k].t9 : t9;
+        const uint32_t so = (uint32_t)(t9 * p.Cin + c2 * CK) * ESZ;
+        const int wslot = st % 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rw, smem + H_PBYTES + wslot * WBYTES + wid * 1024 + i * 4096, wvo[i], so);
+    };
+    auto issue_patch = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) glds16(rx, smem + pdst[r], pvo[r], (uint32_t)chunk * 128u);
+    };
+
+    uint32_t offA[2][4], preB[2][3][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = wm * 64 + m * 16 + li;
+            offA[ks][m] = (uint32_t)(H_PBYTES + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int px = li + kw;
+                preB[ks][kw][n] = (uint32_t)(((wn * 4 + n) * PW + px) * 128 + (((ks * 4 + lg) ^ (px & 7)) << 4));
+            }
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue_patch(0);
+    issue_stage_w(0);
+    int np = 4;  // LDS-DMA pieces of the NEXT stage that may still be in flight when a stage starts
+    if (1 < NS) issue_stage_w(1);
+    else np = 0;
+    u32x4_t da[4] = {}, db[4] = {};
+
+    auto stage = [&](auto IDXc, int c) {
+        constexpr int IDX = decltype(IDXc)::value;
+        constexpr int KH = TC::taps[IDX].khp, KW = TC::taps[IDX].kwp;
+        const int s = c * NT + IDX;
+        const uint32_t wso = (uint32_t)(s % 3) * WBYTES;
+        wait_vm4(np);
+        __builtin_amdgcn_s_barrier();
+        if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+            issue_patch(c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        np = 0;
+        if (s + 2 < NS) {
+            issue_stage_w(s + 2);
+            np = 4;
+        }
+        u32x4_t a0[4], b0[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA[0][m] + wso);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b0[n] = *(const u32x4_t*)(smem + preB[0][KW][n] + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + offA[1][m] + wso);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) db[n] = *(const u32x4_t*)(smem + preB[1][KW][n] + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        stage(IC<0>{}, c);
+        if constexpr (NT > 1) stage(IC<1>{}, c);
+        if constexpr (NT > 2) {
+            stage(IC<2>{}, c);
+            stage(IC<3>{}, c);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+
+    float bv[4][4];  // after the loop: the 4-tap class is within a few registers of the 256 budget
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    constexpr int OS = 128 * ESZ + 16;
+    EpiStore<T, 128, H_NTHR> est;
+    est.prefetch_tile16_s2(p, tid, co0, ((long long)b * (2 * H) + 2 * oh0 + PY) * (2 * W) + 2 * ow0 + PX, 2 * W);
+    __syncthreads();
+    char* const O = smem;
+    epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
+    __syncthreads();
+    est.finish(p, O, OS, tid);
+}
+
+// One kernel per class (four launches): with the four bodies in one kernel the register allocation of the 4-tap class governs
+// all of them and the merged code spilled 144 VGPRs.
+template <typename T, int CLS>
+__global__ __launch_bounds__(H_NTHR, 2) void conv_patch_ts2_kernel(const C2wConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    conv_patch_ts2_class<T, CLS>(p, smem, L);
+}
+
+template <typename T, int CLS>
+int launch_ts2_class(const C2wConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_ts2_kernel<T, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    const int nN = (a.Cout + 127) / 128;
+    const int nM = a.B * (a.Hin >> 3) * (a.Win >> 4);
+    conv_patch_ts2_kernel<T, CLS><<<nM * nN, H_NTHR, H_LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
+    int rc = launch_ts2_class<T, 3>(a, st);
+    if (rc == 0) rc = launch_ts2_class<T, 1>(a, st);
+    if (rc == 0) rc = launch_ts2_class<T, 2>(a, st);
+    if (rc == 0) rc = launch_ts2_class<T, 0>(a, st);
+    return rc;
+}
+
 template <typename T>
 int launch(const C2wConvArgs& a, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
@@ -494,6 +706,21 @@ int launch_pair(const C2wConvArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 }  // namespace
+
+// input gradient of the stride-2 convs per output-parity class on the halo patch (conv_patch_ts2_kernel)
+bool c2w_conv_ts2_patch_eligible(const C2wConvArgs& a) {
+    static const bool off = getenv("C2W_CONV_TS2_PATCH") != nullptr && atoi(getenv("C2W_CONV_TS2_PATCH")) == 0;
+    return !off && a.mode == C2W_CONV_TS2 && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hin & 7) == 0 && (a.Win & 15) == 0 &&
+           a.ln_x == nullptr && a.lnf_y == nullptr && a.y2 == nullptr && a.act == C2W_ACT_NONE &&
+           (long long)a.B * (a.Hin >> 3) * (a.Win >> 4) * ((a.Cout + 127) / 128) * 4 < (1ll << 31);
+}
+
+int c2w_conv_patch_ts2(const C2wConvArgs& a, int dtype, hipStream_t st) {
+    if (dtype == C2W_DTYPE_F32) return launch_ts2<float>(a, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_ts2<bf16_t>(a, st);
+    if (dtype == C2W_DTYPE_F16) return launch_ts2<f16_t>(a, st);
+    return C2W_ERR_BAD_ARG;
+}
 
 // 8-pixel-wide images: two of them per 8x16 tile (conv_patch_half_kernel<T, PAIR>); no fused LayerNorm epilogues in that mode
 bool c2w_conv_pair_eligible(const C2wConvArgs& a) {

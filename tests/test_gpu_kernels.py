@@ -58,6 +58,8 @@ CONV_CASES = [
     (ops.CONV_TS2, 2, 8, 8, 128, 64, 64, 64),       # dgrad of a stride-2 conv: 8x8 dy -> 16x16 dx
     (ops.CONV_TS2, 4, 8, 8, 128, 64, 64, 64),       # same, a quarter of the pixels fills a tile: parity-class tiles (1/2/2/4 taps)
     (ops.CONV_TS2, 8, 16, 8, 64, 192, 192, 192),    # parity classes: 4 tiles per class, 2 images per tile, 2 channel tiles
+    (ops.CONV_TS2, 2, 16, 16, 128, 128, 128, 128),  # parity-class halo-patch kernel: 2 tiles per image, 2 K-chunks (bf16)
+    (ops.CONV_TS2, 3, 8, 32, 64, 192, 180, 192),    # same: two tiles per row, two channel tiles (second partial), masked weight rows
     (ops.CONV_1X1, 5, 1, 1, 64, 320, 320, 320),     # Linear on 5 rows
     (ops.CONV_1X1, 2, 8, 8, 128, 384, 384, 384),    # qkv-style 1x1
 ]
