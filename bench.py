@@ -218,6 +218,19 @@ def main():
         dts = time.perf_counter() - ts
         if out is not None:
             out["sampler_windows_per_s_per_gpu"] = round((L - w + 1) * a.sample_steps / dts, 1)
+        # BASELINE configs[3]: 64-member ensembles, 8 members per GPU, L = 49: the members' windows share the network batches
+        members, Ls = 8, 36 + w
+        noise = torch.randn(members, Ls, a.vars, a.size, a.size, device=dev)
+        nst = max(a.sample_steps, 6)
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer.pipeline.sample(sf, noise, steps=3, show_progressbar=False)  # the side streams' allocator pools fill on first use
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            trainer.pipeline.sample(sf, noise, steps=nst, show_progressbar=False)
+            torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
+        if out is not None:
+            out["sampler_cosampled_windows_per_s_per_gpu"] = round(members * (Ls - w + 1) * nst / dts, 1)
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
