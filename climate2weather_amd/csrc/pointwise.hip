@@ -380,6 +380,40 @@ __global__ __launch_bounds__(256) void mse_loss_grad_kernel(const T* __restrict_
 constexpr int LT_PT = 64;  // pixels per tile (256-B runs of every channel plane; ldc = 128 channels -> 33 KB of LDS)
 constexpr int LT_LD = LT_PT + 1;
 
+// Counter-based normal noise: Philox4x32-10 (key = seed, counter = index of a block of four consecutive elements) + Box-Muller.
+// Element e of a stream is lane e & 3 of block e >> 2, so any kernel can regenerate eps[e] instead of reading it: the training
+// step's eps = randn_like(x) (src/thor/pipelines.py:22-25) is never written to or read from HBM (3 x 545 MB per step at B = 128).
+__device__ __forceinline__ f32x4_t philox_normal4(uint32_t k0, uint32_t k1, unsigned long long blk) {
+    uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+    float sa, ca, sb, cb;
+    __sincosf(6.28318530717958647692f * u1, &sa, &ca);
+    __sincosf(6.28318530717958647692f * u3, &sb, &cb);
+    return (f32x4_t){ra * ca, ra * sa, rb * cb, rb * sb};
+}
+__device__ __forceinline__ float philox_normal1(uint32_t k0, uint32_t k1, unsigned long long e) { return philox_normal4(k0, k1, e >> 2)[(int)(e & 3)]; }
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long long n, uint32_t k0, uint32_t k1) {
+    const long long nb = (n + 3) >> 2;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (long long)gridDim.x * blockDim.x) {
+        const f32x4_t v = philox_normal4(k0, k1, (unsigned long long)b);
+        if (4 * b + 3 < n) {
+            *(f32x4_t*)(out + 4 * b) = v;
+        } else {
+            for (int i = 0; 4 * b + i < n; ++i) out[4 * b + i] = v[i];
+        }
+    }
+}
+
 // tile[c][px] = f(plane values) for c < ldc (zero beyond C / beyond HW)
 template <typename F>
 __device__ __forceinline__ void lt_load_planes(float* tile, int C, int ldc, int HW, int p0, size_t img_off, F&& f) {
@@ -406,26 +440,38 @@ __device__ __forceinline__ void lt_load_planes(float* tile, int C, int ldc, int 
     }
 }
 
-template <typename T>
+template <typename T, bool PHILOX = false>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                                  const float* __restrict__ musig, T* __restrict__ y, int B, int C, int HW,
-                                                                 int ldc, long long img_stride) {
+                                                                 int ldc, long long img_stride, uint32_t k0 = 0, uint32_t k1 = 0) {
     constexpr int P = Elem<T>::PER16;
     extern __shared__ float lt_tile[];
     const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
     for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
         const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
         float mu = 1.f, sg = 0.f;
-        if (eps) { mu = musig[2 * b]; sg = musig[2 * b + 1]; }
+        if (eps || PHILOX) { mu = musig[2 * b]; sg = musig[2 * b + 1]; }
         struct Ld {
-            const float *x, *eps; float mu, sg;
+            const float *x, *eps; float mu, sg; uint32_t k0, k1;
+            // x_t = fma(sigma, eps, mu * x) with the product rounded on its own: spelled out so that the kernel that reads eps
+            // and the one that regenerates it round identically (left to the compiler, the two contracted differently)
+            static __device__ __forceinline__ float mix(float mu, float xv, float sg, float e) { return __fmaf_rn(sg, e, __fmul_rn(mu, xv)); }
             __device__ __forceinline__ f32x4_t operator()(size_t o) const {
                 f32x4_t v = *(const f32x4_t*)(x + o);
-                if (eps) { const f32x4_t e = *(const f32x4_t*)(eps + o); v = mu * v + sg * e; }
+                if constexpr (PHILOX) {
+                    const f32x4_t e = philox_normal4(k0, k1, (unsigned long long)o >> 2);  // o is a multiple of 4 on this path
+                    v = (f32x4_t){mix(mu, v[0], sg, e[0]), mix(mu, v[1], sg, e[1]), mix(mu, v[2], sg, e[2]), mix(mu, v[3], sg, e[3])};
+                } else if (eps) {
+                    const f32x4_t e = *(const f32x4_t*)(eps + o);
+                    v = (f32x4_t){mix(mu, v[0], sg, e[0]), mix(mu, v[1], sg, e[1]), mix(mu, v[2], sg, e[2]), mix(mu, v[3], sg, e[3])};
+                }
                 return v;
             }
-            __device__ __forceinline__ float operator()(size_t o, int) const { return eps ? mu * x[o] + sg * eps[o] : x[o]; }
-        } ld{x, eps, mu, sg};
+            __device__ __forceinline__ float operator()(size_t o, int) const {
+                if constexpr (PHILOX) return mix(mu, x[o], sg, philox_normal1(k0, k1, (unsigned long long)o));
+                return eps ? mix(mu, x[o], sg, eps[o]) : x[o];
+            }
+        } ld{x, eps, mu, sg, k0, k1};
         lt_load_planes(lt_tile, C, ldc, HW, p0, (size_t)b * img_stride, ld);  // img_stride < C*HW: overlapping windows of a trajectory
         __syncthreads();
         const int npx = min(LT_PT, HW - p0);
@@ -440,10 +486,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __
     }
 }
 
-template <typename T>
+template <typename T, bool PHILOX = false>
 __global__ __launch_bounds__(256) void mse_loss_grad_tiled_kernel(const T* __restrict__ y, const float* __restrict__ eps, T* __restrict__ dy,
                                                                   float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale,
-                                                                  const float* __restrict__ dscale) {
+                                                                  const float* __restrict__ dscale, uint32_t k0 = 0, uint32_t k1 = 0) {
     if (dscale != nullptr) gscale *= dscale[0];
     constexpr int P = Elem<T>::PER16;
     extern __shared__ float lt_tile[];
@@ -452,10 +498,16 @@ __global__ __launch_bounds__(256) void mse_loss_grad_tiled_kernel(const T* __res
     for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
         const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
         struct Ld {
-            const float* eps;
-            __device__ __forceinline__ f32x4_t operator()(size_t o) const { return *(const f32x4_t*)(eps + o); }
-            __device__ __forceinline__ float operator()(size_t o, int) const { return eps[o]; }
-        } ld{eps};
+            const float* eps; uint32_t k0, k1;
+            __device__ __forceinline__ f32x4_t operator()(size_t o) const {
+                if constexpr (PHILOX) return philox_normal4(k0, k1, (unsigned long long)o >> 2);
+                return *(const f32x4_t*)(eps + o);
+            }
+            __device__ __forceinline__ float operator()(size_t o, int) const {
+                if constexpr (PHILOX) return philox_normal1(k0, k1, (unsigned long long)o);
+                return eps[o];
+            }
+        } ld{eps, k0, k1};
         lt_load_planes(lt_tile, C, ldc, HW, p0, (size_t)b * C * HW, ld);
         __syncthreads();
         const int npx = min(LT_PT, HW - p0);
@@ -822,6 +874,35 @@ extern "C" int c2w_mse_loss_grad_scaled(const void* y, const float* eps, void* d
 extern "C" int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc, float gscale,
                                  int dtype, void* stream) {
     return c2w_mse_loss_grad_scaled(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, nullptr, dtype, stream);
+}
+
+// ---- regenerated noise (philox_normal4): the noise tensor of the training step never exists in memory
+extern "C" int c2w_philox_normal(float* out, long long n, unsigned long long seed, void* stream) {
+    if (!out || n <= 0 || ((uintptr_t)out & 15) != 0) return C2W_ERR_BAD_ARG;
+    philox_normal_kernel<<<grid_for((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(out, n, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_nchw_to_nhwc_noise(const float* x, unsigned long long seed, const float* musig, void* y, int B, int C, int HW, int ldc,
+                                      int dtype, void* stream) {
+    if (!x || !y || !musig || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (lds > 64 * 1024) return C2W_ERR_UNSUPPORTED;  // caller materialises the stream with c2w_philox_normal instead
+    const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
+    DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T, true><<<nblk, 256, lds, (hipStream_t)stream>>>(
+                          x, nullptr, musig, (T*)y, B, C, HW, ldc, (long long)C * HW, (uint32_t)seed, (uint32_t)(seed >> 32))));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
+                                       float gscale, const float* scaler_state, int dtype, void* stream) {
+    if (!y || !dy || !loss_sum || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (lds > 64 * 1024) return C2W_ERR_UNSUPPORTED;
+    const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 2048);
+    DISPATCH_T(dtype, (mse_loss_grad_tiled_kernel<T, true><<<nblk, 256, lds, (hipStream_t)stream>>>(
+                          (const T*)y, nullptr, (T*)dy, loss_sum, B, C, HW, ldc, gscale, scaler_state, (uint32_t)seed, (uint32_t)(seed >> 32))));
+    return (int)hipGetLastError();
 }
 
 extern "C" int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {

@@ -416,7 +416,8 @@ class Engine:
     def forward(self, x: torch.Tensor, t: torch.Tensor, dt: int, tape: Optional[Tape] = None, noise: Optional[Tuple] = None,
                 want_dx: bool = False, nhwc_out: bool = False, x_nhwc: Optional[torch.Tensor] = None, shape=None):
         """eps_pred = ScoreUNet(x, t).  x: (B,C,H,W) fp32 on the GPU; t: numel 1 or B.
-        noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion.
+        noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion; eps may be an int
+        seed instead of a tensor: the kernel regenerates the Philox stream of that seed (ops.philox_normal) and eps never exists.
         With ``tape`` every op records its backward closure (training / exact guidance)."""
         lay = self.layout
         T = TORCH_DTYPE[dt]
@@ -461,7 +462,13 @@ class Engine:
             x0 = x_nhwc
         else:
             x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
-            ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
+            if noise is not None and isinstance(noise[0], int):  # regenerated noise: (seed, musig)
+                if not ops.nchw_to_nhwc_noise(x, noise[0], noise[1], x0, B, C, H * W, lay.cin_pad, dt):
+                    eps = torch.empty_like(x)
+                    ops.philox_normal(eps, eps.numel(), noise[0])
+                    ops.nchw_to_nhwc(x, eps, noise[1], x0, B, C, H * W, lay.cin_pad, dt)
+            else:
+                ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
 
         def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None, want_ln=None):
             """want_ln: None, or the consumer's LayerNorm to emit from this conv's epilogue: ("mod", modulation rows) for a

@@ -143,6 +143,28 @@ def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=Non
           "c2w_mse_loss_grad")
 
 
+def philox_normal(out, n, seed):
+    """out[:n] = the N(0,1) stream of ``seed`` (the one the *_noise launchers regenerate)."""
+    check(_lib.load().c2w_philox_normal(_p(out), n, int(seed), _stream()), "c2w_philox_normal")
+
+
+def nchw_to_nhwc_noise(x, seed, musig, y, B, C, HW, ldc, dtype) -> bool:
+    """nchw_to_nhwc with eps := philox stream of ``seed``; False if the shape is not supported (caller materialises the stream)."""
+    rc = _lib.load().c2w_nchw_to_nhwc_noise(_p(x), int(seed), _p(musig), _p(y), B, C, HW, ldc, dtype, _stream())
+    if rc == -3:
+        return False
+    check(rc, "c2w_nchw_to_nhwc_noise")
+    return True
+
+
+def mse_loss_grad_noise(y, seed, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=None) -> bool:
+    rc = _lib.load().c2w_mse_loss_grad_noise(_p(y), int(seed), _p(dy), _p(loss_sum), B, C, HW, ldc, gscale, _p(scaler), dtype, _stream())
+    if rc == -3:
+        return False
+    check(rc, "c2w_mse_loss_grad_noise")
+    return True
+
+
 def timestep_embedding(t, out, n, dim, max_period=10000.0):
     check(_lib.load().c2w_timestep_embedding(_p(t), _p(out), n, dim, max_period, _stream()), "c2w_timestep_embedding")
 

@@ -4,7 +4,9 @@
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL on ROCm).  What differs from the reference below
 the API:
-  * noise process, network forward, loss, and the whole backward are the engine's HIP sequences (no autograd graph);
+  * noise process, network forward, loss, and the whole backward are the engine's HIP sequences (no autograd graph); the noise
+    eps is a counter-based (Philox) stream that the input-conversion and the loss kernels each regenerate from a per-step seed,
+    so the (B, C, H, W) noise tensor is never written or read (``fused_noise=False`` or an injected ``eps`` restore the tensor);
   * gradients live in ONE flat fp32 buffer laid out in reverse finalisation order; while backward is still running,
     finished buckets of it are all-reduced over xGMI on RCCL's stream (replaces Lightning Fabric's DDP wrapper,
     training_loop.py:116,375-378) -- a sum; the 1/world_size mean is folded into the optimizer kernel;
@@ -34,7 +36,7 @@ class Trainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-3, ema_rates: Sequence[float] = (0.9999,),
                  precision: str = "bf16", batch_size: Optional[int] = None, loss_scaling: float = 1.0,
                  process_group=None, bucket_mb: float = 25.0, init_scale: float = 65536.0, growth_factor: float = 2.0,
-                 backoff_factor: float = 0.5, growth_interval: int = 2000):
+                 backoff_factor: float = 0.5, growth_interval: int = 2000, fused_noise: bool = True):
         self.net = net
         self.pipeline = pipeline or SDAPipeline()
         self.lr, self.lr_fn = lr, lr_fn
@@ -45,6 +47,8 @@ class Trainer:
         self.dt = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}[precision]
         self.scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
         self.loss_scaling = loss_scaling
+        self.fused_noise = fused_noise  # eps regenerated inside the kernels (Philox stream of a per-step seed) instead of randn_like(x)
+        self.last_noise_seed: Optional[int] = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.sync_grads = self.world > 1 or (bool(os.environ.get("C2W_FORCE_DIST")) and dist.is_initialized())
@@ -142,20 +146,31 @@ class Trainer:
         dev = x.device
         if t is None:
             t = torch.rand(B, dtype=torch.float32, device=dev)
+        seed = None
         if eps is None:
-            eps = torch.randn_like(x)
+            if self.fused_noise and x.is_cuda:  # one 62-bit seed per round from torch's CPU generator (no device synchronisation)
+                seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+                self.last_noise_seed = seed
+            else:
+                eps = torch.randn_like(x)
         t = t.reshape(-1).to(dev).float().contiguous()
-        eps = eps.contiguous()
+        if eps is not None:
+            eps = eps.contiguous()
         musig = torch.empty((B, 2), dtype=torch.float32, device=dev)
         ops.mu_sigma(t, musig, B, self.pipeline.eta)
         tape = Tape()
         if sync:
             tape.progress = self._on_progress
-        y = eng.forward(x, t, self.dt, tape=tape, noise=(eps, musig), nhwc_out=True)
+        y = eng.forward(x, t, self.dt, tape=tape, noise=(seed if seed is not None else eps, musig), nhwc_out=True)
         dy = torch.empty_like(y)
         self.loss_sum.zero_()
         n = B * C * H * W
-        ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, 2.0 * self.loss_scaling / n, self.dt, scaler=self.scaler)
+        gs = 2.0 * self.loss_scaling / n
+        if seed is None or not ops.mse_loss_grad_noise(y, seed, dy, self.loss_sum, B, C, H * W, lay.cout_pad, gs, self.dt, scaler=self.scaler):
+            if eps is None:  # shape outside the fused kernel: materialise the same stream
+                eps = torch.empty_like(x)
+                ops.philox_normal(eps, eps.numel(), seed)
+            ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, gs, self.dt, scaler=self.scaler)
         eng.backward(tape, dy)
         return self.loss_sum[0] * (self.loss_scaling / n)
 

@@ -133,6 +133,19 @@ int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum
 /* same with dy additionally multiplied by the device-resident loss scale scaler_state[0] (NULL = 1): fp16 training */
 int c2w_mse_loss_grad_scaled(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
                              float gscale, const float* scaler_state, int dtype, void* stream);
+/* Regenerated noise.  The training step's eps = randn_like(x) (src/thor/pipelines.py:22-25) is consumed twice -- by the forward
+ * process x_t = mu x + sigma eps and by the loss (eps_pred - eps)^2 -- and nowhere else.  A counter-based generator (Philox4x32-10 on
+ * the index of a block of four consecutive elements, Box-Muller) lets both kernels compute eps[e] instead of reading it:
+ *   c2w_philox_normal        out[e] = N(0,1) stream of `seed`                                 (tests; fallback for shapes the fused
+ *                                                                                             kernels do not take)
+ *   c2w_nchw_to_nhwc_noise   c2w_nchw_to_nhwc with eps := that stream (element index = NCHW linear index)
+ *   c2w_mse_loss_grad_noise  c2w_mse_loss_grad_scaled with eps := that stream
+ * Same seed => bit-identical eps in all three.  C2W_ERR_UNSUPPORTED: channel rows too wide for the LDS tile (use the fallback). */
+int c2w_philox_normal(float* out, long long n, unsigned long long seed, void* stream);
+int c2w_nchw_to_nhwc_noise(const float* x, unsigned long long seed, const float* musig, void* y, int B, int C, int HW, int ldc,
+                           int dtype, void* stream);
+int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
+                            float gscale, const float* scaler_state, int dtype, void* stream);
 /* model/score.py:14-34 */
 int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream);
 /* src/thor/pipelines.py:13-20: musig[i] = {mu(t_i), sigma(t_i)} */

@@ -355,6 +355,32 @@ def test_bf16_and_fp16_training_track_fp32_training():
         assert abs(a - b) <= 0.05 * a, (prec, a, b)
 
 
+def test_training_step_with_regenerated_noise_equals_the_step_on_the_written_noise_tensor():
+    """Trainer(fused_noise=True) (the default) never materialises eps: the input conversion and the loss regenerate the Philox stream of
+    the step's seed.  The same step on the tensor c2w_philox_normal writes for that seed gives the same parameters, EMA and loss."""
+    cfg = dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(21)
+        nets.append(ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg).cuda())
+    a = Trainer(nets[0], lr=1e-3, precision="bf16", ema_rates=[0.99])
+    b = Trainer(nets[1], lr=1e-3, precision="bf16", ema_rates=[0.99], fused_noise=False)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(4, 6, 32, 32, generator=g) * 0.5 + 0.5).cuda()
+    t = torch.rand(4, generator=g).cuda()
+    la = a.step(x, t=t)
+    assert a.last_noise_seed is not None and b.last_noise_seed is None
+    eps = torch.empty_like(x)
+    ops.philox_normal(eps, eps.numel(), a.last_noise_seed)
+    lb = b.step(x, t=t, eps=eps)
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    assert torch.equal(a.eng.flat, b.eng.flat) or (a.eng.flat - b.eng.flat).abs().max().item() <= 2e-6  # split-K order is the same; atomics in dm are not
+    assert (a.ema_flats[0] - b.ema_flats[0]).abs().max().item() <= 2e-6
+    s1 = a.last_noise_seed
+    a.step(x, t=t)
+    assert a.last_noise_seed != s1  # a fresh stream every step
+
+
 def test_ensemble_driver_on_device():
     """a14 on the GPU: members of one rank, conditioned with the experiment's operator, state resident in HBM, bf16 network."""
     from climate2weather_amd.sampling import run_ensemble

@@ -507,6 +507,42 @@ def test_attention(shape, dt):
     close(dq, dq_ref, dt, "attention bwd")
 
 
+def test_regenerated_noise_stream_and_the_kernels_that_consume_it():
+    """The training step's eps = randn_like(x) (src/thor/pipelines.py:22-25) as a counter-based stream: c2w_philox_normal writes it,
+    c2w_nchw_to_nhwc_noise / c2w_mse_loss_grad_noise regenerate it -- bit-identical to the launchers that read the written tensor;
+    the stream itself is standard normal (moments, tails, seed dependence)."""
+    d = dev()
+    n = 4_000_003  # not a multiple of 4: the tail of the last block
+    a, b, c = (torch.empty(n, device=d) for _ in range(3))
+    ops.philox_normal(a, n, 1234567890123)
+    ops.philox_normal(b, n, 1234567890123)
+    ops.philox_normal(c, n, 1234567890124)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+    assert abs(a.mean().item()) < 2e-3 and abs(a.var().item() - 1.0) < 3e-3
+    assert abs((a**4).mean().item() - 3.0) < 3e-2 and abs((a**3).mean().item()) < 1e-2
+    assert 5.0 < a.abs().max().item() < 6.5 and abs((a.abs() > 1.959964).float().mean().item() - 0.05) < 1e-3
+    assert abs(torch.corrcoef(torch.stack((a[:-1], a[1:])))[0, 1].item()) < 2e-3  # neighbours (the two Box-Muller outputs) uncorrelated
+    for dt in (F32, BF16, F16):
+        for (B, C, HW, ldc) in [(3, 13, 32 * 32, 64), (2, 65, 64 * 64, 128), (2, 6, 15 * 15, 8)]:  # last: HW % 4 != 0, scalar loads
+            seed = 77 + HW
+            x = rnd((B, C, HW), F32, 1)
+            eps = torch.empty(B * C * HW, device=d)
+            ops.philox_normal(eps, eps.numel(), seed)
+            musig = torch.rand(B, 2, device=d) + 0.1
+            y0 = torch.full((B * HW, ldc), 7.0, dtype=TD[dt], device=d)
+            y1 = y0.clone()
+            ops.nchw_to_nhwc(x, eps, musig, y0, B, C, HW, ldc, dt)
+            assert ops.nchw_to_nhwc_noise(x, seed, musig, y1, B, C, HW, ldc, dt)
+            assert torch.equal(y0, y1)
+            yy = rnd((B * HW, ldc), dt, 2)
+            dy0, dy1 = torch.empty_like(yy), torch.empty_like(yy)
+            l0, l1 = torch.zeros(1, device=d), torch.zeros(1, device=d)
+            ops.mse_loss_grad(yy, eps, dy0, l0, B, C, HW, ldc, 0.37, dt)
+            assert ops.mse_loss_grad_noise(yy, seed, dy1, l1, B, C, HW, ldc, 0.37, dt)
+            assert torch.equal(dy0, dy1)
+            assert abs(l0.item() - l1.item()) <= 1e-5 * abs(l0.item())  # atomics: summation order
+
+
 def test_conv_random_shapes_product_vs_direct_kernel():
     """Seeded sweep over the shape space the dispatcher splits between its kernels (halo-patch 8x16 / 16x16 tiles, gather
     256- and 128-pixel tiles, parity-class TS2): the product path against the one-thread-per-output direct kernel (naive=1),
