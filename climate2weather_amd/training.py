@@ -75,6 +75,7 @@ class Trainer:
             for e in self.ema_flats:
                 e.copy_(eng.flat)
         # all-reduce buckets over the flat gradient buffer, last bucket = first finalised
+        bucket_mb = float(os.environ.get("C2W_BUCKET_MB", bucket_mb))  # env: diagnostic sweep
         per = max(int(bucket_mb * (1 << 20) // 4), 1)
         self.buckets: List[tuple] = []
         end = n
