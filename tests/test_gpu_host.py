@@ -381,6 +381,36 @@ def test_training_step_with_regenerated_noise_equals_the_step_on_the_written_noi
     assert a.last_noise_seed != s1  # a fresh stream every step
 
 
+def test_two_stream_backward_equals_single_stream(monkeypatch):
+    """engine.grad_stream: weight gradients (+ their split-K reductions) on a second HIP stream, ordered by events, operands
+    record_stream'ed.  Gradients of four steps (lr = 0: fixed weights, fresh data) at a size where the kernels run long enough to
+    overlap, against the same steps with everything on one stream (C2W_WGRAD_STREAM=0): equal up to the order of the
+    modulation-gradient atomics (a race would show as garbage in some layer's gradient)."""
+    cfg = dict(embedding_dim=128, hidden_channels=[128, 128, 256], hidden_blocks=[2, 1, 1], attention_levels=[2], kernel_size=3, padding_mode="zeros")
+    grads, losses = [], []
+    for single in ("0", None):
+        if single is None:
+            monkeypatch.delenv("C2W_WGRAD_STREAM", raising=False)
+        else:
+            monkeypatch.setenv("C2W_WGRAD_STREAM", single)
+        torch.manual_seed(8)
+        net = ScoreUNet(channels=13, spatial=2, activation=torch.nn.SiLU, **cfg).cuda()
+        tr = Trainer(net, lr=0.0, weight_decay=0.0, precision="bf16", ema_rates=[], fused_noise=False)
+        assert (tr.eng.grad_stream() is None) == (single == "0")
+        g = torch.Generator().manual_seed(2)
+        gs, ls = [], []
+        for _ in range(4):
+            x = (torch.randn(16, 13, 64, 64, generator=g) * 0.5 + 0.5).cuda()
+            t, eps = torch.rand(16, generator=g).cuda(), torch.randn(16, 13, 64, 64, generator=g).cuda()
+            ls.append(float(tr.step(x, t=t, eps=eps)))
+            gs.append(tr.eng.flat_grad.clone())
+        grads.append(gs)
+        losses.append(ls)
+    assert max(abs(p - q) for p, q in zip(*losses)) <= 1e-5  # the loss sum itself is reduced with atomics
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
+
+
 def test_ensemble_driver_on_device():
     """a14 on the GPU: members of one rank, conditioned with the experiment's operator, state resident in HBM, bf16 network."""
     from climate2weather_amd.sampling import run_ensemble
