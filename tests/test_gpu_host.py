@@ -411,6 +411,27 @@ def test_two_stream_backward_equals_single_stream(monkeypatch):
         assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
 
 
+def test_window_batches_on_several_streams_equal_one_stream(monkeypatch):
+    """A score evaluation whose window batches alternate between HIP streams (score_fn.num_streams) is the same arithmetic as on one
+    stream: bit-identical eps for 3 co-sampled members in 5 batches, repeated to give a race the chance to show."""
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").cuda().eval()
+    net.precision = "bf16"
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=8, device=torch.device("cuda", 0), noise_process=SDAPipeline())
+    x = torch.randn(3, 14, 2, 64, 64, device="cuda")  # 3 members x 12 windows = 36 windows -> 5 balanced batches
+    t = torch.tensor(0.4)
+    with torch.no_grad():
+        monkeypatch.setenv("C2W_SCORE_STREAMS", "1")
+        ref = sf.score_fn(x, t).clone()
+        monkeypatch.setenv("C2W_SCORE_STREAMS", "4")
+        for _ in range(6):
+            out = sf.score_fn(x, t)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+    assert len(sf._side_streams(5)) == 4
+
+
 def test_ensemble_driver_on_device():
     """a14 on the GPU: members of one rank, conditioned with the experiment's operator, state resident in HBM, bf16 network."""
     from climate2weather_amd.sampling import run_ensemble
