@@ -210,6 +210,10 @@ class Engine:
                 # the Parameter OBJECT stays (optimizers, DDP reducers and EMA copies made before the first forward hold it, as
                 # training_loop.py:116-131 does); only its storage moves into the flat buffer
                 params[name].data = view
+        # `p.data = view` leaves each Parameter its own version counter: writes through the Parameter objects (torch.optim steps,
+        # load_state_dict, EMA copies) never bump flat._version, so the cache key folds the Parameters' counters in (_version)
+        self._bound = [params[name] for name in lay.views]
+        self._pver = self._param_versions()
         self.flat = flat
         self.flat_grad = None
         self.shadows.clear()
@@ -245,13 +249,23 @@ class Engine:
                 mod._parameters[attr].grad = torch.as_strided(self.flat_grad, shape, strides, off)
         return self.flat_grad
 
+    def _param_versions(self) -> int:
+        return sum(p._version for p in self._bound)
+
+    def refresh_version(self) -> None:
+        """Re-read the bound Parameters' version counters (once per forward: 228 attribute reads, not one set per launch)."""
+        self._pver = self._param_versions()
+
     def _version(self):
-        return (self.flat._version, self._manual_ver)
+        """Key of every cache derived from the weights (16-bit shadow, padded input-conv operand, input-gradient operands):
+        in-place writes on the flat buffer, raw-pointer writers (weights_changed) and writes through the Parameter objects."""
+        return (self.flat._version, self._manual_ver, self._pver)
 
     def weights_changed(self, shadow_fresh: Optional[int] = None) -> None:
         """Call after the flat buffer was rewritten through raw pointers (fused optimizer): torch's version counter
         does not see those writes.  ``shadow_fresh``: the 16-bit dtype whose shadow the writer also refreshed."""
         self._manual_ver += 1
+        self.refresh_version()
         if shadow_fresh is not None and shadow_fresh in self.shadows:
             self._shadow_ver[shadow_fresh] = self._version()
 
@@ -283,6 +297,7 @@ class Engine:
     def prepare_forward(self, dt: int) -> None:
         """Build every lazily cached forward operand (16-bit weight shadow, padded input-conv weights) on the current stream,
         so that forwards issued afterwards on other streams only read them."""
+        self.refresh_version()
         for rec in self.layout.convs.values():
             self._w(rec, DTYPE_F32 if rec.lin else dt)
 
@@ -420,6 +435,7 @@ class Engine:
         seed instead of a tensor: the kernel regenerates the Philox stream of that seed (ops.philox_normal) and eps never exists.
         With ``tape`` every op records its backward closure (training / exact guidance)."""
         lay = self.layout
+        self.refresh_version()
         T = TORCH_DTYPE[dt]
         if x_nhwc is not None:  # rows already in the network's input layout (the sampler's fused window gather)
             B, C, H, W = shape

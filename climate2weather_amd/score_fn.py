@@ -40,6 +40,19 @@ class PoolStrideOperator:
         return self._pool(x[:: self.t_step])  # differentiable / host path: the same torch ops as the reference
 
 
+def per_channel_std(std, y) -> Optional[torch.Tensor]:
+    """The observation noise as the fused guidance kernel indexes it -- one value, or one per variable -- or None when ``std``
+    broadcasts against ``err = y - A(x0)`` of shape (nobs, F, h, w) in any other way (src/thor/score.py:55: ``std**2``
+    broadcasts like any tensor; the experiments pass (1, F, 1, 1), exp/downscaling.py:236-242)."""
+    std = torch.as_tensor(std, dtype=torch.float32)
+    if std.numel() == 1:
+        return std.reshape(1)
+    F = int(y.shape[-3]) if hasattr(y, "shape") and len(y.shape) >= 3 else None
+    if F is not None and std.numel() == F and std.dim() >= 3 and tuple(std.shape[-3:]) == (F, 1, 1):
+        return std.reshape(F)
+    return None
+
+
 class AbstractScoreFunction:
     device_resident = True
 
@@ -95,7 +108,9 @@ class AbstractScoreFunction:
         self.likelihood = log_p
         self._fused_guidance = None
         if isinstance(A, PoolStrideOperator) and not exact_grad:
-            self._fused_guidance = dict(A=A, y=y, std=torch.as_tensor(std, dtype=torch.float32).reshape(-1), gamma=float(gamma))
+            std_c = per_channel_std(std, y)
+            if std_c is not None:  # any other broadcastable std (per pixel, per observation, ...) takes the autograd path above
+                self._fused_guidance = dict(A=A, y=y, std=std_c, gamma=float(gamma))
         return self
 
     def _guided_fused(self, x, t):

@@ -26,7 +26,7 @@ import torch.distributed as dist
 
 from . import ops
 from .pipelines import SDAPipeline
-from .score_fn import BatchedScoreFunction, PoolStrideOperator
+from .score_fn import BatchedScoreFunction, PoolStrideOperator, per_channel_std
 
 
 def partition_frames(length: int, world: int, markov_order: int) -> List[Tuple[int, int]]:
@@ -114,7 +114,10 @@ class TimeShardedScoreFunction(BatchedScoreFunction):
         nobs = 0 if first >= self.e else (self.e - 1 - first) // t_step + 1
         i0 = first // t_step
         y_loc = y[i0:i0 + nobs].to(device=self.device, dtype=torch.float32).contiguous()
-        std = torch.as_tensor(std, dtype=torch.float32).reshape(-1).to(self.device)
+        std = per_channel_std(std, y)
+        if std is None:
+            raise NotImplementedError("time-sharded guidance takes a scalar std or one value per variable, shape (1, F, 1, 1)")
+        std = std.to(self.device)
         self._guide = dict(A=A, y=y_loc, std=std, gamma=float(gamma), off=first - self.s, nobs=nobs)
         return self
 

@@ -6,8 +6,9 @@ module object directly (``exp/downscaling.py:110-126``).  Unpickling that file n
 (``model``, ``thor``, ``util``, ``zuko``) on the path.  ``load_network_snapshot`` does not: class references into those
 packages are mapped to stand-ins that only hold state, the module tree's ``state_dict`` (the 228 reference key names) is
 read off, the constructor arguments are inferred from the tensor shapes, and the weights are loaded into
-``climate2weather_amd.score.ScoreUNet``.  Everything outside an allow-list of modules is refused, so the loader does not
-execute arbitrary pickled callables.
+``climate2weather_amd.score.ScoreUNet``.  Globals are resolved from an allow-list of exact (module, name) pairs (tensor
+rebuild helpers, ``torch.nn`` module classes, storages through the weights-only loader, this package's own classes); dotted
+names and everything else are refused.
 """
 from __future__ import annotations
 
@@ -23,10 +24,33 @@ from .pipelines import SDAPipeline
 from .score import ScoreUNet
 from .util import EasyDict
 
-_REF_PACKAGES = ("model", "zuko", "thor", "src")
-_SAFE_PREFIXES = ("torch", "collections", "numpy", "_codecs", "copyreg", "builtins")
-_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice",
-                  "range", "object", "getattr"}
+_REF_MODULE_PACKAGES = ("model", "zuko")   # nn.Module subclasses of the reference: only their _parameters / _modules are read
+_REF_OBJECT_PACKAGES = ("thor", "src")     # plain objects of the reference: attributes only
+
+# Exact (module, name) pairs a snapshot may reference; nothing is matched by prefix and no dotted name is resolved (pickle protocol 4
+# resolves "a.b" through getattr, which would reach e.g. torch.serialization.os.system through an allowed module).
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch", "Size"), ("torch", "device"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("_codecs", "encode"),
+    ("climate2weather_amd.score", "ScoreUNet"), ("climate2weather_amd.nn", "UNet"), ("climate2weather_amd.nn", "ModResidualBlock"),
+    ("climate2weather_amd.nn", "AttentionBlock"), ("climate2weather_amd.pipelines", "SDAPipeline"), ("climate2weather_amd.util", "EasyDict"),
+}
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range"}
+_TORCH_DTYPES = {n for n in dir(torch) if isinstance(getattr(torch, n), torch.dtype)}
+_TORCH_NN_MODULES = ("torch.nn.modules.activation", "torch.nn.modules.container", "torch.nn.modules.conv", "torch.nn.modules.flatten",
+                     "torch.nn.modules.linear", "torch.nn.modules.upsampling", "torch.nn.modules.normalization", "torch.nn.modules.dropout",
+                     "torch.nn.modules.pooling")
+
+
+def _storage_from_bytes(b: bytes):
+    """``torch.storage._load_from_bytes`` re-enters ``torch.load(weights_only=False)`` = a second, unrestricted unpickler; storages
+    need no more than the weights-only loader."""
+    return torch.load(io.BytesIO(b), weights_only=True)
 
 
 class _RefModule(torch.nn.Module):
@@ -43,21 +67,30 @@ class _RefObject:
 
 class _SnapshotUnpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str) -> Any:
+        if "." in name:
+            raise pickle.UnpicklingError(f"refusing dotted global {module}.{name} in a network snapshot")
         root = module.split(".")[0]
         if module == "util" and name == "EasyDict":
             return EasyDict
         if module in ("thor.pipelines", "src.thor.pipelines") and name == "SDAPipeline":
             return SDAPipeline
-        if module.startswith("climate2weather_amd"):
+        if root in _REF_MODULE_PACKAGES:
+            return _RefModule
+        if root in _REF_OBJECT_PACKAGES:
+            return _RefObject
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _storage_from_bytes
+        if module == "builtins" and name in _SAFE_BUILTINS:
             return super().find_class(module, name)
-        if root in _REF_PACKAGES:
-            # modules in model/ and zuko.nn are nn.Modules; anything else from the reference keeps its attributes only
-            return _RefModule if root in ("model", "zuko") else _RefObject
-        if root == "builtins":
-            if name in _SAFE_BUILTINS:
-                return super().find_class(module, name)
-            raise pickle.UnpicklingError(f"refusing builtins.{name} in a network snapshot")
-        if any(module == p or module.startswith(p + ".") for p in _SAFE_PREFIXES):
+        if module == "torch" and (name in _TORCH_DTYPES or name.endswith("Storage")):
+            obj = super().find_class(module, name)
+            if isinstance(obj, torch.dtype) or (isinstance(obj, type) and name.endswith("Storage")):
+                return obj
+        if module in _TORCH_NN_MODULES:
+            obj = super().find_class(module, name)
+            if isinstance(obj, type) and issubclass(obj, torch.nn.Module):
+                return obj
+        if (module, name) in _SAFE_GLOBALS:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"refusing {module}.{name} in a network snapshot")
 

@@ -36,7 +36,7 @@ class Trainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-3, ema_rates: Sequence[float] = (0.9999,),
                  precision: str = "bf16", batch_size: Optional[int] = None, loss_scaling: float = 1.0,
                  process_group=None, bucket_mb: float = 25.0, init_scale: float = 65536.0, growth_factor: float = 2.0,
-                 backoff_factor: float = 0.5, growth_interval: int = 2000, fused_noise: bool = True):
+                 backoff_factor: float = 0.5, growth_interval: int = 2000, fused_noise: bool = True, seed: Optional[int] = None):
         self.net = net
         self.pipeline = pipeline or SDAPipeline()
         self.lr, self.lr_fn = lr, lr_fn
@@ -52,6 +52,7 @@ class Trainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.sync_grads = self.world > 1 or (bool(os.environ.get("C2W_FORCE_DIST")) and dist.is_initialized())
+        self.rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
         self.batch_size = batch_size  # global batch (items per optimizer step); None -> B_gpu * world
         self.cur_ndata = 0
         self.step_count = 0
@@ -64,6 +65,14 @@ class Trainer:
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ema_flats = [eng.flat.clone() for _ in self.ema_rates]
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        # The step's random draws (t, the noise seed / eps) come from generators this trainer owns, seeded from (seed, rank) the way
+        # the reference seeds each process (training_loop.py:49: set_random_seed(seed, rank)): ranks that were seeded identically by
+        # their caller still see independent noise.  ``seed`` defaults to torch's initial seed, so torch.manual_seed(s) before the
+        # construction reproduces a run.
+        base = int(torch.initial_seed() if seed is None else seed)
+        mixed = (base * 0x9E3779B97F4A7C15 + (self.rank + 1) * 0xD1B54A32D192ED03) & ((1 << 63) - 1)
+        self.rng_cpu = torch.Generator().manual_seed(mixed)
+        self.rng_dev = torch.Generator(device=dev).manual_seed(mixed)
         # dynamic loss scale {scale, growth tracker, found_inf, optimizer steps taken}: fp16 only (GradScaler is a no-op otherwise)
         self.scaler: Optional[torch.Tensor] = None
         if self.dt == DTYPE_F16:
@@ -146,14 +155,14 @@ class Trainer:
         B, C, H, W = x.shape
         dev = x.device
         if t is None:
-            t = torch.rand(B, dtype=torch.float32, device=dev)
+            t = torch.rand(B, dtype=torch.float32, device=dev, generator=self._rng_for(dev))
         seed = None
         if eps is None:
-            if self.fused_noise and x.is_cuda:  # one 62-bit seed per round from torch's CPU generator (no device synchronisation)
-                seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+            if self.fused_noise and x.is_cuda:  # one 62-bit seed per round from the trainer's CPU generator (no device synchronisation)
+                seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64, generator=self.rng_cpu).item())
                 self.last_noise_seed = seed
             else:
-                eps = torch.randn_like(x)
+                eps = torch.randn(x.shape, dtype=x.dtype, device=dev, generator=self._rng_for(dev))
         t = t.reshape(-1).to(dev).float().contiguous()
         if eps is not None:
             eps = eps.contiguous()
@@ -174,6 +183,11 @@ class Trainer:
             ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, gs, self.dt, scaler=self.scaler)
         eng.backward(tape, dy)
         return self.loss_sum[0] * (self.loss_scaling / n)
+
+    def _rng_for(self, dev) -> torch.Generator:
+        if self.rng_dev.device != torch.device(dev):  # batches on another device than the parameters' (not the product path)
+            self.rng_dev = torch.Generator(device=dev).manual_seed(self.rng_cpu.initial_seed())
+        return self.rng_dev
 
     def optimizer_steps_taken(self) -> int:
         """AdamW steps actually applied: under the fp16 loss scale, steps whose gradients overflowed were skipped on the

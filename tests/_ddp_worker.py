@@ -29,7 +29,11 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_
     x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
     sl = slice(rank, rank + 1)  # global batch 2 -> one item per rank
     loss = tr.step(x[sl].contiguous(), t=t[sl].reshape(-1), eps=eps[sl].contiguous())
-    torch.save(dict(loss=float(loss), sd={k: v.clone() for k, v in net.state_dict().items()}, nb=len(tr.buckets)),
+    # both ranks seeded identically by their caller: the trainer's own generators must still differ by rank (training_loop.py:49)
+    torch.manual_seed(1234)
+    same = Trainer(net, lr=0.0, precision="fp32", ema_rates=[], bucket_mb=bucket_mb, seed=7)
+    draws = dict(seed=same.rng_cpu.initial_seed(), t=torch.rand(4, generator=same.rng_dev))
+    torch.save(dict(loss=float(loss), sd={k: v.clone() for k, v in net.state_dict().items()}, nb=len(tr.buckets), draws=draws),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -27,9 +27,10 @@ def _golden(golden_dir, name):
     return {k: v for k, v in np.load(os.path.join(golden_dir, name), allow_pickle=False).items()}
 
 
-def _tiny(seed=3):
+def _tiny(seed=3, hidden_channels=None):
     torch.manual_seed(seed)
-    return ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY)
+    cfg = dict(TINY, hidden_channels=hidden_channels) if hidden_channels else TINY
+    return ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg)
 
 
 def test_creation_order_init_matches_reference(golden_dir):
@@ -157,6 +158,57 @@ def test_optimizer_created_before_first_forward_trains_the_engine_weights(emu, g
     with torch.no_grad():  # and the next forward uses the stepped weights (the engine sees the optimizer's in-place update)
         y1 = net(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]))
     assert (y1 - torch.from_numpy(g["y"])).abs().max().item() > 1e-5
+    sd1 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    yo = ou.score_unet_forward(sd1, torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]), hidden_blocks=[1, 1], attention_levels=[1])
+    assert torch.allclose(y1, yo, atol=2e-5), (y1 - yo).abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("writer", ["sgd", "load_state_dict", "ema_reset"])
+def test_weight_caches_follow_writes_through_the_parameters(emu, golden_dir, precision, writer):
+    """Every cache derived from the weights (16-bit shadow, zero-padded input-conv operand -- 6 channels here, not a multiple
+    of the K chunk --, input-gradient operands) must follow writes made through the Parameter objects: torch.optim steps,
+    load_state_dict after the first forward, StandardEMA.reset.  Compared with a FRESH network holding the same weights:
+    forward and every gradient."""
+    from climate2weather_amd.ema import StandardEMA
+    g = _golden(golden_dir, "tiny_net.npz")
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    hc = [64, 128] if precision == "bf16" else None  # the 16-bit kernels want hidden channels in whole 64-channel K chunks
+    net = _tiny(hidden_channels=hc)
+    net.precision = precision
+    od.loss(net, x, t, eps).mean().backward()  # first forward + backward: every cache is built
+    if writer == "sgd":
+        opt = torch.optim.SGD(net.parameters(), lr=0.05)
+        for _ in range(2):
+            opt.step()
+            opt.zero_grad()
+            od.loss(net, x, t, eps).mean().backward()
+        opt.step()
+        target = net
+    elif writer == "load_state_dict":
+        other = _tiny(seed=11, hidden_channels=hc)
+        net.load_state_dict(other.state_dict())
+        target = net
+    else:
+        ema = StandardEMA(net, rates=[0.5])
+        target = ema.emas[0]
+        target.precision = precision
+        with torch.no_grad():
+            for p in target.parameters():
+                p.mul_(0.5)
+        od.loss(target, x, t, eps).mean().backward()  # caches of the copy built on the halved weights
+        ema.reset()
+    target.zero_grad()
+    fresh = _tiny(seed=5, hidden_channels=hc)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in target.state_dict().items()})
+    fresh.precision = precision
+    la = od.loss(target, x, t, eps).mean()
+    lb = od.loss(fresh, x, t, eps).mean()
+    la.backward()
+    lb.backward()
+    assert la.item() == lb.item()
+    for (n, a), (_, b) in zip(target.named_parameters(), fresh.named_parameters()):
+        assert torch.equal(a.grad, b.grad), n
 
 
 def test_fp16_snapshot_module_round_trip_runs(emu):

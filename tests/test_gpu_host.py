@@ -513,6 +513,21 @@ def test_reference_style_training_loop_on_the_module_api(golden_dir, tmp_path):
         losses.append(l.item())
     assert all(np.isfinite(losses)) and not torch.equal(net.unet.heads[0].weight.detach(), w_before)
     assert not torch.equal(ema.emas[0].unet.heads[0].weight, w_before)
+    # the 16-bit shadow, padded input-conv operand and input-gradient operands followed torch.optim's / the EMA's writes: the
+    # stepped module computes exactly what a FRESH module with the same weights computes (forward, loss, every gradient)
+    for mod in (net, ema.emas[0]):
+        fresh = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                          attention_levels=[1], kernel_size=3, padding_mode="zeros").cuda()
+        fresh.load_state_dict({k: v.detach().clone() for k, v in mod.state_dict().items()})
+        mod.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            la = od.loss(mod, x, t, eps).mean()
+            lb = od.loss(fresh, x, t, eps).mean()
+        la.backward()
+        lb.backward()
+        assert la.item() == lb.item()
+        for (n, a_), (_, b_) in zip(mod.named_parameters(), fresh.named_parameters()):
+            assert (a_.grad - b_.grad).abs().max().item() <= 1e-5 * b_.grad.abs().max().item() + 1e-9, n  # split-K summation order only
     p = save_network_snapshot(str(tmp_path / "network-snapshot-0000001-0.900000.pkl"), ema.emas[0], pipe, dict(train=dict(window=3)))
     snap = load_network_snapshot(p, device="cuda")
     with torch.no_grad():

@@ -162,6 +162,8 @@ def test_ddp_two_ranks_gloo_equals_single_process(golden_dir, tmp_path, bucket_m
         assert torch.equal(v, r1["sd"][k]), k  # ranks stay in lock step
         _assert_adam_close(v, exp[k], torch.from_numpy(g["grad." + k]), 1e-3, k)
     assert 0.5 * (r0["loss"] + r1["loss"]) == pytest.approx(float(g["loss"]), rel=1e-5)
+    # identical caller-side seeding on both ranks: the trainers' noise / t streams still differ by rank
+    assert r0["draws"]["seed"] != r1["draws"]["seed"] and not torch.equal(r0["draws"]["t"], r1["draws"]["t"])
 
 
 def test_score_function_and_sampler_match_golden(emu, golden_dir):
@@ -196,6 +198,41 @@ def test_score_function_and_sampler_match_golden(emu, golden_dir):
             xs = _sample(pipe, sf, torch.from_numpy(s[name + ".noise"]), corrections, zs, dev, fused)
             ref = torch.from_numpy(s[name + ".x"])
             assert (xs - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), (name, fused)
+
+
+def test_fused_guidance_only_for_per_variable_std(emu, golden_dir):
+    """The guidance kernel indexes std by variable.  Any other broadcastable shape (src/thor/score.py:55 broadcasts ``std**2``
+    like any tensor) must take the generic autograd route and give what the reference's formula gives -- here a per-pixel std
+    of shape (1, 1, h, w), and a 1-D (w,) std that broadcasts along the LAST axis, not over the variables."""
+    from climate2weather_amd.score_fn import per_channel_std
+    s = _golden(golden_dir, "sampler.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    y_obs, gamma = torch.from_numpy(s["y_obs"]), float(s["gamma"])
+    nobs, Fv, h, w = y_obs.shape
+    assert per_channel_std(torch.rand(1, Fv, 1, 1), y_obs).shape == (Fv,) and per_channel_std(0.3, y_obs).shape == (1,)
+    x = torch.from_numpy(s["score_x"])
+    t = torch.tensor(0.6)
+    gen = torch.Generator().manual_seed(0)
+    for std in (torch.rand(1, 1, h, w, generator=gen) + 0.1, torch.rand(w, generator=gen) + 0.1):
+        assert per_channel_std(std, y_obs) is None
+        A = PoolStrideOperator(8, 2)
+        sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+        sf.condition_on(A=A, y=y_obs, std=std, gamma=gamma, exact_grad=False)
+        assert sf._fused_guidance is None
+        out = sf(x, t)
+        with torch.no_grad():
+            eps = sf.score_fn(x, t)
+        mu, sigma = pipe.mu(t), pipe.sigma(t)
+        xg = x.clone().requires_grad_(True)
+        err = y_obs - F.avg_pool2d(((xg - sigma * eps) / mu)[::2], 8)
+        logp = -(err ** 2 / (std ** 2 + gamma * (sigma / mu) ** 2)).sum() / 2
+        (J,) = torch.autograd.grad(logp, xg)
+        assert torch.allclose(out, eps - sigma * J, atol=1e-5 * float((eps - sigma * J).abs().max()))
+    from climate2weather_amd.sharded import TimeShardedScoreFunction
+    ts = TimeShardedScoreFunction(net, 1, length=9, batch_size=4, device=torch.device("cpu"), noise_process=pipe, rank=0, world=1)
+    with pytest.raises(NotImplementedError):
+        ts.condition_on(A=PoolStrideOperator(8, 2), y=y_obs, std=torch.rand(1, 1, h, w) + 0.1, gamma=gamma)
 
 
 def _sample(pipe, sf, noise, corrections, zs, dev, fused):
@@ -387,6 +424,34 @@ def test_reference_network_snapshot_import_and_round_trip(emu, golden_dir, tmp_p
         pickle.dump(dict(ema=os.system), f)
     with pytest.raises(pickle.UnpicklingError):
         load_network_snapshot(str(evil))
+    # protocol-4 STACK_GLOBAL with a dotted name through an allowed module ("torch.serialization", "os.system"), and getattr chains
+    marker = tmp_path / "pwned"
+    for mod, name in (("torch.serialization", "os.system"), ("torch", "serialization.os.system"), ("builtins", "getattr"),
+                      ("builtins", "eval"), ("torch.hub", "load"), ("numpy", "load"), ("torch", "load")):
+        arg = f"touch {marker}"
+        payload = (b"\x80\x04" + b"\x8c" + bytes([len(mod)]) + mod.encode() + b"\x8c" + bytes([len(name)]) + name.encode() + b"\x93"
+                   + b"\x8c" + bytes([len(arg)]) + arg.encode() + b"\x85R.")
+        with open(evil, "wb") as f:
+            f.write(payload)
+        with pytest.raises(pickle.UnpicklingError):
+            load_network_snapshot(str(evil))
+        assert not marker.exists()
+    # a storage payload is a nested torch.save stream: it must go through the weights-only loader, not a second full unpickler
+    class _Boom:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    import io
+    inner = io.BytesIO()
+    torch.save(_Boom(), inner, _use_new_zipfile_serialization=False)
+    mod, name = "torch.storage", "_load_from_bytes"
+    blob = inner.getvalue()
+    payload = (b"\x80\x04" + b"\x8c" + bytes([len(mod)]) + mod.encode() + b"\x8c" + bytes([len(name)]) + name.encode() + b"\x93"
+               + b"B" + len(blob).to_bytes(4, "little") + blob + b"\x85R.")
+    with open(evil, "wb") as f:
+        f.write(payload)
+    with pytest.raises(Exception):
+        load_network_snapshot(str(evil))
+    assert not marker.exists()
 
 
 def test_quantile_normalizer_and_measurement_operator(emu):
