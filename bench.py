@@ -3,16 +3,22 @@
 (training_loop.py:369-391: noise -> ScoreUNet fwd -> MSE -> bwd -> grad all-reduce -> AdamW -> EMA) on the
 default configs/sda_unet.yml network, synthetic (B, F*w, 128, 128) fields, bf16 compute, one process per GPU.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 without a launcher: this process (which never touches a GPU) starts N rank processes itself -- what
+        fabric.launch() does for the reference (train.py:93-100) -- and relays rank 0's JSON line;
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        the ranks are the launcher's: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live (HIP events on the launch stream around every launch of
-the dominant kernel inside the timed region); `cpu_baseline` is the CPU oracle (oracle/, a plain-PyTorch restatement
-of the same step) timed on this box's host cores, rank 0 at N=1 only.
+Prints ONE JSON line on rank 0.  `roofline` is measured live (HIP events on the launch stream around every launch of the
+dominant kernel inside the timed region); `by_kernel` comes from extra steps AFTER the timed region in which every implicit-GEMM
+launch is bracketed by events and the two backward streams are serialised (each kernel alone on the chip); `cpu_baseline` is the
+CPU oracle (oracle/, a plain-PyTorch restatement of the same step) timed on this box's host cores, rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +31,8 @@ sys.path.insert(0, REPO)
 DEFAULT_CFG = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3,
                    padding_mode="zeros", attention_levels=[4])  # configs/sda_unet.yml
 GFLOP_FWD = {65: 116.98, 52: 116.00}  # algorithmic GFLOP per (C,128,128) window forward
-MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md)
+GFLOP_FWD_DEEP = 473.03  # C = 80, 256 x 256
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 / fp16 (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -41,64 +48,219 @@ def parse():
                    help="bf16 (default), fp16 (the reference's autocast type; dynamic loss scale on the device) or fp32 (parity mode)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--sample-steps", type=int, default=2, help="sampler steps timed after the headline run (0 = skip)")
+    p.add_argument("--kernel-steps", type=int, default=2, help="extra steps with every implicit-GEMM launch timed (by_kernel; 0 = skip)")
+    p.add_argument("--no-extras", action="store_true", help="skip by_kernel, the deep-variant leg and the sampler legs")
     return p.parse_args()
 
 
-class KernelTimer:
-    """HIP events (on torch's current stream = the stream the kernels are launched on) around every launch of one
-    kernel shape."""
+# ----------------------------------------------------------------------------------------------------------------- launcher
+def launch(a) -> int:
+    """`--gpus N` without a launcher's environment: one child process per GPU (this parent initialises no GPU: counting devices
+    does not), rendezvous on 127.0.0.1, rank 0's stdout is relayed, everything else goes to stderr."""
+    visible = torch.cuda.device_count()
+    if visible < a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but only {visible} GPU(s) are visible; refusing to report fewer ranks than asked for\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:  # rank 0 is gone: a rank still alive two minutes later is stuck in a collective
+            p.kill()
+            rcs.append(p.wait())
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
-    def __init__(self, ops, match):
-        self.ops, self.match, self.events, self.enabled = ops, match, [], False
-        self._orig = ops.conv
+
+# ----------------------------------------------------------------------------------------------------------------- kernel timing
+class LaunchTimer:
+    """HIP events around implicit-GEMM launches (ops.conv / ops.conv_wgrad), recorded on the stream each launch is enqueued on
+    (torch's current stream at the call: the caller's stream for forward / input-gradient launches, the engine's gradient stream
+    for weight gradients).  Launches are identified by the weight (or weight-gradient) pointer they are given, i.e. by LAYER, so
+    the padded network-input / output convs are priced at their own algorithmic FLOP and not mistaken for a residual-block conv
+    of the same padded geometry."""
+
+    def __init__(self, ops, eng, dt, batch):
+        self.ops, self.eng, self.dt, self.batch = ops, eng, dt, batch
+        self.mode = "off"  # "off" | "dominant" | "all"
+        self.events = []  # (layer, kind, geometry-dict, e0, e1)
+        self._conv, self._wgrad = ops.conv, ops.conv_wgrad
+        self.fw, self.dg, self.gw = {}, {}, {}
+        self.dominant = set()
+
+    def index_layers(self):
+        """pointer -> layer tables (after a warm-up step: every cached operand exists)."""
+        eng, lay = self.eng, self.eng.layout
+        from climate2weather_amd.ops import DTYPE_F32
+        for rec in lay.convs.values():
+            d = DTYPE_F32 if rec.lin else self.dt
+            self.fw[eng._w(rec, d).data_ptr()] = rec
+            if rec.dg_off >= 0:
+                self.dg[eng._wT(rec, d).data_ptr()] = rec
+            self.gw[eng._gw(rec).data_ptr()] = rec
+        for name, buf in eng._gwpad.items():
+            self.gw[buf.data_ptr()] = lay.convs[name]
+        lv0 = lay.levels[0]
+        self.dominant = {n for n, r in lay.convs.items() if ".residue." in n and r.rows == lv0.channels and r.cin == lv0.channels
+                         and (n.startswith("unet.descent.0.") or n.startswith(f"unet.ascent.{len(lay.levels) - 1}."))}
 
     def install(self):
         def conv(x, w, bias, y, g, dtype, **kw):
-            if self.enabled and self.match(g, dtype):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self._orig(x, w, bias, y, g, dtype, **kw)
-                e1.record()
-                self.events.append((e0, e1, bias is not None))  # forward launches carry a bias, input-gradient launches do not
-            else:
-                self._orig(x, w, bias, y, g, dtype, **kw)
-        self.ops.conv = conv
+            rec = None
+            if self.mode != "off":
+                rec = self.fw.get(w.data_ptr()) or self.dg.get(w.data_ptr())
+                if self.mode == "dominant" and (rec is None or rec.name not in self.dominant or g["B"] != self.batch):
+                    rec = None
+            if rec is None:
+                return self._conv(x, w, bias, y, g, dtype, **kw)
+            kind = "fwd" if w.data_ptr() in self.fw else "dgrad"
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._conv(x, w, bias, y, g, dtype, **kw)
+            e1.record()
+            self.events.append((rec, kind, g, e0, e1))
 
-    def mean_ms(self, forward_only=False):
-        ts = [a.elapsed_time(b) for a, b, fwd in self.events if fwd or not forward_only]
-        return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+        def conv_wgrad(x, dy, dw, g, dtype, dbias=None):
+            rec = self.gw.get(dw.data_ptr()) if self.mode == "all" else None
+            if rec is None:
+                return self._wgrad(x, dy, dw, g, dtype, dbias=dbias)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._wgrad(x, dy, dw, g, dtype, dbias=dbias)
+            e1.record()
+            self.events.append((rec, "wgrad", g, e0, e1))
+        self.ops.conv, self.ops.conv_wgrad = conv, conv_wgrad
+
+    @staticmethod
+    def flop(rec, kind, g) -> float:
+        """ALGORITHMIC FLOP of one launch: 2 x output pixels of the layer's forward x rows x taps x REAL input channels (padding
+        channels of the network-input / output convs do no algorithmic work).  An input-gradient launch walks the forward's output
+        grid (= its own input grid), a weight-gradient launch is handed the forward geometry."""
+        pix = g["B"] * (g["Hin"] * g["Win"] if kind == "dgrad" else g["Hout"] * g["Wout"])
+        return 2.0 * pix * rec.rows * rec.taps * rec.cin
+
+    def family(self, rec, kind, g) -> str:
+        lay = self.eng.layout
+        n = rec.name
+        if rec.lin:
+            return f"{kind} linear fp32 (time MLP, modulation)"
+        if n in ("unet." + lay.levels[0].head_key, "unet." + lay.levels[0].tail_key):
+            return f"{kind} edge conv {rec.cin}->{rec.rows} (padded to 64-channel chunks) @{g['Hout'] if kind != 'dgrad' else g['Hin']}"
+        if rec.taps == 1:
+            return f"{kind} 1x1 {rec.cin}->{rec.rows} (attention qkv / proj)"
+        if ".heads." in n:
+            return {"fwd": "fwd 3x3 stride-2 (S2)", "dgrad": "dgrad of stride-2 (TS2)", "wgrad": "wgrad of stride-2 (S2)"}[kind] + f" {rec.cin}->{rec.rows}"
+        side = g["Hin"] if kind == "dgrad" else g["Hout"]
+        return f"{kind} 3x3 s1 {rec.cin}->{rec.rows} @{side}x{side}"
+
+    def summarise(self, select=None, steps=1):
+        """-> {family: dict(launches_per_step, avg_ms, ms_per_step, gflop_per_launch, tflops, frac)} over the recorded events."""
+        fam = {}
+        for rec, kind, g, e0, e1 in self.events:
+            if select is not None and not select(rec, kind):
+                continue
+            f = fam.setdefault(self.family(rec, kind, g), [0, 0.0, 0.0])
+            f[0] += 1
+            f[1] += e0.elapsed_time(e1)
+            f[2] += self.flop(rec, kind, g)
+        out = {}
+        for k, (n, ms, fl) in fam.items():
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            peak = 157.0 if "fp32" in k else MFMA_PEAK_TFLOPS
+            out[k] = dict(launches_per_step=round(n / steps, 2), avg_ms=round(ms / n, 4), ms_per_step=round(ms / steps, 3),
+                          gflop_per_launch=round(fl / n / 1e9, 2), tflops=round(tf, 1), frac=round(tf / peak, 4))
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(C, size, cfg):
-    """The oracle (CPU port of the reference step: noise -> net -> loss -> backward) on a bounded sample."""
+    """the oracle (CPU restatement of the reference step) on this box's host cores -- 3 warm-up + 5 timed
+    iterations (median), forward (eval, no_grad, B = 2) and fwd+bwd of `loss(net, x).mean()` (B = 2), at C = 52 (the reference's
+    recipe) and the benchmarked C, at the thread count that maximises windows/s (swept first; all cores oversubscribe this size)."""
     from oracle import diffusion as od
     from oracle import unet as ou
     from climate2weather_amd.score import ScoreUNet
-    torch.manual_seed(0)
-    net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **cfg)
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     B = 2
+    ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, C, size, size, generator=g) * 0.5 + 0.5
-    fwd = lambda a, b: ou.score_unet_forward(sd, a, b, cfg["hidden_blocks"], cfg["attention_levels"])
-    times = []
-    for it in range(5):
+
+    def make(Cc):
+        torch.manual_seed(0)
+        net = ScoreUNet(channels=Cc, spatial=2, activation=torch.nn.SiLU, **cfg)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        x = torch.randn(B, Cc, size, size, generator=g) * 0.5 + 0.5
+        fwd = lambda a, b: ou.score_unet_forward(sd, a, b, cfg["hidden_blocks"], cfg["attention_levels"])
+        return sd, x, fwd
+
+    def run_fwd(sd, x, fwd):
+        with torch.no_grad():
+            fwd(x, torch.rand(B, generator=g))
+
+    def run_train(sd, x, fwd):
         t = torch.rand(B, 1, 1, 1, generator=g)
-        eps = torch.randn(B, C, size, size, generator=g)
-        t0 = time.time()
+        eps = torch.randn(x.shape, generator=g)
         loss = od.loss(fwd, x, t, eps).mean()
         torch.autograd.grad(loss, list(sd.values()))
-        times.append(time.time() - t0)
-    best = sorted(times[1:])[len(times[1:]) // 2]
-    return dict(value=round(B / best, 3), unit="windows/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle fwd+bwd of the same step, B={B}, C={C}, {size}x{size}, fp32, 1 warm-up + 4 timed iterations (median)")
+
+    def timed(fn, args, warm, n):
+        for _ in range(warm):
+            fn(*args)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn(*args)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    main = make(C)
+    sweep = {}
+    for nt in sorted({n for n in (4, 8, 16, 32, 64, 128, ncpu) if n <= ncpu}):
+        torch.set_num_threads(nt)
+        sweep[nt] = round(B / timed(run_fwd, main, 1, 2), 2)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    legs = {}
+    for Cc in sorted({52, C}):
+        m = main if Cc == C else make(Cc)
+        tf, tt = timed(run_fwd, m, 3, 5), timed(run_train, m, 3, 5)
+        legs[f"C={Cc}"] = dict(forward_windows_per_s=round(B / tf, 3), forward_ms_per_iter=round(1e3 * tf, 1),
+                              train_windows_per_s=round(B / tt, 3), train_ms_per_iter=round(1e3 * tt, 1))
+    return dict(value=legs[f"C={C}"]["train_windows_per_s"], unit="windows/s", cores=best, kind="port",
+                sample=f"oracle (plain PyTorch CPU fp32 restatement) fwd+bwd of the same training step, B={B}, C={C}, {size}x{size}, 3 warm-up + 5 "
+                       f"timed iterations (median), {best} threads = the best of the sweep below ({ncpu} logical CPUs on the box)",
+                cpu_model=_cpu_model(), logical_cpus=ncpu, thread_sweep_forward_windows_per_s=sweep, legs=legs)
 
 
-def main():
-    a = parse()
+# ----------------------------------------------------------------------------------------------------------------- one rank
+def run_rank(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and rank == 0:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting the ranks that run\n")
     # stdout carries exactly one line, the JSON: everything else written to file descriptor 1 -- RCCL prints its version banner
     # there from C, flushed at exit, i.e. AFTER the JSON -- goes to stderr; the JSON is written to the saved descriptor.
     sys.stdout.flush()
@@ -109,6 +271,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        world = dist.get_world_size()  # what RCCL saw is what is reported
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -124,15 +287,13 @@ def main():
     C = a.vars * w
     torch.manual_seed(0)
     net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
-    total_ndata = a.batch * world * (a.steps + a.warmup) * 4
+    total_ndata = a.batch * world * (a.steps + a.warmup + a.kernel_steps + 2) * 4
     trainer = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4),
-                      weight_decay=1e-3, ema_rates=[0.9999], precision=a.precision, batch_size=a.batch * world)
+                      weight_decay=1e-3, ema_rates=[0.9999], precision=a.precision, batch_size=a.batch * world, seed=1000)
     ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
     feed = DeviceWindowFeed(ds, dev, rank=rank, num_replicas=world, seed=0)
-    torch.manual_seed(1000 + rank)
 
-    timer = KernelTimer(ops, lambda g, dt: g["mode"] == ops.CONV_S1 and g["Cin"] == 128 and g["Cout"] == 128 and g["Hin"] == a.size
-                        and g["B"] == a.batch)
+    timer = LaunchTimer(ops, trainer.eng, trainer.dt, a.batch)
     timer.install()
 
     def one_step():
@@ -141,10 +302,11 @@ def main():
     for _ in range(a.warmup):
         one_step()
     torch.cuda.synchronize()
+    timer.index_layers()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.mode = "dominant"
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = one_step()
@@ -153,7 +315,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.mode = "off"
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -164,45 +326,80 @@ def main():
 
     out = None
     if rank == 0:
-        # Dominant kernel shape: 3x3 128->128 at full resolution.  Its forward launches have the chip to themselves; its
-        # input-gradient launches share it with the weight-gradient stream (engine.grad_stream), so their durations include
-        # that interference.  The roofline is priced on the launches that run alone (the kernel's own rate); the average over
-        # every launch is reported beside it (it is what `rocprofv3 --stats` averages; tools/rocprof_db_stats.py splits the
-        # trace the same way).
-        k_ms, k_n = timer.mean_ms(forward_only=True)
-        a_ms, a_n = timer.mean_ms()
+        # Dominant kernel: the 3x3 residual-block conv at full resolution (128 -> 128 @128x128: 24 of the 70 convs of a forward and the
+        # same again as input gradients).  Its forward launches have the chip to themselves; its input-gradient launches share it with
+        # the weight-gradient stream (engine.grad_stream), so their durations include that interference.  The roofline is priced on the
+        # launches that run alone (the kernel's own rate); the average over every launch is reported beside it (it is what
+        # `rocprofv3 --stats` averages; tools/rocprof_db_stats.py splits a trace the same way).
+        dom_f = timer.summarise(lambda rec, kind: kind == "fwd", steps=a.steps)
+        dom_a = timer.summarise(steps=a.steps)
         gf_fwd = GFLOP_FWD.get(C, 116.0) if a.size == 128 else None
-        flops_launch = 2.0 * a.batch * a.size * a.size * 128 * 9 * 128
         roof = None
-        if k_ms:
-            ach = flops_launch / (k_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel=f"conv_patch_t3_kernel<16> ({a.precision}) 128->128 @%dx%d, res-block conv forward launches (bias / SiLU / residual / "
-                        "LayerNorm epilogues included; they run alone on the chip)" % (a.size, a.size),
-                        achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
-                        # HBM bytes per launch from the PMC passes of the same kernel and shape (FETCH_SIZE x2 gfx950 correction +
-                        # WRITE_SIZE; profiles/r01k_pmc_conv_patch3_b128.md) -- equal to the algorithmic 537 MB in + 537 MB out
-                        traffic=1.059e9 if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
-                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01k_pmc_conv_patch3_b128.md",
-                        mfma_busy_pmc=0.61, clock_ghz_under_load_pmc=1.73,
-                        launches_timed=k_n, avg_launch_ms=round(k_ms, 4), flops_per_launch=flops_launch,
-                        all_launches=dict(note="forward + input-gradient launches; the latter overlap the weight-gradient stream",
-                                          launches_timed=a_n, avg_launch_ms=round(a_ms, 4),
-                                          achieved=round(flops_launch / (a_ms * 1e-3) / 1e12, 1),
-                                          frac=round(flops_launch / (a_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)))
+        if dom_f:
+            (kname, kf), = list(dom_f.items())[:1]
+            ka = list(dom_a.values())
+            all_ms = sum(v["ms_per_step"] for v in ka)
+            all_n = sum(v["launches_per_step"] for v in ka)
+            all_tf = sum(v["gflop_per_launch"] * v["launches_per_step"] for v in ka) / all_ms if all_ms else 0.0
+            roof = dict(bound="mfma",
+                        kernel=f"conv_patch_t3_kernel<16> ({a.precision}): {kname}, residual-block conv forward launches (bias / SiLU / residual / LayerNorm "
+                               "epilogues included; they run alone on the chip); network-input / output convs are NOT in this set",
+                        achieved=kf["tflops"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=kf["frac"],
+                        launches_timed=int(round(kf["launches_per_step"] * a.steps)), avg_launch_ms=kf["avg_ms"],
+                        flops_per_launch=kf["gflop_per_launch"] * 1e9,
+                        traffic=None,
+                        from_profile=dict(note="NOT measured in this run: PMC passes of the same kernel and shape on another box (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
+                                               "correction + WRITE_SIZE); algorithmic bytes are 537 MB in + 537 MB out per launch",
+                                          source="profiles/r01k_pmc_conv_patch3_b128.md", traffic_bytes_per_launch=1.059e9, mfma_busy=0.61,
+                                          clock_ghz_under_load=1.73) if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
+                        all_launches=dict(note="forward + input-gradient launches of the same layers; the latter overlap the weight-gradient stream",
+                                          launches_timed=int(round(all_n * a.steps)), avg_launch_ms=round(all_ms / all_n, 4) if all_n else None,
+                                          achieved=round(all_tf, 1), frac=round(all_tf / MFMA_PEAK_TFLOPS, 4)))
         out = dict(metric="UNet denoise steps/sec (train fwd+bwd+allreduce+AdamW+EMA windows/s)", value=round(value, 2), unit="windows/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * elapsed / a.steps, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=a.precision, data="synthetic",
                    config=dict(workload=f"configs/sda_unet.yml default net, {a.vars} vars x window {w} = {C} ch, {a.size}x{a.size}, "
                                         f"{a.precision} training step, {a.batch} windows/GPU/step",
                                global_batch=a.batch * world, parallelism=f"dp{world}", params=sum(p.numel() for p in net.parameters())),
+                   world_size_rccl=dist.get_world_size() if dist.is_initialized() else 1,
                    optimizer_steps_per_s=round(a.steps / elapsed, 4), final_loss=round(loss_val, 5), roofline=roof)
         if gf_fwd:
             tf = value * (3 * gf_fwd - 1.96) / 1e3  # fwd + dgrad + wgrad minus the input conv's unused dgrad
             out["model_tflops_per_gpu"] = round(tf / world, 1)
             out["mfma_frac_whole_step"] = round(tf / world / MFMA_PEAK_TFLOPS, 4)
 
-    # ---- sampler leg (outside the headline region): window-forwards/s inside the device-resident sampler
-    if a.sample_steps > 0 and a.size == 128:
+    extras = not a.no_extras
+    # ---- by_kernel (outside the headline region): every implicit-GEMM launch of `kernel_steps` more steps, streams serialised
+    if extras and a.kernel_steps > 0:
+        timer.events.clear()
+        prev = os.environ.get("C2W_WGRAD_STREAM")
+        os.environ["C2W_WGRAD_STREAM"] = "0"  # read per launch by engine.grad_stream(): weight gradients on the caller's stream
+        one_step()
+        torch.cuda.synchronize()
+        timer.mode = "all"
+        ts0 = time.perf_counter()
+        for _ in range(a.kernel_steps):
+            one_step()
+        torch.cuda.synchronize()
+        ser_ms = 1e3 * (time.perf_counter() - ts0) / a.kernel_steps
+        timer.mode = "off"
+        if prev is None:
+            os.environ.pop("C2W_WGRAD_STREAM", None)
+        else:
+            os.environ["C2W_WGRAD_STREAM"] = prev
+        if out is not None:
+            fam = timer.summarise(steps=a.kernel_steps)
+            gemm_ms = sum(v["ms_per_step"] for v in fam.values())
+            out["by_kernel"] = dict(
+                note="every implicit-GEMM launch (ops.conv / ops.conv_wgrad) of %d extra steps, HIP events per launch, backward streams serialised "
+                     "(C2W_WGRAD_STREAM=0) so each kernel runs alone; FLOP are algorithmic (real channel counts); weight-gradient times include the "
+                     "split-K reduction launch; sorted by time per step" % a.kernel_steps,
+                serialised_step_ms=round(ser_ms, 2), implicit_gemm_ms_per_step=round(gemm_ms, 2), everything_else_ms_per_step=round(ser_ms - gemm_ms, 2),
+                kernels=[dict(kernel=k, **v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])])
+        timer.events.clear()
+
+    # ---- sampler legs (outside the headline region): window-forwards/s inside the device-resident sampler
+    if extras and a.sample_steps > 0 and a.size == 128:
         net.precision = a.precision
         L = 128 + w - 1
         import contextlib, io
@@ -232,6 +429,12 @@ def main():
         if out is not None:
             out["sampler_cosampled_windows_per_s_per_gpu"] = round(members * (Ls - w + 1) * nst / dts, 1)
 
+    # ---- BASELINE configs[4] (outside the headline region): deep variant, 80 ch x 256x256, fp16 MFMA, hipGraph-replayed sampler step
+    if extras and a.size == 128 and world == 1:
+        del trainer, feed, ds
+        torch.cuda.empty_cache()
+        out["deep_variant"] = deep_variant(dev)
+
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, a.size, DEFAULT_CFG)
@@ -240,6 +443,73 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def deep_variant(dev, B=16):
+    """BASELINE configs[4]: 5 variables x 16 frames = 80 channels, 256x256 windows (473.03 GFLOP forward per window), fp16 -- the
+    training step and the forward -- and its sampler step (k = 7 -> window 15 -> 75 channels: the reference's windows are odd,
+    SURVEY.md section 0) as eager launches and as a hipGraph replay."""
+    import contextlib, io
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.score_fn import BatchedScoreFunction
+    from climate2weather_amd.training import Trainer
+    res = dict(config="80 ch x 256x256, fp16, B=%d/GPU (BASELINE configs[4])" % B)
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=80, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
+    tr = Trainer(net, SDAPipeline(), lr=1e-4, precision="fp16", ema_rates=[0.9999], seed=1)
+    x = torch.randn(B, 80, 256, 256, device=dev) * 0.5 + 0.5
+    for _ in range(2):
+        tr.step(x)
+    torch.cuda.synchronize()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    res["train_windows_per_s"] = round(B / dt, 1)
+    res["train_model_tflops"] = round(B / dt * (3 * GFLOP_FWD_DEEP - 7.9) / 1e3, 1)
+    net.precision = "fp16"
+    tt = torch.rand(B, device=dev)
+    with torch.no_grad():
+        for _ in range(2):
+            net(x, tt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            net(x, tt)
+        torch.cuda.synchronize()
+    dtf = (time.perf_counter() - t0) / n
+    res["forward_windows_per_s"] = round(B / dtf, 1)
+    del tr, x
+    torch.cuda.empty_cache()
+    k, F, L = 7, 5, 47
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=F * (2 * k + 1), spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev).eval()
+    net.precision = "fp16"
+    pipe = SDAPipeline()
+    for graph in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sf = BatchedScoreFunction(net, markov_order=k, batch_size=33, device=dev, noise_process=pipe)
+            sf.use_graphs = graph
+            noise = torch.randn(L, F, 256, 256, device=dev)
+            pipe.sample(sf, noise, steps=2, show_progressbar=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.sample(sf, noise, steps=6, show_progressbar=False)
+            torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / 6
+        res["sampler_steps_per_s" + ("_hipgraph" if graph else "_eager")] = round(1 / d, 2)
+        res["sampler_window_forwards_per_s" + ("_hipgraph" if graph else "_eager")] = round((L - 2 * k) / d, 1)
+    return res
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(a))
+    run_rank(a)
 
 
 if __name__ == "__main__":

@@ -17,6 +17,37 @@ def seed_from_args(*args) -> int:
     return hash(args) % (1 << 31)
 
 
+def seed_everything(seed: int) -> None:
+    """What ``lightning.fabric.seed_everything(seed, workers=True)`` seeds (util.py:27-29 calls it; lightning 2.2.1 is not
+    installed here, its documented behaviour: python ``random``, numpy's global state and ``torch.manual_seed`` -- which also
+    seeds every CUDA generator)."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def ensemble_members(sample_member, *, seed: int, rank: int, world: int, num_samples: int, shape, steps: int, corrections: int = 0):
+    """The member loop of exp/downscaling.py:96-103,248-265 for ONE rank: ``num_samples % world == 0``; the process is seeded
+    with ``hash((seed, rank)) % 2**31``; member i of the rank has ``sample_id = rank * n_per_gpu + i`` and starts from ONE
+    ``torch.randn(L, C, H, W)`` drawn on the CPU generator; the sampler then draws its corrector normals from the same generator
+    (``pipeline.sample`` keeps its state on the CPU in the reference and fills ``z.normal_()``, src/thor/pipelines.py:59-60,70-82: the
+    same stream as ``torch.randn`` of that shape), one per
+    correction per step, before the next member's noise.
+    ``sample_member(noise, z_draws) -> x`` runs the sampler with those draws (oracle.diffusion.sample takes them explicitly).
+    -> [(sample_id, x)]"""
+    assert num_samples % world == 0, "num_samples must be divisible by world_size"
+    per_gpu = num_samples // world
+    seed_everything(seed_from_args(seed, rank))
+    out = []
+    for i in range(per_gpu):
+        sample_id = rank * per_gpu + i
+        noise = torch.randn(*shape)
+        zs = [torch.randn(*shape) for _ in range(steps * corrections)]
+        out.append((sample_id, sample_member(noise, zs)))
+    return out
+
+
 def linear_lr(cur_ndata: int, total_ndata: int, ref_lr: float) -> float:
     """src/thor/lr.py:17-19."""
     return ref_lr * (1 - cur_ndata / total_ndata)

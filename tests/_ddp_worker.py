@@ -1,4 +1,6 @@
-"""Worker for the world_size-2 gloo test of the gradient all-reduce path (CPU, HIP launchers replaced by tests/emu_ops)."""
+"""Workers for the multi-rank tests of the gradient all-reduce path: "gloo" on the CPU (HIP launchers replaced by tests/emu_ops,
+world_size 2) and "nccl" = RCCL on the GPU (the real kernels; world_size 1 on any box -- a real communicator, real collectives
+issued from the gradient stream --, world_size 2 where two GPUs are visible)."""
 import os
 import sys
 
@@ -7,10 +9,16 @@ import torch
 import torch.distributed as dist
 
 
-def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_mb: float):
+def _init(rank: int, world: int, port: int, backend: str) -> torch.device:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        return dev
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     import emu_ops
@@ -18,22 +26,32 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_
     for name in emu_ops.ALL:
         if hasattr(c2w_ops, name):
             setattr(c2w_ops, name, getattr(emu_ops, name))
+    return torch.device("cpu")
+
+
+def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_mb: float, backend: str = "gloo"):
+    dev = _init(rank, world, port, backend)
     from climate2weather_amd.score import ScoreUNet
     from climate2weather_amd.training import Trainer
 
     g = np.load(os.path.join(golden_dir, "tiny_net.npz"))
     torch.manual_seed(3 + 100 * rank)  # different initial weights per rank: the trainer must broadcast rank 0's
     net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
-                    attention_levels=[1], kernel_size=3, padding_mode="zeros")
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev)
+    if world == 1:
+        os.environ["C2W_FORCE_DIST"] = "1"  # one rank: still broadcast, bucket and all-reduce through the communicator
     tr = Trainer(net, lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=bucket_mb)
-    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
-    sl = slice(rank, rank + 1)  # global batch 2 -> one item per rank
+    assert tr.sync_grads
+    x, t, eps = (torch.from_numpy(g[k]).to(dev) for k in ("x", "t", "eps"))
+    per = x.shape[0] // world  # global batch 2 -> one item per rank (both items on a single rank)
+    sl = slice(rank * per, (rank + 1) * per)
     loss = tr.step(x[sl].contiguous(), t=t[sl].reshape(-1), eps=eps[sl].contiguous())
     # both ranks seeded identically by their caller: the trainer's own generators must still differ by rank (training_loop.py:49)
     torch.manual_seed(1234)
     same = Trainer(net, lr=0.0, precision="fp32", ema_rates=[], bucket_mb=bucket_mb, seed=7)
-    draws = dict(seed=same.rng_cpu.initial_seed(), t=torch.rand(4, generator=same.rng_dev))
-    torch.save(dict(loss=float(loss), sd={k: v.clone() for k, v in net.state_dict().items()}, nb=len(tr.buckets), draws=draws),
+    draws = dict(seed=same.rng_cpu.initial_seed(), t=torch.rand(4, generator=same.rng_dev, device=dev).cpu())
+    torch.save(dict(loss=float(loss), sd={k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, nb=len(tr.buckets), draws=draws,
+                    world=dist.get_world_size(), backend=dist.get_backend()),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

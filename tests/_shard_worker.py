@@ -1,4 +1,5 @@
-"""Worker for the world_size-2 gloo test of the time-sharded sampler (CPU, HIP launchers replaced by tests/emu_ops)."""
+"""Worker for the world_size-2 tests of the time-sharded sampler: "gloo" on the CPU (HIP launchers replaced by tests/emu_ops) and
+"nccl" = RCCL on two GPUs (the real kernels, halo frames point-to-point over xGMI)."""
 import os
 import sys
 
@@ -7,17 +8,10 @@ import torch
 import torch.distributed as dist
 
 
-def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
+def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, backend: str = "gloo"):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
-    import emu_ops
-    from climate2weather_amd import ops as c2w_ops
-    for name in emu_ops.ALL:
-        if hasattr(c2w_ops, name):
-            setattr(c2w_ops, name, getattr(emu_ops, name))
+    from _ddp_worker import _init
+    dev = _init(rank, world, port, backend)
     from climate2weather_amd.pipelines import SDAPipeline
     from climate2weather_amd.score import ScoreUNet
     from climate2weather_amd.score_fn import PoolStrideOperator
@@ -26,12 +20,13 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
     s = np.load(os.path.join(golden_dir, "sampler.npz"))
     torch.manual_seed(3)
     net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
-                    attention_levels=[1], kernel_size=3, padding_mode="zeros").eval()
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev).eval()
+    net.precision = "fp32"
     pipe = SDAPipeline()
     out = {}
     for name, corrections, cond in [("uncond_c0", 0, False), ("uncond_c1", 1, False), ("cond_c0", 0, True)]:
         noise = torch.from_numpy(s[name + ".noise"])
-        sf = TimeShardedScoreFunction(net, markov_order=1, length=noise.shape[0], batch_size=3, device=torch.device("cpu"),
+        sf = TimeShardedScoreFunction(net, markov_order=1, length=noise.shape[0], batch_size=3, device=dev,
                                       noise_process=pipe)
         if cond:
             sf.condition_on(A=PoolStrideOperator(8, 2), y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]),
@@ -39,7 +34,7 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
         lo, hi = sf.bounds[rank]
         zs = [torch.from_numpy(z)[lo:hi] for z in s[name + ".z"]] if corrections else None
         x = sample_time_sharded(pipe, sf, noise[lo:hi], steps=4, corrections=corrections, tau=0.5, z_draws=zs, gather=True)
-        out[name] = x.clone()
+        out[name] = x.cpu().clone()
         out[name + ".bounds"] = sf.bounds
     torch.save(out, os.path.join(out_dir, f"shard{rank}.pt"))
     dist.barrier()

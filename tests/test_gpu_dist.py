@@ -1,0 +1,100 @@
+"""RCCL ("nccl" backend) runs of the two paths that communicate: the training step's bucketed gradient
+all-reduce issued from the gradient stream (training_loop.py:116,373-378) and the time-sharded sampler's halo exchange.
+
+* world_size 1: runs on every GPU box -- a real RCCL communicator, the initial broadcast, every bucket all-reduced from the
+  side stream while backward is still running, the optimizer ordered behind the collectives.
+* world_size 2: the gloo tests' assertions (tests/test_host_emulated.py) on two GPUs; skipped where fewer than two are visible.
+Workers are fresh processes (tests/_ddp_worker.py, tests/_shard_worker.py): one process per GPU, like the product.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host as oh
+
+pytestmark = pytest.mark.gpu
+
+NGPU = torch.cuda.device_count()
+two_gpus = pytest.mark.skipif(NGPU < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _golden(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name), allow_pickle=False).items()}
+
+
+def _check_step(golden_dir, tmp_path, world, bucket_mb):
+    import torch.multiprocessing as mp
+    from _ddp_worker import run
+    mp.spawn(run, args=(world, _free_port(), golden_dir, str(tmp_path), bucket_mb, "nccl"), nprocs=world, join=True)
+    g = _golden(golden_dir, "tiny_net.npz")
+    outs = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    assert all(o["world"] == world and o["backend"] == "nccl" for o in outs)
+    if bucket_mb < 1:
+        assert outs[0]["nb"] > 4  # several buckets chased the backward
+    for k, v in outs[0]["sd"].items():
+        p0, gr = torch.from_numpy(g["sd." + k]), torch.from_numpy(g["grad." + k])
+        exp = oh.adamw_step(p0, gr, torch.zeros_like(p0), torch.zeros_like(p0), 1, 1e-3)[0]
+        big = gr.abs() > 1e-5  # g/(|g|+eps) is ill-conditioned where |g| ~ eps (see tests/test_host_emulated.py)
+        assert torch.allclose(v[big], exp[big], atol=3e-6), k
+        assert (v - exp).abs().max().item() <= 2e-3, k
+        for o in outs[1:]:
+            assert torch.equal(v, o["sd"][k]), k  # ranks stay in lock step
+    assert sum(o["loss"] for o in outs) / world == pytest.approx(float(g["loss"]), rel=1e-4)
+    if world > 1:
+        assert outs[0]["draws"]["seed"] != outs[1]["draws"]["seed"]
+
+
+@pytest.mark.parametrize("bucket_mb", [48.0, 0.05])
+def test_training_step_over_rccl_single_rank(golden_dir, tmp_path, bucket_mb):
+    _check_step(golden_dir, tmp_path, 1, bucket_mb)
+
+
+@two_gpus
+@pytest.mark.parametrize("bucket_mb", [48.0, 0.05])
+def test_training_step_over_rccl_two_ranks_equals_single_process(golden_dir, tmp_path, bucket_mb):
+    _check_step(golden_dir, tmp_path, 2, bucket_mb)
+
+
+@two_gpus
+def test_time_sharded_sampler_over_rccl_two_ranks(golden_dir, tmp_path):
+    import torch.multiprocessing as mp
+    from _shard_worker import run
+    mp.spawn(run, args=(2, _free_port(), golden_dir, str(tmp_path), "nccl"), nprocs=2, join=True)
+    s = _golden(golden_dir, "sampler.npz")
+    r0, r1 = (torch.load(tmp_path / f"shard{r}.pt", weights_only=False) for r in (0, 1))
+    assert r0["uncond_c0.bounds"] == [(0, 5), (5, 9)]
+    for name in ("uncond_c0", "uncond_c1", "cond_c0"):
+        ref = torch.from_numpy(s[name + ".x"])
+        assert torch.equal(r0[name], r1[name]), name
+        assert (r0[name] - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), name
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` without torchrun starts N rank processes itself (train.py:93-100: fabric.launch()) and relays
+    rank 0's single JSON line; n_gpus is the world size RCCL saw."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 2 if NGPU >= 2 else 1
+    env = dict(os.environ, C2W_FORCE_DIST="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--sample-steps", "0", "--no-extras"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["config"]["parallelism"] == f"dp{n}" and rec["config"]["global_batch"] == 8 * n
+    assert rec["world_size_rccl"] == n and rec["value"] > 0

@@ -469,6 +469,33 @@ def test_ensemble_driver_on_device():
         assert (both[m] - alone).abs().max().item() <= 1e-4 * alone.abs().max().item()
 
 
+@pytest.mark.parametrize("corrections,cond", [(0, False), (1, False), (0, True)])
+def test_ensemble_members_are_the_reference_members_on_the_gpu(corrections, cond):
+    """a14 parity on the HIP path: seed s, rank r, member i is the member of the reference's loop (exp/downscaling.py:96-103,248-265;
+    oracle/host.py::ensemble_members over the CPU oracle network / score function / sampler).  2 ranks x 2 members, fp32, <= 3e-4."""
+    from climate2weather_amd.sampling import run_ensemble
+    net = _tiny().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    kw = dict(length=5, n_vars=2, height=16, width=16, markov_order=1, num_samples=4, steps=3, batch_size=2, seed=7, corrections=corrections,
+              tau=0.5)
+    cnd = {}
+    if cond:
+        A = PoolStrideOperator(8, 2)
+        truth = torch.rand(5, 2, 16, 16, generator=torch.Generator().manual_seed(9))
+        cnd = dict(A=A, y=oh.measure(truth, 8, 2), std=torch.tensor([0.5, 0.3]).view(1, 2, 1, 1), gamma=1e-2)
+    fwd = lambda a, b: ou.score_unet_forward(sd, a, b, hidden_blocks=[1, 1], attention_levels=[1])
+    score = od.GuidedScore(fwd, 1, A=(lambda z: oh.measure(z, 8, 2)) if cond else None, y=cnd.get("y"), std=cnd.get("std"), gamma=1e-2,
+                           exact_grad=False, batch_size=2)
+    for rank in (0, 1):
+        mine = run_ensemble(net, world=2, rank=rank, device=torch.device("cuda", 0), precision="fp32", exact_grad=False, **kw, **cnd)
+        ref = oh.ensemble_members(lambda noise, zs: od.sample(score, noise, steps=3, corrections=corrections, tau=0.5, z_draws=zs),
+                                  seed=7, rank=rank, world=2, num_samples=4, shape=(5, 2, 16, 16), steps=3, corrections=corrections)
+        assert [i for i, _ in mine] == [i for i, _ in ref] == [2 * rank, 2 * rank + 1]
+        for (_, a), (_, b) in zip(mine, ref):
+            assert a.is_cuda
+            assert (a.cpu() - b).abs().max().item() <= 3e-4 * b.abs().max().item()
+
+
 def test_reference_style_training_loop_on_the_module_api(golden_dir, tmp_path):
     """The reference's loop with only the class names changed: module -> .cuda() -> StandardEMA deep copies ->
     torch.optim.AdamW(net.parameters()) -> [pipeline.loss(net, x).mean().backward(); optimizer.step(); ema.update()] -> snapshot.

@@ -19,7 +19,9 @@ from climate2weather_amd.pipelines import SDAPipeline
 from climate2weather_amd.score import ScoreUNet
 from climate2weather_amd.score_fn import BatchedScoreFunction, DefaultScoreFunction, PoolStrideOperator
 from climate2weather_amd.training import Trainer, load_latest_checkpoint, save_checkpoint
+from oracle import diffusion as od
 from oracle import host as oh
+from oracle import unet as ou
 
 TINY = dict(embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3,
             padding_mode="zeros")
@@ -524,6 +526,46 @@ def test_ensemble_driver_shards_members_by_rank(emu):
     truth = torch.rand(5, 2, 16, 16)
     rc = run_ensemble(net, world=1, rank=0, A=A, y=A(truth), std=torch.tensor([0.5, 0.5]).view(1, 2, 1, 1), gamma=1e-2, **dict(kw, num_samples=1))
     assert rc[0][1].shape == (5, 2, 16, 16)
+
+
+def _oracle_members(sd, kw, rank, world, A=None, y=None, std=None, gamma=1e-2):
+    """oracle/host.py::ensemble_members over the oracle's network, score function and sampler (CPU, fp32)."""
+    fwd = lambda a, b: ou.score_unet_forward(sd, a, b, hidden_blocks=[1, 1], attention_levels=[1])
+    score = od.GuidedScore(fwd, kw["markov_order"], A=(lambda z: oh.measure(z, A.s_step, A.t_step)) if A is not None else None, y=y, std=std,
+                           gamma=gamma, exact_grad=False, batch_size=kw["batch_size"])
+    shape = (kw["length"], kw["n_vars"], kw["height"], kw["width"])
+    return oh.ensemble_members(lambda noise, zs: od.sample(score, noise, steps=kw["steps"], corrections=kw.get("corrections", 0),
+                                                           tau=kw.get("tau", 0.5), z_draws=zs),
+                               seed=kw["seed"], rank=rank, world=world, num_samples=kw["num_samples"], shape=shape, steps=kw["steps"],
+                               corrections=kw.get("corrections", 0))
+
+
+@pytest.mark.parametrize("corrections,cond", [(0, False), (1, False), (0, True)])
+def test_ensemble_members_are_the_reference_members(emu, corrections, cond):
+    """a14 parity: seed s, rank r, member i -> the member the reference's loop generates (exp/downscaling.py:96-103,248-265):
+    process seeded with hash((seed, rank)), one CPU randn(L, C, H, W) per member in member order, corrector normals from the same
+    CPU stream in the sampler's order.  2 ranks x 2 members, against oracle/host.py::ensemble_members, <= 3e-4 of scale."""
+    from climate2weather_amd.sampling import run_ensemble
+    net = _tiny().eval()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    kw = dict(length=5, n_vars=2, height=16, width=16, markov_order=1, num_samples=4, steps=3, batch_size=2, seed=7, corrections=corrections,
+              tau=0.5)
+    cnd = {}
+    if cond:
+        A = PoolStrideOperator(8, 2)
+        truth = torch.rand(5, 2, 16, 16, generator=torch.Generator().manual_seed(9))
+        cnd = dict(A=A, y=A(truth), std=torch.tensor([0.5, 0.3]).view(1, 2, 1, 1), gamma=1e-2)
+    for rank in (0, 1):
+        mine = run_ensemble(net, world=2, rank=rank, device=torch.device("cpu"), precision="fp32", exact_grad=False, **kw, **cnd)
+        ref = _oracle_members(sd, kw, rank, 2, **cnd)
+        assert [i for i, _ in mine] == [i for i, _ in ref] == [2 * rank, 2 * rank + 1]
+        for (_, a), (_, b) in zip(mine, ref):
+            assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item()
+    # the device stream is a different (opt-in) stream
+    dev = run_ensemble(net, world=2, rank=0, device=torch.device("cpu"), precision="fp32", rng="device", **kw, **cnd)
+    assert dev[0][1].shape == (5, 2, 16, 16)
+    with pytest.raises(ValueError):
+        run_ensemble(net, world=2, rank=0, device=torch.device("cpu"), precision="fp32", rng="philox", **kw)
 
 
 @pytest.mark.parametrize("cond", [False, True])

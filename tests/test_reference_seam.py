@@ -104,3 +104,30 @@ def test_reference_loss_ema_and_default_score_function_with_this_network(monkeyp
     with torch.no_grad():
         y = dsf(torch.from_numpy(s["score_x"]), torch.tensor(0.7))
     assert torch.allclose(y, torch.from_numpy(s["score_y"]), atol=2e-5)
+
+
+def test_member_random_stream_is_the_reference_drivers(monkeypatch):
+    """exp/downscaling.py:100-103,248-265 restated by oracle/host.py::ensemble_members: the driver itself is not importable here
+    (fire / xarray / lightning), but the two things it does with random numbers are -- seed the process, `torch.randn(L,C,H,W)` per
+    member, then the REFERENCE's `pipeline.sample`, whose corrector fills `z.normal_()` from the same CPU stream.  Running those
+    statements with the reference's sampler classes must give the members `run_ensemble(rng="reference")` gives."""
+    emu_ops.install(monkeypatch, c2w_ops)
+    from climate2weather_amd.sampling import run_ensemble
+    from oracle import host as oh
+    ref_pipe = _load("ref_pipelines_seam2", f"{REF}/src/thor/pipelines.py")
+    ref_score = _load("ref_score_seam2", f"{REF}/src/thor/score.py")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY).eval()
+    L, C, H, W, rank, world, n, seed = 5, 2, 16, 16, 1, 2, 4, 7
+    mine = run_ensemble(net, world=world, rank=rank, device=torch.device("cpu"), precision="fp32", length=L, n_vars=C, height=H, width=W,
+                        markov_order=1, num_samples=n, steps=3, corrections=1, tau=0.5, batch_size=2, seed=seed)
+    pipe = ref_pipe.SDAPipeline()
+    sf = ref_score.BatchedScoreFunction(net, markov_order=1, batch_size=2, device=torch.device("cpu"), noise_process=pipe)
+    oh.seed_everything(hash((seed, rank)) % (1 << 31))  # util.py:27-29
+    per = n // world
+    for i in range(per):  # exp/downscaling.py:248-258
+        noise_vec = torch.randn(L, C, H, W)
+        x = pipe.sample(sf, noise_vec, steps=3, corrections=1, tau=0.5, show_progressbar=False)
+        sid, xm = mine[i]
+        assert sid == rank * per + i
+        assert (xm - x).abs().max().item() <= 3e-4 * x.abs().max().item()
