@@ -138,6 +138,23 @@ class ScoreUNet(torch.nn.Module):
             new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
         return new
 
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """``nn.Module.load_state_dict`` that also takes the reference's own files: zuko's LayerNorm registers ``eps`` as a persistent
+        buffer, so a reference ``training-state-*.ckpt`` / module ``state_dict()`` carries one ``*.eps`` key per LayerNorm (40 in the
+        default network) next to the 228 parameter tensors (src/thor/checkpoint.py:37-57; SURVEY.md 8c iii) -- the LayerNorm here is
+        parameter- and buffer-free, its epsilon a kernel argument -- and Fabric's module wrapper prefixes keys with
+        ``_forward_module.`` on some versions.  Both are normalised away; everything else stays strict."""
+        own = self.state_dict().keys() if any(k.endswith(".eps") for k in state_dict) else ()
+        clean = type(state_dict)() if isinstance(state_dict, dict) else {}
+        for k, v in state_dict.items():
+            k = k[len("_forward_module."):] if k.startswith("_forward_module.") else k
+            if k.endswith(".eps") and k not in own:
+                if abs(float(v) - 1e-5) > 1e-12:
+                    raise ValueError(f"{k} = {float(v)}: this engine's channel LayerNorm uses eps = 1e-5 (model/nn.py:44,154,183)")
+                continue
+            clean[k] = v
+        return super().load_state_dict(clean, strict=strict, assign=assign)
+
     def compute_dtype(self) -> int:
         if self.precision == "fp32":
             return DTYPE_F32

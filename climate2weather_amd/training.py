@@ -255,8 +255,7 @@ class Trainer:
                     ema=dict(rates=list(self.ema_rates), emas=[sd for _, sd in self.ema_state_dicts()]))
 
     def load_state_dict(self, sd):
-        net_sd = {k[len("_forward_module."):] if k.startswith("_forward_module.") else k: v for k, v in sd["net"].items()}
-        self.net.load_state_dict(net_sd)
+        self.net.load_state_dict(sd["net"])  # tolerates zuko's `*.eps` buffer keys and Fabric's `_forward_module.` prefix (score.py)
         self.eng = self.net._get_engine()
         self.eng.weights_changed()
         self.load_optimizer_state_dict(sd["optimizer"])
@@ -268,6 +267,9 @@ class Trainer:
             views = self.eng.layout.views
             for flat, esd in zip(self.ema_flats, sd["ema"]["emas"]):
                 for name, t in esd.items():
+                    name = name[len("_forward_module."):] if name.startswith("_forward_module.") else name
+                    if name not in views and name.endswith(".eps"):
+                        continue  # zuko LayerNorm buffer of a reference checkpoint
                     off, shape, strides = views[name]
                     torch.as_strided(flat, shape, strides, off).copy_(t)
 

@@ -561,3 +561,61 @@ def test_reference_style_training_loop_on_the_module_api(golden_dir, tmp_path):
         ya = ema.emas[0](x, t.reshape(-1))
         yb = snap.ema(x, t.reshape(-1))
     assert (ya - yb).abs().max().item() <= 2e-2 * ya.abs().max().item()  # the snapshot stores fp16 weights
+
+
+# ------------------------------------------------------------------------------------------------ f2: snapshot / checkpoint formats
+def test_reference_network_snapshot_runs_on_the_hip_path(golden_dir):
+    """the reference-made `network-snapshot-*.pkl` fixture (pickled fp16 reference module, tests/golden/make_snapshot.py)
+    -> load_network_snapshot -> HIP forward, against the imported reference's fp32 outputs of the same network (tiny_net.npz).
+    Tolerance = the fp16 rounding of the stored weights (training_loop.py:259): 5e-3 of scale (the CPU-emulated test sees the same)."""
+    from climate2weather_amd.snapshot import load_network_snapshot
+    g = _golden(golden_dir, "tiny_net.npz")
+    snap = load_network_snapshot(os.path.join(golden_dir, "ref_snapshot_tiny.pkl"), device="cuda", precision="fp32")
+    assert snap.markov_order == 1 and next(snap.ema.parameters()).is_cuda
+    for k, v in snap.ema.state_dict().items():
+        assert torch.equal(v.cpu(), torch.from_numpy(g["sd." + k]).to(torch.float16).float()), k
+    with torch.no_grad():
+        y = snap.ema(torch.from_numpy(g["xt"]).cuda(), torch.from_numpy(g["t"]).cuda())
+        y32 = snap.ema(torch.from_numpy(g["x32"]).cuda(), torch.tensor(0.3).cuda())
+    for a, ref in ((y, g["y"]), (y32, g["y32"])):
+        assert (a.cpu() - torch.from_numpy(ref)).abs().max().item() <= 5e-3 * float(np.abs(ref).max())
+    # the same weights through the oracle: what is left is the kernels' own error, <= 1e-4
+    sd = {k: v.cpu() for k, v in snap.ema.state_dict().items()}
+    yo = ou.score_unet_forward(sd, torch.from_numpy(g["x32"]), torch.tensor(0.3), hidden_blocks=[1, 1], attention_levels=[1])
+    assert (y32.cpu() - yo).abs().max().item() <= 1e-4 * yo.abs().max().item()
+    # and the sampler runs on it, as exp/downscaling.py:110-126,208-214 does with the unpickled module
+    sf = BatchedScoreFunction(snap.ema, markov_order=snap.markov_order, batch_size=4, device=torch.device("cuda", 0), noise_process=snap.pipeline)
+    x = snap.pipeline.sample(sf, torch.randn(5, 2, 32, 32), steps=2, show_progressbar=False)
+    assert x.shape == (5, 2, 32, 32) and torch.isfinite(x).all()
+
+
+def test_resume_from_a_reference_made_training_state_checkpoint_on_the_gpu(golden_dir):
+    from _ckpt_check import resume_from_reference_checkpoint
+    resume_from_reference_checkpoint(golden_dir, torch.device("cuda", 0), lambda seed: _tiny(seed=seed))
+
+
+# ------------------------------------------------------------------------------------------------ f3: on-device dataset feed
+@pytest.mark.parametrize("start_idx", [0, 37])
+def test_device_window_feed_yields_the_reference_batches(start_idx):
+    """the array lives in HBM and a batch is an index gather on the device; the batches are the items
+    dataset.py:114-126 builds at the indices dataset.py:23-40 walks (oracle/host.py::infinite_order / window_item), here for rank 1
+    of 2, across an epoch boundary, and resumed from `start_idx = cur_ndata` (training_loop.py:164-171)."""
+    from climate2weather_amd.data import COSMODataset, DeviceWindowFeed, SyntheticWindowDataset
+    arr = np.random.RandomState(1).randn(30, 4, 16, 16).astype(np.float32)
+    ds = COSMODataset(arr, num_features=4, spatial_res=16, window=13, flatten=True)
+    feed = DeviceWindowFeed(ds, torch.device("cuda", 0), rank=1, num_replicas=2, seed=5, start_idx=start_idx)
+    order = oh.infinite_order(len(ds), rank=1, num_replicas=2, seed=5, start_idx=start_idx, count=3 * 7)
+    assert len(ds) == 18 and len(set(order)) > 1
+    data = torch.from_numpy(arr)
+    for b in range(3):
+        batch = feed.next_batch(7)
+        assert batch.is_cuda and batch.shape == (7, 52, 16, 16) and batch.dtype == torch.float32
+        for j in range(7):
+            assert torch.equal(batch[j].cpu(), oh.window_item(data, order[7 * b + j], 13)), (b, j)
+    # the synthetic stand-in used by bench.py: same item contract
+    sds = SyntheticWindowDataset(n_frames=20, n_vars=2, height=16, width=16, window=3, seed=0)
+    sfeed = DeviceWindowFeed(sds, torch.device("cuda", 0), rank=0, num_replicas=1, seed=0)
+    so = oh.infinite_order(len(sds), 0, 1, 0, 0, 4)
+    sb = sfeed.next_batch(4)
+    for j in range(4):
+        assert torch.equal(sb[j].cpu(), oh.window_item(sds.data, so[j], 3))

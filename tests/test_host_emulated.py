@@ -107,6 +107,11 @@ def test_gradient_accumulation_sums_rounds(emu, golden_dir):
     assert ga.abs().sum() > g1.abs().sum() > 0  # two rounds accumulated into the same buffer
 
 
+def test_resume_from_a_reference_made_training_state_checkpoint(emu, golden_dir):
+    from _ckpt_check import resume_from_reference_checkpoint
+    resume_from_reference_checkpoint(golden_dir, torch.device("cpu"), lambda seed: _tiny(seed=seed))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
