@@ -206,6 +206,52 @@ def full_net_fingerprint():
     np.savez_compressed(os.path.join(HERE, "full_net_slice.npz"), y_slice=y[:, :, ::16, ::16].numpy())
 
 
+# Representative gradient tensors of the default network kept as strided slices: the network-input conv, a residual
+# conv at full resolution, a stride-2 head, the up-conv back to full resolution, the output conv, attention qkv / proj, a modulation
+# projection and the time MLP.  (step over dim 0, step over dim 1)
+FULL_GRAD_SLICES = {
+    "unet.heads.0.weight": (4, 1), "unet.descent.0.1.residue.1.weight": (8, 8), "unet.ascent.4.2.residue.3.weight": (8, 8),
+    "unet.heads.1.0.weight": (8, 8), "unet.heads.4.0.weight": (32, 24), "unet.tails.3.2.weight": (8, 8), "unet.tails.0.2.weight": (24, 32),
+    "unet.tails.4.weight": (1, 8), "unet.descent.2.1.residue.3.weight": (16, 16), "unet.descent.4.2.residue.1.weight": (32, 32),
+    "unet.descent.4.1.qkv.weight": (48, 32), "unet.ascent.0.3.proj_out.weight": (32, 32), "unet.descent.0.0.project.0.weight": (8, 32),
+    "unet.ascent.2.1.project.0.weight": (16, 32), "map_layer0.weight": (16, 1), "map_layer1.weight": (32, 32),
+}
+
+
+def full_net_gradients():
+    """Backward of the default network pinned to the imported reference (training_loop.py:376-378 over src/thor/pipelines.py:27-35 with
+    the draws injected): B = 2 at C = 52 (the reference's recipe) and C = 65 (north-star, the benchmarked channel count: exercises the
+    65 -> 128 channel padding of the network-input / output convs).  72 M gradients are too many to ship: per tensor the absolute sum
+    and the L2 norm (float64) of ALL 228 gradients, strided slices of the tensors in FULL_GRAD_SLICES, every bias gradient of those in
+    full, plus the loss and a strided output slice.  Inputs are regenerated by the tests from the seeds below."""
+    cfg = yaml.full_load(open(f"{REF}/configs/sda_unet.yml"))
+    pipe = pipelines.SDAPipeline()
+    for C in (52, 65):
+        torch.manual_seed(0)
+        net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **cfg)
+        g = torch.Generator().manual_seed(4000 + C)
+        x = torch.randn(2, C, 128, 128, generator=g) * 0.5 + 0.5
+        t = torch.rand(2, 1, 1, 1, generator=g)
+        eps = torch.randn(2, C, 128, 128, generator=g)
+        xt = pipe.mu(t) * x + pipe.sigma(t) * eps
+        y = net(xt, t)
+        loss = ((y - eps) ** 2).mean()
+        names = [k for k, _ in net.named_parameters()]
+        grads = dict(zip(names, torch.autograd.grad(loss, list(net.parameters()))))
+        out = {"seed": np.int64(4000 + C), "t": t.numpy(), "loss": np.float64(loss.item()), "y_slice": y.detach()[:, :, ::16, ::16].numpy(),
+               "names": np.array(names),
+               "abs_sum": np.array([grads[k].double().abs().sum().item() for k in names]),
+               "norm": np.array([grads[k].double().norm().item() for k in names]),
+               "x_checksum": np.float64(x.double().sum().item()), "eps_checksum": np.float64(eps.double().sum().item())}
+        for k, (s0, s1) in FULL_GRAD_SLICES.items():
+            out["slice." + k] = grads[k][::s0, ::s1].contiguous().numpy()
+            out["step." + k] = np.array([s0, s1])
+            kb = k[: -len("weight")] + "bias"
+            out["full." + kb] = grads[kb].numpy()
+        np.savez_compressed(os.path.join(HERE, f"full_net_grads_c{C}.npz"), **out)
+        print(f"C={C}: loss {loss.item():.6f}")
+
+
 def ema_kat():
     torch.manual_seed(4)
     lin = torch.nn.Linear(4, 3)
@@ -220,11 +266,15 @@ def ema_kat():
 
 
 if __name__ == "__main__":
-    kats()
-    ops()
-    net = tiny_net()
-    sampler(net)
-    ema_kat()
-    full_net_fingerprint()
+    if sys.argv[1:] == ["full_net_gradients"]:
+        full_net_gradients()
+    else:
+        kats()
+        ops()
+        net = tiny_net()
+        sampler(net)
+        ema_kat()
+        full_net_fingerprint()
+        full_net_gradients()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

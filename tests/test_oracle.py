@@ -154,3 +154,35 @@ def test_ema_and_adamw(golden_dir):
         assert torch.allclose(q, p.detach(), atol=1e-6)
     assert oh.batch_split(512, 4, 128) == (128, 1)
     assert oh.batch_split(512, 2, 128) == (128, 2)
+
+
+@pytest.mark.parametrize("C", [52, 65])
+def test_full_size_backward_fingerprints(golden_dir, C):
+    """The oracle itself against the full-size gradient fixtures of the imported reference (make_golden.py::full_net_gradients):
+    default network, B = 2, injected (t, eps) -- loss, L2 norm / absolute sum of all 228 gradients, the kept slices."""
+    from climate2weather_amd.score import ScoreUNet  # parameter container only: creation-order init == the reference's (tested)
+    g = {k: v for k, v in np.load(os.path.join(golden_dir, f"full_net_grads_c{C}.npz"), allow_pickle=False).items()}
+    cfg = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3, padding_mode="zeros",
+               attention_levels=[4])
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **cfg)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    x = torch.randn(2, C, 128, 128, generator=gen) * 0.5 + 0.5
+    t = torch.rand(2, 1, 1, 1, generator=gen)
+    eps = torch.randn(2, C, 128, 128, generator=gen)
+    assert eps.double().sum().item() == pytest.approx(float(g["eps_checksum"]), rel=1e-12)
+    fwd = lambda a, b: ou.score_unet_forward(sd, a, b, cfg["hidden_blocks"], cfg["attention_levels"])
+    loss = od.loss(fwd, x, t, eps).mean()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6)
+    names = [str(n) for n in g["names"]]
+    grads = dict(zip(sd.keys(), torch.autograd.grad(loss, list(sd.values()))))
+    for n, nr, ab in zip(names, g["norm"], g["abs_sum"]):
+        assert grads[n].double().norm().item() == pytest.approx(float(nr), rel=1e-4), n
+        assert grads[n].double().abs().sum().item() == pytest.approx(float(ab), rel=1e-4), n
+    for k in g:
+        if k.startswith("slice."):
+            n = k[len("slice."):]
+            s0, s1 = (int(v) for v in g["step." + n])
+            ref = torch.from_numpy(g[k])
+            assert (grads[n][::s0, ::s1] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-12, n
