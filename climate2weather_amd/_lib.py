@@ -39,8 +39,8 @@ _PROTOS = {
     "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_void_p],
-    "c2w_set_workspace": [c_void_p, c_ulonglong],
+    "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_ulonglong, c_int, c_void_p],
+    "c2w_conv_wgrad_workspace_bytes": [POINTER(ConvArgs), c_int],
     "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,
                         c_int, c_void_p],
@@ -96,11 +96,16 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise C2wError(f"{LIB_PATH} is missing: run `python -m climate2weather_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback for the product path.")
+    if not os.environ.get("C2W_LIB") and os.environ.get("C2W_ALLOW_STALE_LIB", "") in ("", "0"):
+        from . import build as _build  # content hash of csrc/ + include/ against the stamp the build wrote next to the objects
+        if os.path.isdir(_build.CSRC) and _build._stale():
+            raise C2wError(f"{LIB_PATH} was not built from the sources on disk (stamp {_build.STAMP} missing or different): run "
+                           "`python -m climate2weather_amd.build`.  Refusing to run kernels that do not match the source tree.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name.endswith("_bytes") else c_int
     lib.c2w_target.restype = c_char_p
     lib.c2w_target.argtypes = []
     _lib = lib

@@ -2,6 +2,7 @@
 
     python -m climate2weather_amd.build
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -10,20 +11,47 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libc2w_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]
 SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch3.hip", "wgrad.hip", "wgrad_patch.hip", "pointwise.hip", "attention.hip", "attention_mfma.hip",
            "sampler.hip"]
 
 
+STAMP = os.path.join(HERE, "build", "sources.sha256")
+
+
+def sources_digest() -> str:
+    """sha256 over every file the library is compiled from (csrc/*.hip, csrc/*.h, include/c2w_hip.h) and the compile flags."""
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))) + [os.path.join(INCLUDE, "c2w_hip.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def file_digest(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    """The library is reused only if it was built from exactly these sources (content hash, not mtimes: a copied tree has neither)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "c2w_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().split()[:1] != [sources_digest()]
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    force = force or os.environ.get("C2W_FORCE_BUILD", "") not in ("", "0")
     if not force and not _stale():
+        if verbose:
+            print(f"reused {LIB}: sources sha256 {sources_digest()[:16]} match the stamp; library sha256 {file_digest(LIB)[:16]}", flush=True)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -34,7 +62,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(path):
             continue
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC, "-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-I" + INCLUDE, "-I" + CSRC, "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -48,6 +76,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(sources_digest() + "\n")
+    if verbose:
+        print(f"compiled {len(objs)} translation units for gfx950 -> {LIB}: sources sha256 {sources_digest()[:16]}, library sha256 {file_digest(LIB)[:16]}",
+              flush=True)
     return LIB
 
 

@@ -48,8 +48,6 @@ int c2w_conv_patch3(const C2wConvArgs& a, int dtype, hipStream_t st);
 
 // halo-patch weight-gradient kernel for the same convolutions (wgrad_patch.hip)
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a);
-int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st);
-
-// scratch buffer for split-K partial sums of the weight-gradient kernels (c2w_set_workspace, wgrad_patch.hip)
-extern float* c2w_g_ws;
-extern size_t c2w_g_ws_bytes;
+// ws / ws_bytes: the caller's scratch buffer for the split-K partial sums (NULL / too small: fp32 atomics)
+int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, int dtype, hipStream_t st);
+size_t c2w_wgrad_patch_ws_bytes(const C2wConvArgs& a, int dtype);

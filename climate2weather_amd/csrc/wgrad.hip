@@ -328,24 +328,43 @@ FastDiv make_div(uint32_t d) {
     return r;
 }
 
+// split of the K (pixel) range: one resident wave of workgroups (2 per CU): measured best on the 8x8 / stride-2 / upsampling shapes
+// (atomics grow with the split)
+template <int ESZ, int NT>
+static void split_plan(const C2wConvArgs& a, int& tilesM, int& tilesN, int& nsplit, int& ktiles_per_split) {
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    const long long npix = (long long)a.B * a.Hout * a.Wout;
+    const int nkt = (int)((npix + KT - 1) / KT);
+    tilesN = (NT * (a.Cin / CIB) + 3) / 4;
+    tilesM = (a.Cout + COT - 1) / COT;
+    const int tilesMN = tilesM * tilesN;
+    static const int target = getenv("C2W_WGRAD_TARGET") ? atoi(getenv("C2W_WGRAD_TARGET")) : 432;
+    nsplit = (target + tilesMN - 1) / tilesMN;
+    if (nsplit > nkt) nsplit = nkt;
+    if (nsplit < 1) nsplit = 1;
+    ktiles_per_split = (nkt + nsplit - 1) / nsplit;
+    nsplit = (nkt + ktiles_per_split - 1) / ktiles_per_split;
+}
+
+template <int ESZ, int NT>
+static size_t ws_need(const C2wConvArgs& a) {
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    int tilesM, tilesN, nsplit, per;
+    split_plan<ESZ, NT>(a, tilesM, tilesN, nsplit, per);
+    return nsplit > 1 ? (size_t)nsplit * tilesM * tilesN * COT * 4 * CIB * sizeof(float) : 0;
+}
+
 template <typename T, int MODE>
-int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
+int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
     constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
     WgradArgs p;
     p.dy = a.y; p.x = a.x; p.dw = dw; p.db = db;
     p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Cin = a.Cin; p.Hout = a.Hout; p.Wout = a.Wout; p.Cout = a.Cout; p.ldy = a.ldy;
-    const long long npix = (long long)a.B * a.Hout * a.Wout;
-    const int nkt = (int)((npix + KT - 1) / KT);
-    const int tilesN = (NT * (a.Cin / CIB) + 3) / 4, tilesM = (a.Cout + COT - 1) / COT;
+    int tilesM, tilesN;
+    split_plan<ESZ, NT>(a, tilesM, tilesN, p.nsplit, p.ktiles_per_split);
     const int tilesMN = tilesM * tilesN;
-    static const int target = getenv("C2W_WGRAD_TARGET") ? atoi(getenv("C2W_WGRAD_TARGET")) : 432;
-    int nsplit = (target + tilesMN - 1) / tilesMN;  // one resident wave of workgroups (2 per CU): measured best on the 8x8 / stride-2 / upsampling shapes (atomics grow with the split)
-    if (nsplit > nkt) nsplit = nkt;
-    if (nsplit < 1) nsplit = 1;
-    p.ktiles_per_split = (nkt + nsplit - 1) / nsplit;
-    p.nsplit = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
     p.div_hw = make_div((uint32_t)(a.Hout * a.Wout));
     p.div_w = make_div((uint32_t)a.Wout);
     constexpr int lds_main = NSLOT * (ABYTES + BBYTES);
@@ -357,7 +376,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
         attr_set = true;
     }
     const size_t need = (size_t)p.nsplit * tilesMN * COT * 4 * CIB * sizeof(float);
-    p.ws = (c2w_g_ws != nullptr && need <= c2w_g_ws_bytes && p.nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? c2w_g_ws : nullptr;
+    p.ws = (ws != nullptr && need <= ws_bytes && p.nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? ws : nullptr;
     wgrad_kernel<T, MODE><<<tilesMN * p.nsplit, NTHREADS, lds, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per4 = (size_t)tilesMN * COT * 4 * CIB / 4;
@@ -368,12 +387,12 @@ int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
 }
 
 template <typename T>
-int launch_dtype(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
+int launch_dtype(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
     switch (a.mode) {
-        case C2W_CONV_1X1: return launch<T, C2W_CONV_1X1>(a, dw, db, st);
-        case C2W_CONV_S1: return launch<T, C2W_CONV_S1>(a, dw, db, st);
-        case C2W_CONV_S2: return launch<T, C2W_CONV_S2>(a, dw, db, st);
-        case C2W_CONV_UP: return launch<T, C2W_CONV_UP>(a, dw, db, st);
+        case C2W_CONV_1X1: return launch<T, C2W_CONV_1X1>(a, dw, db, ws, ws_bytes, st);
+        case C2W_CONV_S1: return launch<T, C2W_CONV_S1>(a, dw, db, ws, ws_bytes, st);
+        case C2W_CONV_S2: return launch<T, C2W_CONV_S2>(a, dw, db, ws, ws_bytes, st);
+        case C2W_CONV_UP: return launch<T, C2W_CONV_UP>(a, dw, db, ws, ws_bytes, st);
     }
     return C2W_ERR_BAD_ARG;
 }
@@ -383,17 +402,38 @@ int launch_dtype(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
 // Geometry is passed with the forward call's argument block: x = the forward input, y = dY (gradient w.r.t. the forward
 // output, [B*Hout*Wout][ldy]); w/bias/res/mul/act are ignored.  dw is [Cout][taps][Cin] fp32 and is accumulated into;
 // dbias (optional) receives the bias gradient sum_q dY[q][co] from the same pass over dY.
-extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, int dtype, void* stream) {
-    if (a == nullptr || a->x == nullptr || a->y == nullptr || dw == nullptr) return C2W_ERR_BAD_ARG;
+static int wgrad_check(const C2wConvArgs* a, int dtype) {
+    if (a == nullptr) return C2W_ERR_BAD_ARG;
+    if (dtype != C2W_DTYPE_F32 && dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16) return C2W_ERR_BAD_ARG;
     const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
     if (a->Cin <= 0 || a->Cin % (128 / esz) != 0) return C2W_ERR_BAD_SHAPE;
     if (a->Cout <= 0 || a->ldy % (16 / esz) != 0 || a->Cout > a->ldy) return C2W_ERR_BAD_SHAPE;
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
     if ((long long)a->B * a->Hout * a->Wout >= (1ll << 31)) return C2W_ERR_BAD_SHAPE;
+    if (a->mode != C2W_CONV_1X1 && a->mode != C2W_CONV_S1 && a->mode != C2W_CONV_S2 && a->mode != C2W_CONV_UP) return C2W_ERR_BAD_ARG;
+    return 0;
+}
+
+extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, void* workspace, unsigned long long workspace_bytes, int dtype,
+                              void* stream) {
+    const int rc = wgrad_check(a, dtype);
+    if (rc != 0) return rc;
+    if (a->x == nullptr || a->y == nullptr || dw == nullptr) return C2W_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch(*a, dw, dbias, dtype, st);
-    if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, dbias, st);
-    if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, dbias, st);
-    if (dtype == C2W_DTYPE_F16) return launch_dtype<f16_t>(*a, dw, dbias, st);
-    return C2W_ERR_BAD_ARG;
+    float* ws = (float*)workspace;
+    const size_t wsb = workspace == nullptr ? 0 : (size_t)workspace_bytes;
+    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch(*a, dw, dbias, ws, wsb, dtype, st);
+    if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, dbias, ws, wsb, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, dbias, ws, wsb, st);
+    return launch_dtype<f16_t>(*a, dw, dbias, ws, wsb, st);
+}
+
+// Bytes of scratch c2w_conv_wgrad would use for this geometry (0: the launch does not split its reduction), or a negative status.
+extern "C" long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* a, int dtype) {
+    const int rc = wgrad_check(a, dtype);
+    if (rc != 0) return rc;
+    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return (long long)c2w_wgrad_patch_ws_bytes(*a, dtype);
+    const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
+    if (a->mode == C2W_CONV_1X1) return (long long)(esz == 4 ? ws_need<4, 1>(*a) : ws_need<2, 1>(*a));
+    return (long long)(esz == 4 ? ws_need<4, 9>(*a) : ws_need<2, 9>(*a));
 }

@@ -25,9 +25,6 @@
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA after the
 #endif             // first tile, 32 no epilogue
 
-// process-wide workspace registered by the host (c2w_set_workspace): one thread per rank, launches on one stream are ordered
-float* c2w_g_ws = nullptr;
-size_t c2w_g_ws_bytes = 0;
 
 namespace {
 
@@ -336,29 +333,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// split of the K (pixel-tile) range over workgroups: one resident workgroup per CU and ONE round: tilesMN * nsplit <= 256 (rounding
+// up gave 270 workgroups for 384 -> 384 -- a second round for 14 of them: 155 us instead of one round's ~90 at 16x16); every workgroup
+// costs 295 KB of partial sums
+template <int ESZ, bool PAIR>
+static void split_plan(const C2wConvArgs& a, int& ktiles, int& tilesMN, int& nsplit, int& ktiles_per_split) {
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    ktiles = PAIR ? ((a.B + 1) >> 1) * (a.Hin >> 3) : a.B * (a.Hin >> 3) * (a.Win >> 4);
+    tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
+    nsplit = 256 / tilesMN;
+    if (nsplit > ktiles) nsplit = ktiles;
+    if (nsplit < 1) nsplit = 1;
+    ktiles_per_split = (ktiles + nsplit - 1) / nsplit;
+    nsplit = (ktiles + ktiles_per_split - 1) / ktiles_per_split;
+}
+
+template <int ESZ, bool PAIR>
+static size_t ws_need(const C2wConvArgs& a) {
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    int ktiles, tilesMN, nsplit, per;
+    split_plan<ESZ, PAIR>(a, ktiles, tilesMN, nsplit, per);
+    return nsplit > 1 ? (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float) : 0;
+}
+
 template <typename T, bool PAIR>
-int launch(const C2wConvArgs& a, float* dw, float* db, hipStream_t st) {
+int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
     WpArgs p;
     p.dy = a.y; p.x = a.x; p.dw = dw; p.db = db;
     p.B = a.B; p.H = a.Hin; p.W = a.Win; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
-    p.ktiles = PAIR ? ((a.B + 1) >> 1) * (a.Hin >> 3) : a.B * (a.Hin >> 3) * (a.Win >> 4);
-    const int tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
-    // one resident workgroup per CU and ONE round: tilesMN * nsplit <= 256 (rounding up gave 270 workgroups for 384 -> 384 -- a
-    // second round for 14 of them: 155 us instead of one round's ~90 at 16x16); every workgroup costs 295 KB of partial sums
-    int nsplit = 256 / tilesMN;
-    if (nsplit > p.ktiles) nsplit = p.ktiles;
-    if (nsplit < 1) nsplit = 1;
-    p.ktiles_per_split = (p.ktiles + nsplit - 1) / nsplit;
-    nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    int tilesMN, nsplit;
+    split_plan<ESZ, PAIR>(a, p.ktiles, tilesMN, nsplit, p.ktiles_per_split);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
-    p.ws = (c2w_g_ws != nullptr && need <= c2w_g_ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? c2w_g_ws : nullptr;
+    p.ws = (ws != nullptr && need <= ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? ws : nullptr;
     wgrad_patch_kernel<T, PAIR><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
@@ -379,23 +392,21 @@ bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
     return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && ((a.Win & 15) == 0 || wgrad_pair(a));
 }
 
-int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, int dtype, hipStream_t st) {
+int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, int dtype, hipStream_t st) {
     if (wgrad_pair(a)) {
-        if (dtype == C2W_DTYPE_F32) return launch<float, true>(a, dw, db, st);
-        if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, true>(a, dw, db, st);
-        if (dtype == C2W_DTYPE_F16) return launch<f16_t, true>(a, dw, db, st);
+        if (dtype == C2W_DTYPE_F32) return launch<float, true>(a, dw, db, ws, ws_bytes, st);
+        if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, true>(a, dw, db, ws, ws_bytes, st);
+        if (dtype == C2W_DTYPE_F16) return launch<f16_t, true>(a, dw, db, ws, ws_bytes, st);
         return C2W_ERR_BAD_ARG;
     }
-    if (dtype == C2W_DTYPE_F32) return launch<float, false>(a, dw, db, st);
-    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, false>(a, dw, db, st);
-    if (dtype == C2W_DTYPE_F16) return launch<f16_t, false>(a, dw, db, st);
+    if (dtype == C2W_DTYPE_F32) return launch<float, false>(a, dw, db, ws, ws_bytes, st);
+    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, false>(a, dw, db, ws, ws_bytes, st);
+    if (dtype == C2W_DTYPE_F16) return launch<f16_t, false>(a, dw, db, ws, ws_bytes, st);
     return C2W_ERR_BAD_ARG;
 }
 
-// Scratch memory for the split-K partial sums of the weight-gradient kernels (caller-owned device buffer; NULL / 0 to
-// unregister).  Without it the kernels combine their partial sums with fp32 atomics.
-extern "C" int c2w_set_workspace(void* ptr, unsigned long long bytes) {
-    c2w_g_ws = (float*)ptr;
-    c2w_g_ws_bytes = (size_t)bytes;
-    return 0;
+size_t c2w_wgrad_patch_ws_bytes(const C2wConvArgs& a, int dtype) {
+    const bool pair = wgrad_pair(a);
+    if (dtype == C2W_DTYPE_F32) return pair ? ws_need<4, true>(a) : ws_need<4, false>(a);
+    return pair ? ws_need<2, true>(a) : ws_need<2, false>(a);
 }

@@ -191,6 +191,7 @@ class Engine:
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
         self._wg_stream = None  # second HIP stream for the weight-gradient launches (see _wg)
+        self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
         self.attach(net)
 
     # ------------------------------------------------------------------ parameter storage
@@ -241,8 +242,6 @@ class Engine:
         a view into it, so optimizers / all-reduce see one contiguous tensor."""
         if self.flat_grad is None:
             self.flat_grad = torch.zeros_like(self.flat)
-            if self.flat.is_cuda:
-                ops.ensure_workspace(self.flat.device)  # split-K partial sums of the weight-gradient kernels
         if bind and net is not None:
             for name, (off, shape, strides) in self.layout.views.items():
                 mod, attr = _resolve(net, name)
@@ -366,9 +365,21 @@ class Engine:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
 
+    def workspace(self) -> Optional[torch.Tensor]:
+        """Split-K scratch for a weight-gradient launch on torch's CURRENT stream.  One buffer per (engine, stream): launches on one
+        stream are ordered, so they can share it; two engines, or one engine's backward on two streams (training on the gradient
+        stream next to an exact-guidance backward elsewhere), never see each other's partial sums."""
+        if self.flat is None or not self.flat.is_cuda:
+            return None
+        key = torch.cuda.current_stream(self.flat.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.device != self.flat.device:
+            ws = self._ws[key] = ops.new_workspace(self.flat.device)
+        return ws
+
     def _wg(self, x: torch.Tensor, gy: torch.Tensor, rec: ConvRec, g: dict, dt: int) -> None:
         """dW, dbias of ``rec`` (dense operand) into the flat gradient buffer, on the gradient stream."""
-        self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec)), x, gy)
+        self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
 
     def _wgrad(self, rec: ConvRec, x: torch.Tensor, gy: torch.Tensor, g: dict, dt: int) -> None:
         """dW (+ dbias) of ``rec`` into the flat gradient buffer; a padded-operand layer goes through a padded scratch."""
@@ -383,7 +394,7 @@ class Engine:
                 buf = self._gwpad[rec.name] = torch.zeros(n, dtype=torch.float32, device=self.flat.device)
             else:
                 buf.zero_()
-            ops.conv_wgrad(x, gy, buf, g, dt, dbias=self._gb(rec))
+            ops.conv_wgrad(x, gy, buf, g, dt, dbias=self._gb(rec), workspace=self.workspace())
             self.flat_grad[rec.w_off: rec.w_off + rec.rows * rec.taps * rec.cin].view(rec.rows, rec.taps, rec.cin).add_(
                 buf.view(rec.rows, rec.taps, rec.kstride)[:, :, : rec.cin])
         self._on_grad_stream(run, x, gy)
@@ -417,7 +428,7 @@ class Engine:
                     gt = self._geom(rec.rows, 1, 1, rec.cin, 1, 1, rows, ld, rows, CONV_1X1)
                     # same kernels, same split-K workspace as the weight gradients: same stream, then wait for the result
                     wmat = self._w(rec, DTYPE_F32)
-                    self._on_grad_stream(lambda: ops.conv_wgrad(wmat, gyT, dx, gt, DTYPE_F32), gyT, dx)
+                    self._on_grad_stream(lambda: ops.conv_wgrad(wmat, gyT, dx, gt, DTYPE_F32, workspace=self.workspace()), gyT, dx)
                     self.join_grad_stream()
                     return dx
                 dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)

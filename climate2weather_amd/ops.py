@@ -73,31 +73,31 @@ def conv_lnbwd_supported(g: dict, dtype: int) -> bool:
     return bool(_lib.load().c2w_conv_lnbwd_supported(ctypes.byref(a), dtype))
 
 
-def conv_wgrad(x, dy, dw, g: dict, dtype: int, dbias=None):
-    """c2w_conv_wgrad: dw += dY^T . gather(x); dbias (optional) += column sums of dY."""
+def conv_wgrad(x, dy, dw, g: dict, dtype: int, dbias=None, workspace: Optional[torch.Tensor] = None):
+    """c2w_conv_wgrad: dw += dY^T . gather(x); dbias (optional) += column sums of dY.
+    ``workspace``: fp32 scratch tensor for the split-K partial sums (``new_workspace``), handed over per call; one per stream.
+    Without it (or when it is too small for the geometry) the partial sums are combined with fp32 atomics."""
     a = _conv_args(x, None, None, None, None, dy, g, 0, 0)
     a.w = None
-    check(_lib.load().c2w_conv_wgrad(ctypes.byref(a), _p(dw), _p(dbias), dtype, _stream()), "c2w_conv_wgrad")
+    nbytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    check(_lib.load().c2w_conv_wgrad(ctypes.byref(a), _p(dw), _p(dbias), _p(workspace), nbytes, dtype, _stream()), "c2w_conv_wgrad")
 
 
-_WORKSPACE = {}
+def conv_wgrad_workspace_bytes(g: dict, dtype: int) -> int:
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    n = int(_lib.load().c2w_conv_wgrad_workspace_bytes(ctypes.byref(a), dtype))
+    if n < 0:
+        check(n, "c2w_conv_wgrad_workspace_bytes")
+    return n
 
 
-def ensure_workspace(device, nbytes: int = 96 << 20) -> None:
-    """Register a scratch buffer for the weight-gradient kernels' split-K partial sums (c2w_set_workspace): 96 MB covers
-    every layer of the default network at any batch (75.5 MB per launch, independent of the batch size)."""
-    key = str(device)
-    if key not in _WORKSPACE:
-        buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-        _WORKSPACE.clear()  # the library keeps ONE pointer: one device per process
-        _WORKSPACE[key] = buf
-        check(_lib.load().c2w_set_workspace(_p(buf), nbytes), "c2w_set_workspace")
+WORKSPACE_BYTES = 96 << 20  # covers every layer of the default network at any batch (75.5 MB per launch, independent of the batch size)
 
 
-def drop_workspace() -> None:
-    """Unregister the scratch buffer (the kernels fall back to fp32 atomics)."""
-    _WORKSPACE.clear()
-    check(_lib.load().c2w_set_workspace(None, 0), "c2w_set_workspace")
+def new_workspace(device, nbytes: int = WORKSPACE_BYTES) -> torch.Tensor:
+    """A scratch buffer for ``conv_wgrad`` (allocated on torch's current stream: keep one per stream that launches weight gradients)."""
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
 def ln_forward(x, m, y, npix, HW, C, ldm, eps, unbiased, dtype):

@@ -92,16 +92,20 @@ int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);
 int c2w_conv_forward(const C2wConvArgs* args, int dtype, int naive, void* stream);
 
 /* dW[co][tap][ci] (fp32) += sum_q dY[q][co] * x[src(q,tap)][ci]  -- weight gradient of the same geometry.
- * Pass the forward call's block with y := dY; w/bias/res/mul/act are ignored.  Split-K over pixels across
- * workgroups, combined with fp32 atomics: zero dw (or leave the value to accumulate onto) beforehand.
+ * Pass the forward call's block with y := dY; w/bias/res/mul/act are ignored.  The reduction over pixels is split across
+ * workgroups: zero dw (or leave the value to accumulate onto) beforehand.
  * dbias (may be NULL): [Cout] fp32, += sum_q dY[q][co] (the bias gradient, from the same pass over dY).
+ * workspace / workspace_bytes: caller-owned device scratch (16-byte aligned) for the split's partial sums, handed over PER CALL --
+ * the library keeps no pointer, so the entry point is re-entrant: with it the workgroups store their partial tiles and a second
+ * launch on the same stream reduces them in a fixed order (75 MB of coalesced stores + reads per launch instead of 75 MB of fp32
+ * atomics; results are deterministic); NULL, or fewer bytes than c2w_conv_wgrad_workspace_bytes() asks for: fp32 atomics.
+ * Contents are undefined before and after the call.  One buffer must not be handed to launches that may run concurrently
+ * (different streams without an ordering between them): give each stream its own.
  * Replaces autograd's weight/bias backward of every Conv2d/Conv1d/Linear cited above. */
-int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, float* dbias, int dtype, void* stream);
-/* Optional scratch buffer (caller-owned device memory, fp32) for the split-K partial sums of c2w_conv_wgrad's halo-patch
- * kernel: with it the workgroups store their partial tiles and a second launch reduces them (75 MB of coalesced stores +
- * reads per launch instead of 75 MB of fp32 atomics); without it, or if it is too small for a launch, atomics are used.
- * Process-wide (one rank = one process = one stream of launches); pass NULL, 0 to unregister. */
-int c2w_set_workspace(void* ptr, unsigned long long bytes);
+int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, float* dbias, void* workspace, unsigned long long workspace_bytes, int dtype,
+                   void* stream);
+/* Scratch bytes c2w_conv_wgrad uses for this geometry and dtype (0: no split), or a negative C2W_ERR_* status. */
+long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* args, int dtype);
 
 /* y = LN_C(x + m[b]): parameter-free channel LayerNorm (zuko.nn.LayerNorm at model/nn.py:44,154,183) fused with
  * the time-modulation add of model/nn.py:28.  x,y: [npix][C]; m: fp32 rows of C (row b = pixel / HW, stride ldm;

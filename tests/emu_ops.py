@@ -111,11 +111,11 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
         _rows(y2, npix, ldy)[:, :Cout] = F.silu(out.to(T).float()).to(T)
 
 
-def ensure_workspace(device, nbytes=0):
-    pass
+def new_workspace(device, nbytes=0):
+    return None
 
 
-def conv_wgrad(x, dy, dw, g, dtype, dbias=None):
+def conv_wgrad(x, dy, dw, g, dtype, dbias=None, workspace=None):
     B, Hin, Win, Cin, Hout, Wout, Cout, ldy = (g[k] for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ldy"))
     taps = 1 if g["mode"] == CONV_1X1 else 9
     X = _rows(x, B * Hin * Win, Cin).view(B, Hin, Win, Cin).float().permute(0, 3, 1, 2)

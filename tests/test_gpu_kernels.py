@@ -234,10 +234,7 @@ def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased, dt):
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] != ops.CONV_TS2])
 def test_conv_wgrad(case, dt, force_gather, monkeypatch):
     mode, B, Hin, Win, Cin, Cout, wrows, ldy = case
-    if force_gather == "workspace":  # split-K partial sums through the registered scratch buffer instead of atomics
-        ops.ensure_workspace(dev())
-    else:
-        ops.drop_workspace()
+    ws = ops.new_workspace(dev()) if force_gather == "workspace" else None  # split-K partial sums through a scratch buffer instead of atomics
     if force_gather is True:
         if mode != ops.CONV_S1:
             pytest.skip("only 3x3 stride-1 has two kernels")
@@ -252,16 +249,23 @@ def test_conv_wgrad(case, dt, force_gather, monkeypatch):
     dw_ref = dw.clone()
     db = torch.zeros(Cw + 8, dtype=torch.float32, device=dev())
     db_ref = db.clone()
-    ops.conv_wgrad(x, dy, dw, g, dt, dbias=db)
+    ops.conv_wgrad(x, dy, dw, g, dt, dbias=db, workspace=ws)
     E.conv_wgrad(x, dy, dw_ref, g, dt, dbias=db_ref)
     torch.cuda.synchronize()
+    need = ops.conv_wgrad_workspace_bytes(g, dt)
+    assert 0 <= need <= ops.WORKSPACE_BYTES
     close(dw, dw_ref, dt, f"wgrad mode={mode}", tol=1e-4 if dt == F32 else 1e-2)
     close(db, db_ref, dt, f"wgrad bias mode={mode}", tol=1e-4 if dt == F32 else 1e-2)
     assert db[Cw:].abs().max().item() == 0.0
     assert dw[-64:].abs().max().item() == 0.0  # nothing written past the tensor
     # accumulation semantics: a second call adds
-    ops.conv_wgrad(x, dy, dw, g, dt)
+    ops.conv_wgrad(x, dy, dw, g, dt, workspace=ws)
     close(dw, 2 * dw_ref, dt, "wgrad accumulate", tol=1e-4 if dt == F32 else 1e-2)
+    if ws is not None and need > 0:  # a buffer smaller than the launch needs is not used: same result through atomics
+        small = torch.empty(max(need // 4 - 4, 4), dtype=torch.float32, device=dev())
+        dw2 = torch.zeros_like(dw)
+        ops.conv_wgrad(x, dy, dw2, g, dt, workspace=small)
+        close(dw2, dw_ref, dt, "wgrad with an undersized workspace", tol=1e-4 if dt == F32 else 1e-2)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
@@ -595,10 +599,7 @@ def test_wgrad_random_shapes_vs_restatement():
         dt = [F32, BF16][rs.randint(2)]
         if dt == BF16 and it % 2:
             dt = F16  # same byte layout, other matrix-core opcode and conversions
-        if rs.rand() < 0.5:
-            ops.ensure_workspace(dev())
-        else:
-            ops.drop_workspace()
+        ws = ops.new_workspace(dev()) if rs.rand() < 0.5 else None
         B = int(rs.randint(1, 4))
         Hin, Win = int(rs.choice([4, 8, 16, 24])), int(rs.choice([8, 16, 32]))
         if mode == ops.CONV_S2:
@@ -614,10 +615,9 @@ def test_wgrad_random_shapes_vs_restatement():
         dw = torch.zeros(Cw * taps * Cin, dtype=torch.float32, device=dev())
         db = torch.zeros(Cw, dtype=torch.float32, device=dev())
         dw_ref, db_ref = dw.clone(), db.clone()
-        ops.conv_wgrad(x, dy, dw, g, dt, dbias=db)
+        ops.conv_wgrad(x, dy, dw, g, dt, dbias=db, workspace=ws)
         E.conv_wgrad(x, dy, dw_ref, g, dt, dbias=db_ref)
         torch.cuda.synchronize()
         what = f"random wgrad #{it}: mode={mode} dt={dt} B={B} {Hin}x{Win} {Cin}->{Cw}/{ldy}"
         close(dw, dw_ref, dt, what, tol=1e-4 if dt == F32 else 1e-2)
         close(db, db_ref, dt, what + " bias", tol=1e-4 if dt == F32 else 1e-2)
-    ops.drop_workspace()

@@ -5,7 +5,7 @@ import torch
 from climate2weather_amd import ops
 dev = torch.device("cuda:0")
 B=128
-ops.ensure_workspace(dev)
+ws = ops.new_workspace(dev)
 SHAPES = [(ops.CONV_S1, 128, 128, 128), (ops.CONV_S1, 64, 128, 128), (ops.CONV_S1, 32, 256, 256), (ops.CONV_S1, 16, 384, 384), (ops.CONV_S1, 16, 512, 384),
           (ops.CONV_S1, 32, 384, 256), (ops.CONV_S1, 8, 512, 512), (ops.CONV_S2, 128, 128, 128), (ops.CONV_S2, 64, 128, 256), (ops.CONV_S2, 32, 256, 384),
           (ops.CONV_S2, 16, 384, 512), (ops.CONV_1X1, 8, 512, 1536), (ops.CONV_1X1, 8, 512, 512)]
@@ -16,7 +16,7 @@ for (mode, H, Cin, Cout) in SHAPES:
     taps = 1 if mode == ops.CONV_1X1 else 9
     dw = torch.zeros(Cout*taps*Cin, device=dev)
     gf = 2.0 * B * Ho * Ho * Cout * taps * Cin / 1e9
-    def fn(): ops.conv_wgrad(x, y, dw, g, ops.DTYPE_BF16)
+    def fn(): ops.conv_wgrad(x, y, dw, g, ops.DTYPE_BF16, workspace=ws)
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
