@@ -240,6 +240,8 @@ def cpu_baseline(C, size, cfg):
     for nt in sorted({n for n in (4, 8, 16, 32, 64, 128, ncpu) if n <= ncpu}):
         torch.set_num_threads(nt)
         sweep[nt] = round(B / timed(run_fwd, main, 1, 2), 2)
+        if sweep[nt] < 0.5 * max(sweep.values()):  # past the knee: more threads only oversubscribe this size (256 threads: 60 s per pass)
+            break
     best = max(sweep, key=sweep.get)
     torch.set_num_threads(best)
     legs = {}

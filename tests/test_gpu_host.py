@@ -271,7 +271,9 @@ def test_time_sharded_sampler_single_rank_and_local_guidance(golden_dir):
     mu, sigma = pipe._mu_sigma_f(0.7)
     ops.guidance(x, full, y, std, y.shape[0], Fv, H, H, 8, 2, mu, sigma, float(s["gamma"]))
     sf1 = TimeShardedScoreFunction(net, markov_order=1, length=L, batch_size=4, device=dev, noise_process=pipe, rank=1, world=2)
-    sf1.condition_on(A=PoolStrideOperator(8, 2), y=y, std=std, gamma=float(s["gamma"]))
+    sf1.condition_on(A=PoolStrideOperator(8, 2), y=y, std=torch.from_numpy(s["std"]).cuda(), gamma=float(s["gamma"]))  # (1, F, 1, 1)
+    with pytest.raises(NotImplementedError):  # a 1-D (F,) std would broadcast over the LAST axis in the reference: not per variable
+        sf1.condition_on(A=PoolStrideOperator(8, 2), y=y, std=std, gamma=float(s["gamma"]))
     lo, hi = sf1.bounds[1]
     part = eps[lo:hi].clone()
     sf1._apply_guidance(x[lo:hi].contiguous(), part, 0.7)
