@@ -38,8 +38,15 @@ constexpr int ABYTES = KPX * 256;        // dY tile
 constexpr int PPITCH = 24;               // patch row pitch (pixels); 18 used
 constexpr int NPIECE = 10 * 3;           // 1 KiB pieces per patch
 constexpr int PBYTES = NPIECE * 1024;    // 30,720
-constexpr int SLOT = ABYTES + PBYTES;    // 63,488
-constexpr int LDS_BYTES = 2 * SLOT;      // 126,976
+// LDS plan: THREE dY slots + TWO patch slots (159,744 of the CU's 163,840 bytes).  With one slot pair per operand the whole next K
+// tile (62 KB) is issued at the top of a tile's compute phase and must land within it -- measured, it does not: a tile's 144 MFMAs
+// per wave take ~2.5 us, 62 KB through one CU's LDS-DMA path ~3.3 us behind an HBM/L2 latency, and 40 % of the wave time sat in
+// the s_waitcnt + barrier of the next tile (profiles/r01q_pmc_wgrad_patch_b128.md).  The dY tile, the larger half, is therefore
+// fetched TWO tiles ahead (it has a whole extra compute phase to land) and only the 30 KB patch one tile ahead: the bytes a tile
+// boundary waits for are halved, and 62 KB stay in flight per CU at all times instead of draining to zero at every boundary.
+constexpr int NSLOT_A = 3, NSLOT_P = 2;
+constexpr int PBASE = NSLOT_A * ABYTES;                  // patch slots sit behind the dY slots
+constexpr int LDS_BYTES = PBASE + NSLOT_P * PBYTES;      // 159,744
 
 struct WpArgs {
     const void* dy;
@@ -126,17 +133,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     const size_t ximg = (size_t)H * W * p.Cin * ESZ;
     const size_t yimg = (size_t)H * W * p.ldy * ESZ;
 
-    auto issue = [&](int t, int slot) {
-        const int b = PAIR ? 2 * t : t / tpi, tt = PAIR ? 0 : t - (t / tpi) * tpi;  // PAIR: 8x8 images, one K tile per pair
+    // K tile t -> image b, tile origin (oh0, ow0)
+    auto tile_origin = [&](int t, int& b, int& oh0, int& ow0) {
+        b = PAIR ? 2 * t : t / tpi;  // PAIR: 8x8 images, one K tile per pair
+        const int tt = PAIR ? 0 : t - (t / tpi) * tpi;
         const int ty = tt / tw, tx = tt - ty * tw;
-        const int oh0 = ty << 3, ow0 = tx << 4;
+        oh0 = ty << 3;
+        ow0 = tx << 4;
+    };
+    auto issueA = [&](int t, int sa) {  // dY tile of K tile t -> dY slot sa: 4 x 1 KiB per wave
+        int b, oh0, ow0;
+        tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;  // a missing partner image reads as zeros (out of the descriptor's range)
         const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.dy + (size_t)b * yimg, (uint32_t)yimg * nimg);
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg * nimg);
-        char* const base = smem + slot * SLOT;
+        char* const base = smem + sa * ABYTES;
         const uint32_t aso = (uint32_t)((oh0 * W + ow0) * p.ldy) * ESZ;
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(ra, base + wid * 1024 + i * 8192, avo[i], aso);
+    };
+    auto issueP = [&](int t, int sp) {  // input halo patch of K tile t -> patch slot sp: 4 x 1 KiB per wave
+        int b, oh0, ow0;
+        tile_origin(t, b, oh0, ow0);
+        const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg * nimg);
+        char* const base = smem + PBASE + sp * PBYTES;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             uint32_t voff;
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && ppx[r] < 18;
                 voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + plc[r] : C2W_OOB;
             }
-            glds16(rx, base + ABYTES + pdst[r], voff, 0);
+            glds16(rx, base + pdst[r], voff, 0);
         }
     };
 
@@ -176,22 +196,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int pix = (r + t / 3) * PPITCH + c + t % 3 + (PAIR ? 2 * (lg & 1) : 0);
-                offB[t][h] = (uint32_t)(ABYTES + pix * 128 + (((uint32_t)(nt * 2 + (pp >> 1)) ^ swzP(pix)) << 4) + 8 * (pp & 1));
+                offB[t][h] = (uint32_t)(pix * 128 + (((uint32_t)(nt * 2 + (pp >> 1)) ^ swzP(pix)) << 4) + 8 * (pp & 1));
             }
         }
     }
 
-    if (t0 < t1) issue(t0, 0);
-    int slot = 0;
+    // Issue order per wave (vmcnt retires in it):  P(t0) A(t0) A(t0+1) | P(t0+1) A(t0+2) | P(t0+2) A(t0+3) | ...
+    // At the top of tile t the 4 youngest operations are the pieces of A(t+1) (if it exists): vmcnt(4) lets them fly on.
+    if (t0 < t1) {
+        issueP(t0, 0);
+        issueA(t0, 0);
+        if (t0 + 1 < t1) issueA(t0 + 1, 1);
+    }
+    int sa = 0, sp = 0;
     for (int t = t0; t < t1; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading the other slot
-        if ((C2W_EXP & 4) == 0 && t + 1 < t1) issue(t + 1, slot ^ 1);
-        const char* const S = smem + slot * SLOT;
+        if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading tile t - 1's slots
+        if ((C2W_EXP & 4) == 0) {
+            if (t + 1 < t1) issueP(t + 1, sp ^ 1);                       // patch slot of tile t - 1
+            if (t + 2 < t1) issueA(t + 2, sa == 0 ? 2 : sa - 1);         // dY slot of tile t - 1: (sa + 2) mod 3
+        }
+        const char* const SA = smem + sa * ABYTES;
+        const char* const SP = smem + PBASE + sp * PBYTES;
         if constexpr (BF) {
             typedef __attribute__((ext_vector_type(4))) short s16x4_t;
             typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-            auto tr8 = [&](uint32_t o0, uint32_t o1) {
+            auto tr8 = [&](const char* S, uint32_t o0, uint32_t o1) {
                 if constexpr ((C2W_EXP & 2) != 0) return (bf16x8_t){(short)o0, (short)o1, (short)t, 3, 4, 5, 6, 7};
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o0));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o1));
@@ -205,12 +236,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8_t a[MTW];
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) a[m] = tr8(offA[m][0] + ks * 32 * 256, offA[m][1] + ks * 32 * 256);
+                for (int m = 0; m < MTW; ++m) a[m] = tr8(SA, offA[m][0] + ks * 32 * 256, offA[m][1] + ks * 32 * 256);
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
                     bf16x8_t bfr;
                     if ((C2W_WPV & 1) != 0 && tp < 3 && ks > 0) bfr = keep[tp];
-                    else bfr = tr8(offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
+                    else bfr = tr8(SP, offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
                     if ((C2W_WPV & 1) != 0 && tp >= 6) keep[tp - 6] = bfr;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) {
@@ -231,18 +262,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 #pragma unroll 4
             for (int kk = 0; kk < 32; ++kk) {  // 4 pixels per MFMA: lane (i, g) feeds pixel 4*kk + g
                 const int row = kk * 4 + lg;
-                const float a = *(const float*)(S + row * 256 + ((((uint32_t)(mt0 * 4 + (li >> 2))) ^ swzA(row)) << 4) + (li & 3) * 4);
+                const float a = *(const float*)(SA + row * 256 + ((((uint32_t)(mt0 * 4 + (li >> 2))) ^ swzA(row)) << 4) + (li & 3) * 4);
                 const int r = kk >> 2, c = 4 * (kk & 3) + lg;
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
                     const int pix = (r + tp / 3) * PPITCH + c + tp % 3 + (PAIR && (kk & 2) ? 2 : 0);
-                    const float bv = *(const float*)(S + ABYTES + pix * 128 + ((((uint32_t)(nt * 4 + (li >> 2))) ^ swzP(pix)) << 4) + (li & 3) * 4);
+                    const float bv = *(const float*)(SP + pix * 128 + ((((uint32_t)(nt * 4 + (li >> 2))) ^ swzP(pix)) << 4) + (li & 3) * 4);
                     acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[tp][0], 0, 0, 0);
                 }
                 if (do_bias) accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb[0], 0, 0, 0);
             }
         }
-        slot ^= 1;
+        sa = sa == 2 ? 0 : sa + 1;
+        sp ^= 1;
     }
 
     // ---- epilogue: per tap, tile -> LDS [co][ci] fp32 -> atomics as whole (co, tap) rows of CIB floats

@@ -151,7 +151,8 @@ def test_full_size_net_fp32_vs_reference_fingerprint(golden_dir):
 
 
 # (loss rel, output slice, per-tensor |g|_2 and sum|g| rel, gradient slices) -- all "of the scale": max|a - b| / max|b| for tensors
-FULL_GRAD_TOL = {"fp32": (1e-5, 1e-4, 2e-4, 2e-4), "bf16": (1e-2, 3e-2, 3e-2, 6e-2), "fp16": (2e-3, 5e-3, 5e-3, 1.5e-2)}
+# Observed on MI355X (profiles/r02_full_grad_parity.txt): fp32 2e-7 / 2e-6 / 6e-7 / 2e-6; bf16 4e-5 / 1e-2 / 3e-3 / 1.2e-2; fp16 3e-6 / 1.4e-3 / 4e-4 / 2e-3
+FULL_GRAD_TOL = {"fp32": (2e-6, 1e-4, 2e-5, 2e-5), "bf16": (3e-4, 3e-2, 1e-2, 4e-2), "fp16": (3e-5, 5e-3, 2e-3, 8e-3)}
 
 
 @pytest.mark.parametrize("C", [52, 65])
