@@ -15,15 +15,17 @@
 //     workgroups, partial sums combined with fp32 atomics issued as full 256-B rows (staged through LDS per tap);
 //   * the bias gradient rides along as one extra MFMA per co-tile against a vector of ones.
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
+#include <utility>
 #include "conv_geom.h"
 
 #ifndef C2W_WPV
 #define C2W_WPV 0  // bit 0: patch fragments of the kh = 2 taps carried to the next K step (see the main loop): spills (252 + 12 VGPRs), off
 #endif
 #ifndef C2W_EXP
-#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA after the
-#endif             // first tile, 32 no epilogue
+#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 LDS-DMA after the first tile
+#endif             // reads out of range (issued, nothing fetched), 8 not issued at all, 32 no epilogue
 
 
 namespace {
@@ -59,6 +61,26 @@ struct WpArgs {
 };
 
 
+
+template <int N> struct IC { static constexpr int value = N; };
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+// f(IC<0>{}), ..., f(IC<N - 1>{}): loop indices that are constant expressions (asm immediates, register-array subscripts)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// one 16x32 (or 32x16) 16-bit MFMA operand = two transposing 8-byte LDS reads
+typedef __attribute__((ext_vector_type(2))) int tr_half;
+struct tr_frag {
+    tr_half lo, hi;
+    __device__ __forceinline__ bf16x8_t vec() const { return __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(4))) int){lo[0], lo[1], hi[0], hi[1]}); }
+};
+
+// ok ? v : (an offset that is always out of the descriptor's range) as a SELECT: written as a plain ternary over the address arithmetic
+// hipcc turns it into a branch around that arithmetic (s_and_saveexec + s_cbranch_execz), which cuts the MFMA stream of the main loop
+// into basic blocks; the empty asm makes v a value that exists on both paths.
+__device__ __forceinline__ uint32_t sel_oob(bool ok, uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return ok ? v : C2W_OOB;
+}
 
 __device__ __forceinline__ uint32_t swzA(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
 __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2)); }
@@ -96,79 +118,114 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     const int t0 = split * p.ktiles_per_split;
     const int t1 = (t0 + p.ktiles_per_split < p.ktiles) ? t0 + p.ktiles_per_split : p.ktiles;
 
-    // ---- dY staging slots (tile-relative): 128 rows x 16 chunks = 4 rounds
-    uint32_t avo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = tid + NTHREADS * i, row = s >> 4, pc = s & 15;
+    // ---- staging addresses.  Each wave moves 4 dY pieces and 4 patch pieces (1 KiB = 64 lanes x 16 B) per K tile.  The per-lane source
+    // offsets are recomputed from the lane number where a piece is issued (a dozen integer instructions between MFMAs) instead of
+    // being kept in 16 registers across the whole tile loop: the accumulators leave no room for them (the kernel spilled with them).
+    //   dY piece i: slot s = tid + 512 i -> row = s >> 4 (pixel of the tile), chunk = s & 15 (16-B chunk of the 256-B channel row);
+    //     the source-side swizzle of a row does not depend on i (rows 32 apart), so offset(i) = offset(0) + i * (two tile rows).
+    //   patch piece r: piece number pc = 8 r + wave (pieces past the end repeat the last one) -> patch row pc / 3, 8-pixel group pc % 3.
+    const size_t ximg = (size_t)H * W * p.Cin * ESZ;
+    const size_t yimg = (size_t)H * W * p.ldy * ESZ;
+    const uint32_t a_step = PAIR ? (uint32_t)(16 * p.ldy * ESZ) : (uint32_t)(2 * W * p.ldy * ESZ);  // bytes between dY pieces i and i + 1
+    auto dy_voff0 = [&](int tid_) -> uint32_t {
+        const int row = tid_ >> 4, pc = tid_ & 15;
         const uint32_t lc = (uint32_t)pc ^ swzA(row);
         const int c = co0 + (int)lc * (16 / ESZ);
         if constexpr (PAIR) {  // tile column >= 8: the same row of the next image
-            avo[i] = (c < p.Cout) ? (uint32_t)((((row >> 4) * 8 + (row & 7)) * p.ldy + c) * ESZ) + (uint32_t)((row >> 3) & 1) * (uint32_t)((size_t)H * W * p.ldy * ESZ)
-                                  : C2W_OOB;
+            return sel_oob(c < p.Cout, (uint32_t)((((row >> 4) * 8 + (row & 7)) * p.ldy + c) * ESZ) + (uint32_t)((row >> 3) & 1) * (uint32_t)yimg);
         } else {
-            avo[i] = (c < p.Cout) ? (uint32_t)((((row >> 4) * W + (row & 15)) * p.ldy + c) * ESZ) : C2W_OOB;
+            return sel_oob(c < p.Cout, (uint32_t)((((row >> 4) * W + (row & 15)) * p.ldy + c) * ESZ));
         }
-    }
-    // ---- patch pieces of this wave (4 rounds; pieces past the end repeat the last one)
-    int ppr[4], ppx[4], pdst[4];
-    uint32_t plc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int pc = r * 8 + wid;
-        pc = pc < NPIECE ? pc : NPIECE - 1;
+    };
+    auto patch_piece = [&](int r) -> int {  // wave-uniform
+        const int pc = r * 8 + wid;
+        return pc < NPIECE ? pc : NPIECE - 1;
+    };
+    auto patch_voff = [&](int r, int lane_, int oh0, int ow0) -> uint32_t {
+        const int pc = patch_piece(r);
         const int pr = pc / 3, pg = pc - pr * 3;
-        const int px = pg * 8 + (lane >> 3);
-        ppr[r] = pr;
-        ppx[r] = px;
-        pdst[r] = pc * 1024;
-        plc[r] = (uint32_t)(((lane & 7) ^ swzP(pr * PPITCH + px)) << 4) + (uint32_t)ci0 * ESZ;
-        if constexpr (PAIR) {  // 8x8 images: one K tile per image pair, so the whole source offset is tile-independent -> kept in plc[r]
+        const int px = pg * 8 + (lane_ >> 3);
+        const uint32_t lanepart = (uint32_t)(((lane_ & 7) ^ swzP(pr * PPITCH + px)) << 4) + (uint32_t)ci0 * ESZ;
+        if constexpr (PAIR) {  // 8x8 images, two per K tile, each with its own zero halo: patch columns 0..9 / 10..19
             const int pimg = px >= 10 ? 1 : 0;
             const int ih = pr - 1, iw = px - 1 - 10 * pimg;
             const bool ok = (unsigned)ih < 8u && (unsigned)iw < 8u && px < 20;
-            plc[r] = ok ? (uint32_t)((ih * 8 + iw) * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)(64 * p.Cin * ESZ) + plc[r] : C2W_OOB;
+            return sel_oob(ok, (uint32_t)((ih * 8 + iw) * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)(64 * p.Cin * ESZ) + lanepart);
+        } else {
+            const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+            return sel_oob(ok, (uint32_t)((ih * W + iw) * p.Cin) * ESZ + lanepart);
         }
-    }
-    const size_t ximg = (size_t)H * W * p.Cin * ESZ;
-    const size_t yimg = (size_t)H * W * p.ldy * ESZ;
+    };
 
     // K tile t -> image b, tile origin (oh0, ow0)
     auto tile_origin = [&](int t, int& b, int& oh0, int& ow0) {
         b = PAIR ? 2 * t : t / tpi;  // PAIR: 8x8 images, one K tile per pair
         const int tt = PAIR ? 0 : t - (t / tpi) * tpi;
         const int ty = tt / tw, tx = tt - ty * tw;
-        oh0 = ty << 3;
-        ow0 = tx << 4;
+        // integer division runs on the vector ALU: without the readfirstlane the quotients -- and every descriptor / offset derived from
+        // them, live across the whole tile -- stay in vector registers
+        b = __builtin_amdgcn_readfirstlane(b);
+        oh0 = __builtin_amdgcn_readfirstlane(ty << 3);
+        ow0 = __builtin_amdgcn_readfirstlane(tx << 4);
     };
-    auto issueA = [&](int t, int sa) {  // dY tile of K tile t -> dY slot sa: 4 x 1 KiB per wave
+    // LDS-DMA of one K tile = 4 patch pieces + 4 dY pieces (1 KiB each) per wave.  The descriptors and the tile origin are set up
+    // once per tile (TileSrc), the pieces are issued one at a time: inside the MFMA stream of the tile being computed (see the main
+    // loop), not as a burst behind the barrier -- a piece holds the issuing wave's instruction stream for 60-185 cycles, and eight of
+    // them back to back on all eight waves at once left the CU's matrix pipes empty for >1000 cycles per K tile.
+    struct TileSrc {
+        __amdgpu_buffer_rsrc_t rsrc;
+        int oh0, ow0;
+        uint32_t aso;
+        char* base;
+    };
+    auto srcA = [&](int t, int sa) {  // dY tile of K tile t -> dY slot sa
         int b, oh0, ow0;
         tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;  // a missing partner image reads as zeros (out of the descriptor's range)
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.dy + (size_t)b * yimg, (uint32_t)yimg * nimg);
-        char* const base = smem + sa * ABYTES;
-        const uint32_t aso = (uint32_t)((oh0 * W + ow0) * p.ldy) * ESZ;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(ra, base + wid * 1024 + i * 8192, avo[i], aso);
+        TileSrc s;
+        s.rsrc = make_rsrc((const char*)p.dy + (size_t)b * yimg, (uint32_t)yimg * nimg);
+        s.oh0 = oh0;
+        s.ow0 = ow0;
+        s.aso = (uint32_t)((oh0 * W + ow0) * p.ldy) * ESZ;
+        s.base = smem + sa * ABYTES + wid * 1024;
+        return s;
     };
-    auto issueP = [&](int t, int sp) {  // input halo patch of K tile t -> patch slot sp: 4 x 1 KiB per wave
+    auto srcP = [&](int t, int sp) {  // input halo patch of K tile t -> patch slot sp
         int b, oh0, ow0;
         tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg * nimg);
-        char* const base = smem + PBASE + sp * PBYTES;
+        TileSrc s;
+        s.rsrc = make_rsrc((const char*)p.x + (size_t)b * ximg, (uint32_t)ximg * nimg);
+        s.oh0 = oh0;
+        s.ow0 = ow0;
+        s.aso = 0;
+        s.base = smem + PBASE + sp * PBYTES;
+        return s;
+    };
+    // ``live`` false (no such tile: the tail of the split): the piece is still issued -- branch-free loop body, constant vmcnt
+    // bookkeeping -- but reads out of range, i.e. writes zeros into a slot nobody reads again.
+    auto pieceA = [&](const TileSrc& s, int i, bool live = true) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));  // recompute here (see "staging addresses")
+        const uint32_t v = dy_voff0(tid_);
+        glds16(s.rsrc, s.base + i * 8192, sel_oob(live, v), s.aso + (uint32_t)i * a_step);
+    };
+    auto pieceP = [&](const TileSrc& s, int r, bool live = true) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const uint32_t v = patch_voff(r, lane_, s.oh0, s.ow0);
+        glds16(s.rsrc, s.base + patch_piece(r) * 1024, sel_oob(live, v), 0);
+    };
+    auto issueA = [&](int t, int sa) {
+        const TileSrc s = srcA(t, sa);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uint32_t voff;
-            if constexpr (PAIR) {
-                voff = plc[r];
-            } else {
-                const int ih = oh0 - 1 + ppr[r], iw = ow0 - 1 + ppx[r];
-                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && ppx[r] < 18;
-                voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + plc[r] : C2W_OOB;
-            }
-            glds16(rx, base + pdst[r], voff, 0);
-        }
+        for (int i = 0; i < 4; ++i) pieceA(s, i);
+    };
+    auto issueP = [&](int t, int sp) {
+        const TileSrc s = srcP(t, sp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pieceP(s, r);
     };
 
     f32x4_t acc[9][MTW];
@@ -206,58 +263,95 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     if (t0 < t1) {
         issueP(t0, 0);
         issueA(t0, 0);
-        if (t0 + 1 < t1) issueA(t0 + 1, 1);
+        const TileSrc s1 = srcA(t0 + 1 < t1 ? t0 + 1 : t0, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pieceA(s1, i, t0 + 1 < t1);
     }
     int sa = 0, sp = 0;
     for (int t = t0; t < t1; ++t) {
-        if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the 4 youngest = the dY pieces of tile t + 1 (real or out of range)
         __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading tile t - 1's slots
-        if ((C2W_EXP & 4) == 0) {
-            if (t + 1 < t1) issueP(t + 1, sp ^ 1);                       // patch slot of tile t - 1
-            if (t + 2 < t1) issueA(t + 2, sa == 0 ? 2 : sa - 1);         // dY slot of tile t - 1: (sa + 2) mod 3
+        // next patch -> the patch slot of tile t - 1; the dY tile after next -> the dY slot of tile t - 1 = (sa + 2) mod 3
+        const bool hasP = (C2W_EXP & 4) == 0 && t + 1 < t1, hasA = (C2W_EXP & 4) == 0 && t + 2 < t1;
+        const TileSrc nP = srcP(hasP ? t + 1 : t, sp ^ 1), nA = srcA(hasA ? t + 2 : t, sa == 0 ? 2 : sa - 1);
+        if constexpr (!BF || (C2W_WPV & 2) != 0) {  // burst behind the barrier (fp32 path; diagnostic A/B for the 16-bit path)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pieceP(nP, r, hasP);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pieceA(nA, i, hasA);
         }
         const char* const SA = smem + sa * ABYTES;
         const char* const SP = smem + PBASE + sp * PBYTES;
         if constexpr (BF) {
-            typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-            auto tr8 = [&](const char* S, uint32_t o0, uint32_t o1) {
-                if constexpr ((C2W_EXP & 2) != 0) return (bf16x8_t){(short)o0, (short)o1, (short)t, 3, 4, 5, 6, 7};
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o0));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(S + o1));
-                return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            // Fragment reads are INLINE ASM.  Through the ds_read_tr16_b64 builtin hipcc (ROCm 7.2) places "s_waitcnt vmcnt(0)" in
+            // front of the first LDS read that follows an LDS-DMA issue (the read might alias the DMA's destination), i.e. the next
+            // tile's loads were waited for before the current tile's first MFMA: the round-1 kernel never overlapped its loads with
+            // its arithmetic (its 40 % "parked" wave time).  The asm reads are invisible to that pass; what orders them is what the
+            // hardware needs and nothing more: the counted vmcnt + barrier at the tile boundary (the data landed), and the counted
+            // lgkmcnt below (LDS returns in order) with a sched_barrier behind it (hipcc moves MFMAs across an asm wait otherwise).
+            const uint32_t sA = (uint32_t)(uintptr_t)SA, sP = (uint32_t)(uintptr_t)SP;
+            auto rd = [&](tr_frag& f, uint32_t base, uint32_t o0, uint32_t o1, auto IMMc) {
+                constexpr int IMM = decltype(IMMc)::value;
+                if constexpr ((C2W_EXP & 2) != 0) {
+                    f.lo = (tr_half){(int)o0, (int)base};
+                    f.hi = (tr_half){(int)o1, IMM};
+                } else {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(base + o0), "n"(IMM));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(base + o1), "n"(IMM));
+                }
             };
-            // A K step covers two pixel rows, so the patch fragment of tap (kh = 2, kw) at step ks is the fragment of tap (kh = 0, kw)
-            // at step ks + 1 (same LDS addresses: the swizzle ignores the bits 2 * PPITCH pixels change): with C2W_WPV & 1 it is kept in
-            // registers -- 27 patch fragments per K tile instead of 36.  Not enabled: the kernel sits at 252 VGPRs and the 12 more spill.
-            bf16x8_t keep[3];
+            static_for<4>([&](auto KSc) {
+                constexpr int ks = decltype(KSc)::value;
+                if constexpr ((C2W_WPV & 2) == 0 && (C2W_EXP & 8) == 0) {
+                    // The next tiles' LDS-DMA, four pieces at a time at K-step boundaries (fragment registers are dead there), and
+                    // never on both waves of a SIMD at once (waves w and w + 4 share one): a piece holds the issuing wave's
+                    // instruction stream for 60-185 cycles; while one wave of the pair is held its partner has the matrix pipe to
+                    // itself.  Patch pieces (waited for at the next tile boundary) first, dY pieces (a tile of slack more) later.
+                    const bool first = wid < 4;
+                    if ((ks == 0 && first) || (ks == 1 && !first)) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8_t a[MTW];
+                        for (int r = 0; r < 4; ++r) pieceP(nP, r, hasP);
+                    }
+                    if ((ks == 2 && first) || (ks == 3 && !first)) {
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) a[m] = tr8(SA, offA[m][0] + ks * 32 * 256, offA[m][1] + ks * 32 * 256);
+                        for (int i = 0; i < 4; ++i) pieceA(nA, i, hasA);
+                    }
+                }
+                constexpr int PF = (C2W_WPV & 4) != 0 ? 1 : 2;  // patch fragments are read PF taps ahead of their MFMAs
+                tr_frag a[MTW], bq[PF + 1];
 #pragma unroll
-                for (int tp = 0; tp < 9; ++tp) {
-                    bf16x8_t bfr;
-                    if ((C2W_WPV & 1) != 0 && tp < 3 && ks > 0) bfr = keep[tp];
-                    else bfr = tr8(SP, offB[tp][0] + ks * 2 * PPITCH * 128, offB[tp][1] + ks * 2 * PPITCH * 128);
-                    if ((C2W_WPV & 1) != 0 && tp >= 6) keep[tp - 6] = bfr;
+                for (int m = 0; m < MTW; ++m) rd(a[m], sA, offA[m][0], offA[m][1], IC<ks * 32 * 256>{});
+                static_for<PF>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    rd(bq[j], sP, offB[j][0], offB[j][1], IC<ks * 2 * PPITCH * 128>{});
+                });
+                static_for<9>([&](auto TPc) {
+                    constexpr int tp = decltype(TPc)::value;
+                    if constexpr (tp + PF < 9) rd(bq[(tp + PF) % (PF + 1)], sP, offB[tp + PF][0], offB[tp + PF][1], IC<ks * 2 * PPITCH * 128>{});
+                    constexpr int AHEAD = (tp + PF < 9 ? PF : 8 - tp) * 2;  // reads younger than tap tp's: they may stay in flight
+                    if constexpr ((C2W_EXP & 2) == 0) {
+                        if constexpr (AHEAD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        else if constexpr (AHEAD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8_t bfr = bq[tp % (PF + 1)].vec();
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) {
                         if constexpr ((C2W_EXP & 1) == 0) {
-                            acc[tp][m] = mfma16s<T>(a[m], bfr, acc[tp][m]);
+                            acc[tp][m] = mfma16s<T>(a[m].vec(), bfr, acc[tp][m]);
                         } else {
-                            asm volatile("" ::"v"(a[m]), "v"(bfr));
+                            asm volatile("" ::"v"(a[m].vec()), "v"(bfr));
                         }
                     }
-                }
-                if (do_bias) {
-                    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
+                    if (tp == 8 && do_bias) {
+                        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) accb[m] = mfma16s<T>(a[m], ones, accb[m]);
-                }
-            }
+                        for (int m = 0; m < MTW; ++m) accb[m] = mfma16s<T>(a[m].vec(), ones, accb[m]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // the next reads overwrite fragment registers: not before these MFMAs are issued
+                });
+            });
         } else {
 #pragma unroll 4
             for (int kk = 0; kk < 32; ++kk) {  // 4 pixels per MFMA: lane (i, g) feeds pixel 4*kk + g
