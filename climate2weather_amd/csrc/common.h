@@ -5,6 +5,7 @@
 // training in it needs the loss scale of c2w_grad_scaler_*); all arithmetic outside
 // the MFMA operands is fp32.
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -154,6 +155,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+template <int N> struct IC { static constexpr int value = N; };
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+// f(IC<0>{}), ..., f(IC<N - 1>{}): loop indices that are constant expressions (asm immediates, register-array subscripts)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// one 16x32 (or 32x16) 16-bit MFMA operand = two transposing 8-byte LDS reads
+typedef __attribute__((ext_vector_type(2))) int tr_half;
+struct tr_frag {
+    tr_half lo, hi;
+    __device__ __forceinline__ bf16x8_t vec() const { return __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(4))) int){lo[0], lo[1], hi[0], hi[1]}); }
+};
 
 #define HIP_CHECK_RET(expr)                 \
     do {                                    \

@@ -12,6 +12,7 @@
 // x 64 pixels per stage; 8 waves = 2 (M) x 4 (N: one column block each).  Split-K over pixel ranges across
 // workgroups; partial tiles are combined with fp32 global atomics issued as 256-B contiguous wave instructions
 // (tile staged through LDS first).  dW must be zero-initialised (or hold the value to accumulate onto).
+#include <cstdint>
 #include <cstdlib>
 
 #include "conv_geom.h"
@@ -186,33 +187,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
         const char* const Ab = Abuf + buf * ABYTES;
         const char* const Bb = Bbuf + buf * BBYTES;
         if constexpr (ESZ == 2) {
-            typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+            // Fragment reads in inline asm with counted lgkmcnt waits (see wgrad_patch.hip: through the ds_read_tr16_b64 builtin hipcc
+            // waits vmcnt(0) -- for the stages just issued -- in front of the first read of every stage, and the loads never overlap
+            // the MFMAs).
+            const uint32_t sA = (uint32_t)(uintptr_t)Ab, sB = (uint32_t)(uintptr_t)Bb;
+            auto rd = [&](tr_frag& f, uint32_t base, uint32_t o0, uint32_t o1, auto IMMc) {
+                constexpr int IMM = decltype(IMMc)::value;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(base + o0), "n"(IMM));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(base + o1), "n"(IMM));
+            };
+            static_for<2>([&](auto KSc) {
+                constexpr int ks = decltype(KSc)::value;
+                tr_frag a[MT], b[NTL];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t a[MT], b[NTL];
+                for (int m = 0; m < MT; ++m) rd(a[m], sA, offA[m][0], offA[m][1], IC<ks * 32 * 256>{});
+                rd(b[0], sB, offB[0][0], offB[0][1], IC<ks * 32 * 512>{});
+                rd(b[1], sB, offB[1][0], offB[1][1], IC<ks * 32 * 512>{});
+                static_for<NTL>([&](auto Nc) {
+                    constexpr int n = decltype(Nc)::value;
+                    if constexpr (n + 2 < NTL) rd(b[n + 2], sB, offB[n + 2][0], offB[n + 2][1], IC<ks * 32 * 512>{});
+                    constexpr int AHEAD = 2 * ((n + 2 < NTL ? n + 2 : NTL - 1) - n);  // reads younger than b[n]'s
+                    if constexpr (AHEAD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else if constexpr (AHEAD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8_t bv = b[n].vec();
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ab + offA[m][0] + ks * 32 * 256));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ab + offA[m][1] + ks * 32 * 256));
-                    a[m] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
+                    for (int m = 0; m < MT; ++m) acc[m][n] = mfma16s<T>(a[m].vec(), bv, acc[m][n]);
+                    if (n == NTL - 1 && do_bias) {
+                        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
 #pragma unroll
-                for (int n = 0; n < NTL; ++n) {
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bb + offB[n][0] + ks * 32 * 512));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bb + offB[n][1] + ks * 32 * 512));
-                    b[n] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NTL; ++n) acc[m][n] = mfma16s<T>(a[m], b[n], acc[m][n]);
-                if (do_bias) {
-                    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) accb[m] = mfma16s<T>(a[m], ones, accb[m]);
-                }
-            }
+                        for (int m = 0; m < MT; ++m) accb[m] = mfma16s<T>(a[m].vec(), ones, accb[m]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
         } else {
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {  // 4 pixels per MFMA: lane (i,g) feeds k = 4*kk + g

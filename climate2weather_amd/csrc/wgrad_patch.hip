@@ -62,18 +62,6 @@ struct WpArgs {
 
 
 
-template <int N> struct IC { static constexpr int value = N; };
-template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
-// f(IC<0>{}), ..., f(IC<N - 1>{}): loop indices that are constant expressions (asm immediates, register-array subscripts)
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// one 16x32 (or 32x16) 16-bit MFMA operand = two transposing 8-byte LDS reads
-typedef __attribute__((ext_vector_type(2))) int tr_half;
-struct tr_frag {
-    tr_half lo, hi;
-    __device__ __forceinline__ bf16x8_t vec() const { return __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(4))) int){lo[0], lo[1], hi[0], hi[1]}); }
-};
-
 // ok ? v : (an offset that is always out of the descriptor's range) as a SELECT: written as a plain ternary over the address arithmetic
 // hipcc turns it into a branch around that arithmetic (s_and_saveexec + s_cbranch_execz), which cuts the MFMA stream of the main loop
 // into basic blocks; the empty asm makes v a value that exists on both paths.
