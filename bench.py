@@ -133,13 +133,13 @@ class LaunchTimer:
             e1.record()
             self.events.append((rec, kind, g, e0, e1))
 
-        def conv_wgrad(x, dy, dw, g, dtype, dbias=None):
+        def conv_wgrad(x, dy, dw, g, dtype, **kw):
             rec = self.gw.get(dw.data_ptr()) if self.mode == "all" else None
             if rec is None:
-                return self._wgrad(x, dy, dw, g, dtype, dbias=dbias)
+                return self._wgrad(x, dy, dw, g, dtype, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._wgrad(x, dy, dw, g, dtype, dbias=dbias)
+            self._wgrad(x, dy, dw, g, dtype, **kw)
             e1.record()
             self.events.append((rec, "wgrad", g, e0, e1))
         self.ops.conv, self.ops.conv_wgrad = conv, conv_wgrad
