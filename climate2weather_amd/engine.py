@@ -423,7 +423,8 @@ class Engine:
                     # matrix as the input and gy^T as the output gradient -- which splits the reduction over the whole chip.
                     ld = (rows + 3) // 4 * 4
                     gyT = torch.zeros((rec.rows, ld), dtype=torch.float32, device=x.device)
-                    gyT[:, :rows] = gy.reshape(-1)[: rows * rec.rows].view(rows, rec.rows).t()
+                    # LDS-tiled transpose (torch's strided copy of the 128 x 8448 matrix took 0.49 ms per step)
+                    ops.weight_transpose(gy, gyT, rows, 1, rec.rows, rec.rows, ld, False, DTYPE_F32)
                     dx = torch.zeros((rows, rec.cin), dtype=torch.float32, device=x.device)
                     gt = self._geom(rec.rows, 1, 1, rec.cin, 1, 1, rows, ld, rows, CONV_1X1)
                     # same kernels, same split-K workspace as the weight gradients: same stream, then wait for the result
