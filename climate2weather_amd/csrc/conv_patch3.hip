@@ -33,28 +33,41 @@
 #ifndef C2W_T3V
 #define C2W_T3V 10  // stage order / LDS-DMA placement / bias placement of conv_patch_t3_kernel (bits: see `stage` below); 10 = measured best
 #endif
+#ifndef C2W_T3_STAGGER
+#define C2W_T3_STAGGER 0  // x 8128 cycles: start delay of the second workgroup of every CU (see the kernel entry)
+#endif
 #ifndef C2W_EXP
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA
 #endif             // in the loop, 32 no epilogue (accumulators reduced to one store per lane)
 
 namespace {
 
-constexpr int T3_NTHR = 256;
+#ifndef C2W_T3_NW
+#define C2W_T3_NW 4  // waves per workgroup of the 16x16-tile kernel: 4 (wave tile 64 co x 128 px, 2 waves per SIMD) or 8 (64 co x 64 px, 4 per SIMD)
+#endif
 constexpr int T3_PW = 20;                     // patch row pitch in pixels (18 used)
 constexpr int T3_WBYTES = 128 * 64;           // one stage of weights: 128 co x 32 ci
 constexpr int T3_OS = 128 * 2 + 16;           // epilogue row stride
 
 // TR = tile rows: 8 -> 8x16 pixels, three workgroups per CU; 16 -> 16x16 pixels (wave tile 64 co x 128 px), two per CU and
 // half the weight bytes streamed per output pixel.
-template <int TR> struct T3Cfg {
+// NW = waves per workgroup: 2 (output-channel halves) x NW / 2 (pixel-row groups).  NW = 8 on the 16x16 tile: sixteen waves per CU,
+// four per SIMD, 128 registers each -- while one of the CU's two workgroups is in its HBM-bound epilogue / next prologue the other
+// still has TWO waves on every SIMD to keep the matrix pipe fed (one wave alone issues its LDS-DMA, its fragment reads and its
+// barrier waits into the pipe's idle time: ~56 % busy; ablations in profiles/r02_experiments.md).
+template <int TR, int NW = 4> struct T3Cfg {
+    static constexpr int NTHR = 64 * NW;
     static constexpr int NPIECE = ((TR + 2) * T3_PW + 7) / 8;  // 1 KiB LDS-DMA pieces of 8 pixels: 25 / 45
     static constexpr int PBYTES = NPIECE * 1024;               // 25,600 / 46,080
-    static constexpr int ROUNDS = (NPIECE + 3) / 4;            // pieces per wave: 7 / 12
-    static constexpr int NB = TR / 8;                          // 64-pixel blocks per wave
+    static constexpr int ROUNDS = (NPIECE + NW - 1) / NW;      // patch pieces per wave
+    static constexpr int WPIECES = 8 / NW;                     // weight pieces per wave per stage (8 KiB per stage)
+    static constexpr int NB = TR / (2 * NW);                   // 64-pixel blocks (4 tile rows) per wave
+    static constexpr int NPASS = TR / 8;                       // epilogue passes of 128 tile pixels
     static constexpr int LDS_LOOP = PBYTES + 3 * T3_WBYTES;    // 50,176 / 70,656
     static constexpr int LDS_EPI = TR * 16 * T3_OS + 512;      // output tile + LayerNorm column sums
     static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
-    static constexpr int WAVES_PER_SIMD = TR == 8 ? 3 : 2;
+    static constexpr int WAVES_PER_SIMD = NW == 8 ? 4 : (TR == 8 ? 3 : 2);
+    static_assert(NB >= 1 && 8 % NW == 0, "wave tiling");
 };
 
 template <int N> struct IC3 { static constexpr int value = N; };
@@ -67,21 +80,32 @@ template <int N> struct IC3 { static constexpr int value = N; };
 __device__ __forceinline__ uint32_t t3_pswz(int col) { return (uint32_t)(col & 7); }
 __device__ __forceinline__ uint32_t t3_wswz(int row) { return (uint32_t)((4 - ((row >> 2) & 3)) & 3); }
 
-__device__ __forceinline__ void t3_wait(int outstanding) {
-    if (outstanding >= 2) {
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+// all but the wave's `WPIECES` youngest loads (the next stage's weight pieces) have landed; `more` false: everything
+template <int WPIECES> __device__ __forceinline__ void t3_wait(bool more) {
+    if (more) {
+        if constexpr (WPIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
-template <int TR, typename T = bf16_t>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
-__global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch_t3_kernel(const C2wConvArgs p) {
+template <int TR, typename T = bf16_t, int NW = 4>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
+__global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv_patch_t3_kernel(const C2wConvArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
-    typedef T3Cfg<TR> CF;
+    typedef T3Cfg<TR, NW> CF;
+    constexpr int T3_NTHR = CF::NTHR;
     constexpr int ESZ = 2;
     constexpr int NB = CF::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [patch | W0 | W1 | W2]
+#if C2W_T3_STAGGER
+    // Two workgroups share a CU.  Dispatched together they run in phase -- both in their MFMA loops, then both in their HBM-bound
+    // epilogue / next prologue -- and neither phase covers the other.  The second workgroup of every CU (the second batch of 256 in
+    // dispatch order) starts a fraction of a tile period late; every later workgroup inherits the phase of the slot it takes over.
+    if (TR == 16 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < C2W_T3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,24 +135,26 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
     // of living in VGPRs through the loop: anything spilled would come back through scratch loads, which return out of order
     // with the LDS-DMA loads and break the counted vmcnt waits below (seen: wrong weight rows with 40 spilled registers).
     auto issue_patch = [&](int chunk) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));  // keeps the chunk-invariant part of the offsets from being hoisted out of the chunk loop (and spilled)
 #pragma unroll
         for (int r = 0; r < CF::ROUNDS; ++r) {
-            int pc = r * 4 + wid;
+            int pc = r * NW + wid;
             pc = pc < CF::NPIECE ? pc : CF::NPIECE - 1;
-            const int f = pc * 8 + (lane >> 3);  // flattened patch pixel
+            const int f = pc * 8 + (lane_ >> 3);  // flattened patch pixel
             const int pr = f / T3_PW, px = f - pr * T3_PW;
             const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
             const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18 && pr < TR + 2;
-            const uint32_t cg = (uint32_t)(lane & 7) ^ t3_pswz(px);
+            const uint32_t cg = (uint32_t)(lane_ & 7) ^ t3_pswz(px);
             const uint32_t voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (cg << 4) : C2W_OOB;
             glds16(rx, smem + pc * 1024, voff, (uint32_t)chunk * 128u);
         }
     };
     // weight stage: 128 rows x 4 slots of 16 B = 2 rounds; lane -> row = (round * 4 + wave) * 16 + lane / 4, slot = lane & 3
-    uint32_t wvo[2];
+    uint32_t wvo[CF::WPIECES];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * 4 + wid) * 16 + (lane >> 2);
+    for (int i = 0; i < CF::WPIECES; ++i) {
+        const int row = (i * NW + wid) * 16 + (lane >> 2);
         const uint32_t cg = (uint32_t)(lane & 3) ^ t3_wswz(row);
         wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (cg << 4);
     }
@@ -138,7 +164,7 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
         }
         const uint32_t so = (uint32_t)(tap * p.Cin + chunk * 64 + half * 32) * ESZ;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(rw, smem + CF::PBYTES + wslot * T3_WBYTES + (i * 4 + wid) * 1024, wvo[i], so);
+        for (int i = 0; i < CF::WPIECES; ++i) glds16(rw, smem + CF::PBYTES + wslot * T3_WBYTES + (i * NW + wid) * 1024, wvo[i], so);
     };
 
     // fragment read offsets.  A: row = wm*64 + m*16 + li, its swizzle depends on (row >> 2) & 3 = (li >> 2) & 3 only, not on m, so
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
             constexpr int T2 = KWM ? (I2 % 3) * 3 + (I2 % 9) / 3 : I2 / 2;
             issue_w(IDX + 2 < 18 ? c : c + 1, T2, H2, I2 % 3);
         };
-        t3_wait(s + 1 < NS ? 2 : 0);  // everything but the next stage's two weight pieces has landed
+        t3_wait<CF::WPIECES>(s + 1 < NS);  // everything but the next stage's weight pieces has landed
         __builtin_amdgcn_s_barrier();
         bool ahead = s + 2 < NS;
         if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
@@ -287,38 +313,42 @@ __global__ __launch_bounds__(T3_NTHR, T3Cfg<TR>::WAVES_PER_SIMD) void conv_patch
     // epilogue: the residual / multiplier rows are fetched AFTER the accumulators have left the registers (the half-tile
     // kernel prefetches them next to live accumulators; that does not fit here) -- the co-resident workgroups cover the
     // exposed latency.  Output rows go through LDS in blocks of 128 (= 8 tile rows), one EpiStore pass each.
-    if constexpr (TR == 8 || (C2W_T3V & 8) != 0) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    // the epilogue's lane coordinates are derived afresh: kept across the loop they cost a register the 128-register variant does not have
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, li_e = lane_e & 15, lg_e = lane_e >> 4;
+    if constexpr (TR == 8 || (C2W_T3V & 8) != 0) epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bv);
     __syncthreads();
     char* const O = smem;
     float* const red = (float*)(smem + TR * 16 * T3_OS);
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-        epi_acc_to_lds<T>(O, T3_OS, acc[j], bv, p.act, wm * 64, (wn * NB + j) * 64, li, lg);
+        epi_acc_to_lds<T>(O, T3_OS, acc[j], bv, p.act, wm * 64, (wn * NB + j) * 64, li_e, lg_e);
 #pragma unroll
-    for (int h = 0; h < NB; ++h) {
-        if (p.ln_x != nullptr && tid < 128) red[tid] = 0.f;
+    for (int h = 0; h < CF::NPASS; ++h) {
+        if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
         EpiStore<T, 128, T3_NTHR> est;
-        est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0 + 8 * h) * W + ow0, W);
+        est.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8 * h) * W + ow0, W);
         __syncthreads();
         const char* const Oh = O + h * 128 * T3_OS;
-        if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid, b, red);
-        else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid, b);
-        else est.finish(p, Oh, T3_OS, tid);
-        if (h + 1 < NB) __syncthreads();  // the LayerNorm column sums are re-zeroed for the next block only after everyone read them
+        if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
+        else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+        else est.finish(p, Oh, T3_OS, tid_e);
+        if (h + 1 < CF::NPASS) __syncthreads();  // the LayerNorm column sums are re-zeroed for the next block only after everyone read them
     }
 }
 
-template <int TR, typename T>
+template <int TR, typename T, int NW>
 int t3_launch(const C2wConvArgs& a, hipStream_t st) {
-    typedef T3Cfg<TR> CF;
+    typedef T3Cfg<TR, NW> CF;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr = true;
     }
     const int nN = (a.Cout + 127) / 128;
     const int nM = a.B * (a.Hin / TR) * (a.Win >> 4);
-    conv_patch_t3_kernel<TR, T><<<nM * nN, T3_NTHR, CF::LDS, st>>>(a);
+    conv_patch_t3_kernel<TR, T, NW><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -336,5 +366,5 @@ bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype) {
 }
 
 int c2w_conv_patch3(const C2wConvArgs& a, int dtype, hipStream_t st) {
-    return dtype == C2W_DTYPE_F16 ? t3_launch<16, f16_t>(a, st) : t3_launch<16, bf16_t>(a, st);
+    return dtype == C2W_DTYPE_F16 ? t3_launch<16, f16_t, C2W_T3_NW>(a, st) : t3_launch<16, bf16_t, C2W_T3_NW>(a, st);
 }

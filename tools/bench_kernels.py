@@ -19,6 +19,7 @@ p.add_argument("--act", type=int, default=1)
 p.add_argument("--epilogues", action="store_true", help="time the conv with each fused epilogue variant")
 a = p.parse_args()
 dev = torch.device("cuda:0")
+WS = ops.new_workspace(dev)  # split-K scratch of the weight-gradient launches (as the engine hands it over)
 
 
 def timeit(fn, iters):
@@ -66,7 +67,7 @@ for dname in a.dtypes.split(","):
                   ms = timeit(lambda: ops.conv(x, w, None, y, g, dt, **kw), a.iters)
                   print(f"   epilogue {name:8s}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
         if "wgrad" in a.kind:
-          ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt), a.iters)
+          ms = timeit(lambda: ops.conv_wgrad(x, y, dw, g, dt, workspace=WS), a.iters)
           print(f"wgrad  {dname} mode={mode} B={B} H={H} {Cin}->{Cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
     if "ln" not in a.kind:
         continue
