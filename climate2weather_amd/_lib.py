@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("C2W_LIB") or os.path.join(HERE, "libc2w_hip.so")  # C
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
-ACT_NONE, ACT_SILU, ACT_SILU_PAIR = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
 
 

@@ -26,7 +26,7 @@ __device__ __forceinline__ void epi_load_bias(const C2wConvArgs& p, int co_base,
 // one wave's 64 (co) x 64 (pixel) accumulator tile -> LDS rows; row0 = first pixel row of the wave inside O.
 // SILU is a template parameter: with a run-time `act` the compiler evaluated the 64 exp/rcp pairs per lane for every
 // conv and selected afterwards (stamps: 3.3k of a 27k-cycle tile, whether or not the activation was requested).
-template <typename T, bool SILU>
+template <typename T, int ACTK>  // 0 none, 1 SiLU, 2 ReLU
 __device__ __forceinline__ void epi_acc_to_lds_impl(char* O, int OS, const f32x4_t (&acc)[4][4], const float (&bv)[4][4], int col0, int row0,
                                                     int li, int lg) {
 #pragma unroll
@@ -39,7 +39,8 @@ __device__ __forceinline__ void epi_acc_to_lds_impl(char* O, int OS, const f32x4
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[m][n][r] + bv[m][r];
-                if constexpr (SILU) v[r] = silu_f(v[r]);
+                if constexpr (ACTK == 1) v[r] = silu_f(v[r]);
+                if constexpr (ACTK == 2) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (sizeof(T) == 4) {
                 *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -54,9 +55,11 @@ template <typename T>
 __device__ __forceinline__ void epi_acc_to_lds(char* O, int OS, const f32x4_t (&acc)[4][4], const float (&bv)[4][4], int act, int col0, int row0,
                                                int li, int lg) {
     if (act == C2W_ACT_SILU) {  // wave-uniform branch
-        epi_acc_to_lds_impl<T, true>(O, OS, acc, bv, col0, row0, li, lg);
+        epi_acc_to_lds_impl<T, 1>(O, OS, acc, bv, col0, row0, li, lg);
+    } else if (act == C2W_ACT_RELU) {
+        epi_acc_to_lds_impl<T, 2>(O, OS, acc, bv, col0, row0, li, lg);
     } else {
-        epi_acc_to_lds_impl<T, false>(O, OS, acc, bv, col0, row0, li, lg);
+        epi_acc_to_lds_impl<T, 0>(O, OS, acc, bv, col0, row0, li, lg);
     }
 }
 
@@ -385,6 +388,18 @@ struct EpiStore {
                         const float sg = sigmoid_f(a_[e]);
                         h_[e] = a_[e] * sg;
                         d_[e] = sg + h_[e] * (1.0f - sg);
+                    }
+                    if (o >= 0) {
+                        *(u32x4_t*)((char*)p.y + o) = pack16<T>(h_);
+                        *(u32x4_t*)((char*)p.y2 + o) = pack16<T>(d_);
+                    }
+                } else if (p.act == C2W_ACT_RELU_PAIR && p.y2 != nullptr) {  // y = max(a, 0), y2 = (a > 0)
+                    float a_[PER16], h_[PER16], d_[PER16];
+                    unpack16<T>(v[i], a_);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) {
+                        h_[e] = fmaxf(a_[e], 0.f);
+                        d_[e] = a_[e] > 0.f ? 1.f : 0.f;
                     }
                     if (o >= 0) {
                         *(u32x4_t*)((char*)p.y + o) = pack16<T>(h_);

@@ -273,6 +273,7 @@ __global__ void conv_naive_kernel(const C2wConvArgs p) {
         }
         if (p.bias && co < p.wrows) acc += p.bias[co];
         if (p.act == C2W_ACT_SILU) acc = silu_f(acc);
+        if (p.act == C2W_ACT_RELU) acc = fmaxf(acc, 0.f);
         const size_t off = (size_t)Q * p.ldy + co;
         if (p.mul) {
             float g = Elem<T>::ld((const T*)p.mul + off);
@@ -284,6 +285,13 @@ __global__ void conv_naive_kernel(const C2wConvArgs p) {
             const float a_ = Elem<T>::ld((const T*)p.y + off);  // as stored
             Elem<T>::st((T*)p.y + off, silu_f(a_));
             Elem<T>::st((T*)p.y2 + off, dsilu_f(a_));
+            continue;
+        }
+        if (p.act == C2W_ACT_RELU_PAIR && p.y2) {
+            Elem<T>::st((T*)p.y + off, acc);
+            const float a_ = Elem<T>::ld((const T*)p.y + off);  // as stored
+            Elem<T>::st((T*)p.y + off, fmaxf(a_, 0.f));
+            Elem<T>::st((T*)p.y2 + off, a_ > 0.f ? 1.f : 0.f);
             continue;
         }
         Elem<T>::st((T*)p.y + off, acc);
@@ -365,6 +373,8 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->Cout <= 0 || a->Cout % (16 / esz) != 0 || a->ldy % (16 / esz) != 0) return C2W_ERR_BAD_SHAPE;
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return C2W_ERR_BAD_SHAPE;
     if (a->Hout >= 65536 || a->Wout >= 65536) return C2W_ERR_BAD_SHAPE;
+    if (a->act < C2W_ACT_NONE || a->act > C2W_ACT_RELU_PAIR) return C2W_ERR_BAD_ARG;
+    if ((a->act == C2W_ACT_SILU_PAIR || a->act == C2W_ACT_RELU_PAIR) && a->y2 == nullptr) return C2W_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;

@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 from .nn import BlockSpec, LevelSpec
-from .ops import (ACT_NONE, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F16, DTYPE_F32, MUL_DSILU, MUL_PLAIN, TORCH_DTYPE)
+from .ops import (ACT_NONE, ACT_RELU, ACT_RELU_PAIR, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F16, DTYPE_F32, MUL_DSILU, MUL_PLAIN, TORCH_DTYPE)
 
 LN_EPS = 1e-5
 ALIGN = 64  # elements; keeps every region 256-B aligned in fp32 and 128-B aligned in the bf16 shadow
@@ -63,6 +63,7 @@ class Layout:
         self.cin_pad = _round_up(unet.in_channels, 64)
         self.cout_pad = _round_up(unet.out_channels, 64)
         self.noise_features = net.noise_features
+        self.activation = getattr(unet, "activation_kind", "silu")  # of the residual blocks (model/nn.py:156); the time MLP is always SiLU
         self.convs: Dict[str, ConvRec] = {}
         self.views: Dict[str, Tuple[int, Tuple[int, ...], Tuple[int, ...]]] = {}  # param name -> (offset, shape, strides)
         off = 0
@@ -539,11 +540,12 @@ class Engine:
             # itself is never stored
             d1 = torch.empty((npix, Cc), dtype=T, device=dev) if train else None
             mulmode = MUL_PLAIN
-            if train and os.environ.get("C2W_KEEP_PREACT"):  # diagnostic A/B: keep a and silu(a), evaluate silu'(a) in the backward pass
+            act_inf, act_train = (ACT_RELU, ACT_RELU_PAIR) if lay.activation == "relu" else (ACT_SILU, ACT_SILU_PAIR)
+            if train and os.environ.get("C2W_KEEP_PREACT") and lay.activation == "silu":  # diagnostic A/B: keep a and silu(a), evaluate silu'(a) in the backward pass
                 a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE, y2=d1)
                 h1, d1, mulmode = d1, a1, MUL_DSILU
             else:
-                h1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_SILU_PAIR if train else ACT_SILU, y2=d1)
+                h1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=act_train if train else act_inf, y2=d1)
             if want_ln is not None:
                 out, g2, r2, hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin, want_ln=want_ln)
             else:

@@ -77,8 +77,12 @@ class UNet(torch.nn.Module):
         if kwargs.get("padding_mode", "zeros") != "zeros":
             raise NotImplementedError("only padding_mode='zeros' (configs/sda_unet.yml:14)")
         act = activation()
-        if not isinstance(act, torch.nn.SiLU):
-            raise NotImplementedError("the HIP epilogues implement SiLU, the activation train.py:171 passes")
+        if isinstance(act, torch.nn.SiLU):
+            self.activation_kind = "silu"   # what train.py:171 passes
+        elif isinstance(act, torch.nn.ReLU):
+            self.activation_kind = "relu"   # the reference's own default (model/nn.py:118)
+        else:
+            raise NotImplementedError("the HIP epilogues implement SiLU (train.py:171) and ReLU (the default of model/nn.py:118)")
         self.in_channels, self.out_channels, self.mod_features, self.spatial = in_channels, out_channels, mod_features, spatial
         self.hidden_channels = list(hidden_channels)
         self.hidden_blocks = list(hidden_blocks)

@@ -115,9 +115,11 @@ def infer_config(sd: Dict[str, torch.Tensor]) -> Dict[str, Any]:
                 padding_mode="zeros")
 
 
-def network_from_state_dict(sd: Dict[str, torch.Tensor], device=None, precision: Optional[str] = None) -> ScoreUNet:
+def network_from_state_dict(sd: Dict[str, torch.Tensor], device=None, precision: Optional[str] = None, activation=torch.nn.SiLU) -> ScoreUNet:
+    """``activation``: the residual blocks' activation class -- not recorded in a state_dict (train.py:171 passes SiLU, the UNet's own
+    default is ReLU); ``load_network_snapshot`` reads it off the pickled module tree."""
     sd = {k: v for k, v in sd.items() if not k.endswith(".eps")}  # zuko's LayerNorm may carry an `eps` buffer (SURVEY.md §8c)
-    net = ScoreUNet(activation=torch.nn.SiLU, **infer_config(sd))
+    net = ScoreUNet(activation=activation, **infer_config(sd))
     net.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()})
     if device is not None:
         net = net.to(device)
@@ -144,7 +146,9 @@ def load_network_snapshot(path_or_file, device=None, precision: Optional[str] = 
             net.precision = precision
         net = net.eval().requires_grad_(False)
     else:
-        net = network_from_state_dict(ema.state_dict(), device=device, precision=precision)
+        kinds = {type(m) for m in ema.modules()}
+        act = torch.nn.ReLU if torch.nn.ReLU in kinds and torch.nn.SiLU not in kinds else torch.nn.SiLU
+        net = network_from_state_dict(ema.state_dict(), device=device, precision=precision, activation=act)
     pipe = data.get("pipeline")
     if not isinstance(pipe, SDAPipeline):
         pipe = SDAPipeline(eta=getattr(pipe, "eta", 1e-3))

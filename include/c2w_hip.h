@@ -38,7 +38,9 @@ enum {
 /* C2W_ACT_SILU_PAIR (training): with a = the conv result as stored, y = silu(a) and y2 = silu'(a) -- the activation the next
  * conv reads and the factor the backward pass multiplies by (model/nn.py:156 forward/backward), so the pre-activation itself
  * is never written and the backward epilogue needs no transcendental. */
-enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1, C2W_ACT_SILU_PAIR = 2 };
+/* C2W_ACT_RELU / C2W_ACT_RELU_PAIR: the same for torch.nn.ReLU, the default `activation` of the reference's UNet (model/nn.py:118):
+ * y = max(a, 0), y2 = (a > 0) -- the backward pass multiplies by y2 with C2W_MUL_PLAIN. */
+enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1, C2W_ACT_SILU_PAIR = 2, C2W_ACT_RELU = 3, C2W_ACT_RELU_PAIR = 4 };
 enum { C2W_MUL_PLAIN = 0, C2W_MUL_DSILU = 1 };
 
 /* y[q][co] = act( sum_{tap,ci} w[co][tap][ci] * x[src(q,tap)][ci] + bias[co] ) (* mul' ) (+ res)

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
-ACT_NONE, ACT_SILU, ACT_SILU_PAIR = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
 TD = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16, DTYPE_F16: torch.float16}
 
@@ -94,6 +94,8 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
         out = F.pad(out, (0, 0, 0, 0, 0, Cout - rows))
     if act == ACT_SILU:
         out = F.silu(out)
+    if act == ACT_RELU:
+        out = F.relu(out)
     npix = B * Hout * Wout
     out = out.permute(0, 2, 3, 1).reshape(npix, Cout).to(T).float()
     if mul is not None:
@@ -105,6 +107,11 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
         a_ = out.to(T).float()
         _rows(y, npix, ldy)[:, :Cout] = F.silu(a_).to(T)
         _rows(y2, npix, ldy)[:, :Cout] = _dsilu(a_).to(T)
+        return
+    if act == ACT_RELU_PAIR:
+        a_ = out.to(T).float()
+        _rows(y, npix, ldy)[:, :Cout] = F.relu(a_).to(T)
+        _rows(y2, npix, ldy)[:, :Cout] = (a_ > 0).to(T)
         return
     _rows(y, npix, ldy)[:, :Cout] = out.to(T)
     if y2 is not None:

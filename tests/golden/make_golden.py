@@ -140,6 +140,29 @@ def tiny_net():
     return net
 
 
+def tiny_net_relu():
+    """The same tiny network (same seed, hence the weights of tiny_net.npz) with the reference UNet's OWN default activation,
+    torch.nn.ReLU (model/nn.py:118; train.py:171 passes SiLU): output, loss and every gradient on tiny_net.npz's inputs."""
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.ReLU, **TINY)
+    g0 = np.load(os.path.join(HERE, "tiny_net.npz"))
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), g0["sd." + k]), k
+    x, t, eps = (torch.from_numpy(g0[k]) for k in ("x", "t", "eps"))
+    pipe = pipelines.SDAPipeline()
+    xt = pipe.mu(t) * x + pipe.sigma(t) * eps
+    y = net(xt, t)
+    loss = ((y - eps) ** 2).mean()
+    names = [k for k, _ in net.named_parameters()]
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    out = {"y": y.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64)}
+    for k, gr in zip(names, grads):
+        out["grad." + k] = gr.numpy()
+    with torch.no_grad():
+        out["y32"] = net(torch.from_numpy(g0["x32"]), torch.tensor(0.3)).numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_net_relu.npz"), **out)
+
+
 def sampler(net):
     """Sampler trajectories on the tiny net: L=9, F=2, k=1, 32^2, 4 steps."""
     pipe = pipelines.SDAPipeline()
@@ -268,10 +291,13 @@ def ema_kat():
 if __name__ == "__main__":
     if sys.argv[1:] == ["full_net_gradients"]:
         full_net_gradients()
+    elif sys.argv[1:] == ["tiny_net_relu"]:
+        tiny_net_relu()
     else:
         kats()
         ops()
         net = tiny_net()
+        tiny_net_relu()
         sampler(net)
         ema_kat()
         full_net_fingerprint()

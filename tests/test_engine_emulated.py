@@ -227,3 +227,25 @@ def test_fp16_snapshot_module_round_trip_runs(emu):
         y1 = m(x, t)
     assert y1.dtype == x.dtype
     assert (y1 - y0).abs().max().item() <= 5e-3 * y0.abs().max().item()  # fp16 rounding of the weights only
+
+
+def test_relu_network_matches_the_reference(emu, golden_dir):
+    """activation=torch.nn.ReLU -- the default of the reference's UNet (model/nn.py:118) -- through the engine: ACT_RELU / ACT_RELU_PAIR
+    epilogues, the stored (a > 0) mask as the backward multiplier.  Forward, loss and every gradient against the imported reference."""
+    g = _golden(golden_dir, "tiny_net.npz")
+    r = _golden(golden_dir, "tiny_net_relu.npz")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.ReLU, **TINY)
+    assert net.unet.activation_kind == "relu"
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    with torch.no_grad():
+        y32 = net(torch.from_numpy(g["x32"]), torch.tensor(0.3))
+    assert torch.allclose(y32, torch.from_numpy(r["y32"]), atol=2e-5)
+    loss = od.loss(net, x, t, eps).mean()
+    assert loss.item() == pytest.approx(float(r["loss"]), rel=1e-5)
+    loss.backward()
+    for n, p in net.named_parameters():
+        ref = torch.from_numpy(r["grad." + n])
+        assert torch.allclose(p.grad, ref, atol=1e-5 + 2e-4 * ref.abs().max().item()), (n, (p.grad - ref).abs().max().item())
+    with pytest.raises(NotImplementedError):
+        ScoreUNet(channels=6, spatial=2, activation=torch.nn.GELU, **TINY)

@@ -311,3 +311,34 @@ def test_deep_variant_fp16_forward_vs_oracle_and_graph_replayed_score():
         if graphs:
             assert len(sf._graphs) == 1 and len(next(iter(sf._graphs.values()))["graphs"]) == 2
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_relu_network_vs_reference_golden(golden_dir):
+    """The reference UNet's own default activation (torch.nn.ReLU, model/nn.py:118) on the HIP path: fp32 forward / loss / every
+    gradient against the imported reference (tests/golden/tiny_net_relu.npz), 16-bit forward within the mode tolerances."""
+    g = _golden(golden_dir, "tiny_net.npz")
+    r = _golden(golden_dir, "tiny_net_relu.npz")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.ReLU, **TINY).cuda()
+    net.precision = "fp32"
+    x, t, eps = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "eps"))
+    with torch.no_grad():
+        y32 = net(torch.from_numpy(g["x32"]).cuda(), torch.tensor(0.3).cuda())
+    assert _rel(y32, torch.from_numpy(r["y32"])) <= 1e-4
+    loss = od.loss(net, x, t, eps).mean()
+    assert loss.item() == pytest.approx(float(r["loss"]), rel=1e-4)
+    loss.backward()
+    for n, p in net.named_parameters():
+        assert _rel(p.grad, torch.from_numpy(r["grad." + n])) <= 2e-4, n
+    torch.manual_seed(3)
+    big = ScoreUNet(channels=6, spatial=2, activation=torch.nn.ReLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    sd = {k: v.detach().clone() for k, v in big.state_dict().items()}
+    big = big.cuda()
+    xb = torch.randn(3, 6, 32, 32, generator=torch.Generator().manual_seed(1))
+    tb = torch.tensor([0.2, 0.5, 0.9])
+    yo = ou.score_unet_forward(sd, xb, tb, [1, 1], [1], act=torch.nn.functional.relu)
+    for mode, tol in (("fp32", 1e-4), ("fp16", 5e-3), ("bf16", 3e-2)):
+        big.precision = mode
+        with torch.no_grad():
+            assert _rel(big(xb.cuda(), tb.cuda()), yo) <= tol, mode

@@ -186,3 +186,21 @@ def test_full_size_backward_fingerprints(golden_dir, C):
             s0, s1 = (int(v) for v in g["step." + n])
             ref = torch.from_numpy(g[k])
             assert (grads[n][::s0, ::s1] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-12, n
+
+
+def test_tiny_net_with_the_unets_default_relu(golden_dir):
+    """model/nn.py:118: the UNet's own default activation is ReLU (train.py:171 passes SiLU).  Oracle (act=F.relu) vs the imported
+    reference built with activation=torch.nn.ReLU on the same weights and inputs."""
+    g = {k: v for k, v in np.load(os.path.join(golden_dir, "tiny_net.npz"), allow_pickle=False).items()}
+    r = {k: v for k, v in np.load(os.path.join(golden_dir, "tiny_net_relu.npz"), allow_pickle=False).items()}
+    sd = {k[3:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("sd.")}
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    fwd = lambda a, b: ou.score_unet_forward(sd, a, b, hidden_blocks=[1, 1], attention_levels=[1], act=F.relu)
+    y = fwd(od.perturb(x, t, eps), t)
+    assert torch.allclose(y, torch.from_numpy(r["y"]), atol=2e-5)
+    loss = ((y - eps) ** 2).mean()
+    assert loss.item() == pytest.approx(float(r["loss"]), rel=1e-5)
+    grads = torch.autograd.grad(loss, list(sd.values()))
+    for (k, _), gr in zip(sd.items(), grads):
+        ref = torch.from_numpy(r["grad." + k])
+        assert torch.allclose(gr, ref, atol=1e-6 + 2e-4 * ref.abs().max().item()), k
