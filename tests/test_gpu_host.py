@@ -376,8 +376,15 @@ def test_training_step_with_regenerated_noise_equals_the_step_on_the_written_noi
     ops.philox_normal(eps, eps.numel(), a.last_noise_seed)
     lb = b.step(x, t=t, eps=eps)
     assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
-    assert torch.equal(a.eng.flat, b.eng.flat) or (a.eng.flat - b.eng.flat).abs().max().item() <= 2e-6  # split-K order is the same; atomics in dm are not
-    assert (a.ema_flats[0] - b.ema_flats[0]).abs().max().item() <= 2e-6
+    # Same arithmetic on both sides; what may differ is the summation ORDER of fp32 atomics (bias / modulation gradients), and Adam's
+    # first step is lr * g / (|g| + eps): where |g| ~ eps a last-bit difference moves the parameter by up to 2 lr.  So: tight where
+    # the gradient is well above eps, bounded by 2 lr everywhere (the rule of _assert_adam_close).
+    big = b.eng.flat_grad.abs() > 1e-5
+    d = (a.eng.flat - b.eng.flat).abs()
+    assert d[big].max().item() <= 2e-6 and d.max().item() <= 2.0 * 1e-3
+    assert (a.eng.flat_grad - b.eng.flat_grad).abs().max().item() <= 1e-5 * b.eng.flat_grad.abs().max().item()
+    de = (a.ema_flats[0] - b.ema_flats[0]).abs()
+    assert de[big].max().item() <= 2e-6 and de.max().item() <= 2.0 * 1e-3 * 0.01 + 1e-6
     s1 = a.last_noise_seed
     a.step(x, t=t)
     assert a.last_noise_seed != s1  # a fresh stream every step
