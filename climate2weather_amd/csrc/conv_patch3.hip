@@ -43,7 +43,7 @@
 namespace {
 
 #ifndef C2W_T3_NW
-#define C2W_T3_NW 4  // waves per workgroup of the 16x16-tile kernel: 4 (wave tile 64 co x 128 px, 2 waves per SIMD) or 8 (64 co x 64 px, 4 per SIMD)
+#define C2W_T3_NW 8  // waves per workgroup of the 16x16-tile kernel: 4 (wave tile 64 co x 128 px, 2 waves per SIMD) or 8 (64 co x 64 px, 4 per SIMD)
 #endif
 constexpr int T3_PW = 20;                     // patch row pitch in pixels (18 used)
 constexpr int T3_WBYTES = 128 * 64;           // one stage of weights: 128 co x 32 ci
