@@ -15,6 +15,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
+CONV_POOL2 = 1  # ConvArgs.flags
 
 
 class C2wError(RuntimeError):
@@ -28,7 +29,7 @@ class ConvArgs(Structure):
         ("Hout", c_int32), ("Wout", c_int32), ("Cout", c_int32), ("ldy", c_int32),
         ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),
         ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
-        ("ln_eps", c_float), ("ln_pad_", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p),
+        ("ln_eps", c_float), ("flags", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p),
     ]
 
 
@@ -38,6 +39,7 @@ _PROTOS = {
     "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_pool2_supported": [POINTER(ConvArgs), c_int],
     "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_ulonglong, c_int, c_void_p],
     "c2w_conv_wgrad_workspace_bytes": [POINTER(ConvArgs), c_int],

@@ -322,6 +322,36 @@ struct EpiStore {
         }
     }
 
+    // ---- 2x2 sum pooling of a pass of 128 tile pixels (8 tile rows x 16 columns in LDS rows R = 16 * row + col) -> 4 x 8 pooled
+    // pixels: the adjoint of Upsample(nearest, x2) (model/nn.py:184) on the input gradient of the up-conv.  Each thread adds the
+    // four rows of a pooled pixel in the order c2w_sumpool2 does ((g00 + g01) + g10) + g11, in fp32, from the values as they
+    // would have been stored.  ppix0 = NHWC index of the pass's first POOLED pixel, Wp = pooled image width.
+    __device__ __forceinline__ void finish_pool2(const C2wConvArgs& p, const char* O, int OS, int tid, int co0, long long ppix0, int Wp) {
+        static_assert(NROWS == 128, "one pass = 8 tile rows");
+        constexpr int ITEMS = 32 * SEGS;
+#pragma unroll
+        for (int i0 = 0; i0 < ITEMS; i0 += NTHR) {
+            const int idx = i0 + tid;
+            if (ITEMS % NTHR != 0 && idx >= ITEMS) break;
+            const int pp = idx / SEGS, cs = idx - pp * SEGS;
+            const int pr = pp >> 3, pc = pp & 7;
+            const int r00 = (2 * pr) * 16 + 2 * pc;
+            float s[PER16], f[PER16];
+            unpack16<T>(*(const u32x4_t*)(O + r00 * OS + cs * 16), s);
+            unpack16<T>(*(const u32x4_t*)(O + (r00 + 1) * OS + cs * 16), f);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) s[e] += f[e];
+            unpack16<T>(*(const u32x4_t*)(O + (r00 + 16) * OS + cs * 16), f);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) s[e] += f[e];
+            unpack16<T>(*(const u32x4_t*)(O + (r00 + 17) * OS + cs * 16), f);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) s[e] += f[e];
+            const int c = co0 + cs * PER16;
+            if (c < p.Cout) *(u32x4_t*)((char*)p.y + ((ppix0 + (long long)pr * Wp + pc) * p.ldy + c) * ESZ) = pack16<T>(s);
+        }
+    }
+
     // sum over the 16 lanes that share a pixel row = one DPP row: four row rotations on the VALU (no LDS-pipe shuffles)
     template <int CTRL>
     static __device__ __forceinline__ float dpp_add(float v) {

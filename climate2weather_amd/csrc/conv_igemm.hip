@@ -350,6 +350,14 @@ extern "C" int c2w_conv_patch_supported(const C2wConvArgs* a, int dtype) {
     return a != nullptr && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr ? 1 : 0;
 }
 
+extern "C" int c2w_conv_pool2_supported(const C2wConvArgs* a, int dtype) {
+    (void)dtype;
+    if (a == nullptr || a->mode != C2W_CONV_S1 || a->res != nullptr || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE ||
+        a->ln_x != nullptr || a->lnf_y != nullptr)
+        return 0;
+    return c2w_conv_patch_eligible(*a) && !c2w_conv_pair_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_POOL2") == nullptr ? 1 : 0;
+}
+
 extern "C" int c2w_conv_lnfwd_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE || a->ln_x != nullptr) return 0;
@@ -378,6 +386,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     hipStream_t st = (hipStream_t)stream;
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
+    if ((a->flags & C2W_CONV_POOL2) != 0 && (naive != 0 || !c2w_conv_pool2_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if (naive == 0 && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_s1(*a, dtype, st);
     if (naive == 0 && c2w_conv_pair_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_pair(*a, dtype, st);
     if (naive == 0 && c2w_conv_ts2_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_ts2(*a, dtype, st);

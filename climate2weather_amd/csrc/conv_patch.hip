@@ -286,13 +286,17 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     }
     const int tn = L % nN, tm = L / nN;
     const int co0 = tn * 128;
-    const int H = p.Hin, W = p.Win;
+    // H x W = the grid the tiles and the taps live on (= the output); with C2W_CONV_UP it is the nearest-neighbour x2 upsampling of the
+    // Hs x Ws source map, which is never materialised: patch pixel (ih, iw) is fetched from source pixel (ih >> 1, iw >> 1)
+    // (model/nn.py:184-189; the zero padding is that of the upsampled map).
+    const bool up = !PAIR && p.mode == C2W_CONV_UP;
+    const int H = p.Hout, W = p.Wout, Ws = p.Win;
     const int tw = PAIR ? 1 : W >> 4, tpi = (H >> 3) * tw;
     const int b = PAIR ? 2 * (tm / tpi) : tm / tpi, tt = tm - (tm / tpi) * tpi;
     const int ty = tt / tw, tx = tt - ty * tw;
     const int oh0 = ty << 3, ow0 = tx << 4;
 
-    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
     const int nimg = PAIR ? (b + 1 < p.B ? 2 : 1) : 1;  // images under the descriptor: a missing partner reads as zeros (out of range)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)(img_bytes * nimg));
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
@@ -310,7 +314,8 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px - 10 * pimg;
         const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < (PAIR ? 20 : 18);
         const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
-        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)img_bytes + (lc << 4) : C2W_OOB;
+        const int spix = up ? (ih >> 1) * Ws + (iw >> 1) : ih * Ws + iw;
+        pvo[r] = ok ? (uint32_t)(spix * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)img_bytes + (lc << 4) : C2W_OOB;
         pdst[r] = pc * 1024;
     }
     uint32_t wvo[4];  // weight tile: 128 rows x 8 chunks = 4 rounds of 256 threads
@@ -420,8 +425,9 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     C2W_STAMP(st2);
     unsigned long long sa = 0, sb = 0, sc = 0;
     EpiStore<T, 128, H_NTHR> est;
+    const bool pool2 = !PAIR && (p.flags & C2W_CONV_POOL2) != 0;
     if constexpr (PAIR) est.prefetch_pair8(p, tid, co0, ((long long)b * H + oh0) * W, H * W, nimg);
-    else est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    else if (!pool2) est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
     C2W_STAMP(sa);
     __syncthreads();
     C2W_STAMP(sb);
@@ -434,7 +440,9 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     C2W_STAMP(sc);
     __syncthreads();
     C2W_STAMP(st3);
-    if constexpr (ESZ == 2 && !PAIR) {
+    if (pool2) {
+        est.finish_pool2(p, O, OS, tid, co0, ((long long)b * (H >> 1) + (oh0 >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
+    } else if constexpr (ESZ == 2 && !PAIR) {
         if (p.ln_x != nullptr) est.finish_ln(p, O, OS, tid, b, red);
         else if (p.lnf_y != nullptr) est.finish_lnf(p, O, OS, tid, b);
         else est.finish(p, O, OS, tid);
@@ -673,14 +681,14 @@ int launch(const C2wConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int nN = (a.Cout + 127) / 128;
-    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr || a.lnf_y != nullptr || (a.Hin & 15) != 0) {  // two half-tile workgroups per CU
+    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr || a.lnf_y != nullptr || (a.Hin & 15) != 0 || a.mode != C2W_CONV_S1) {  // two half-tile workgroups per CU
         static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
         static bool attr_h = false;
         if (!attr_h) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
             attr_h = true;
         }
-        const int nMh = a.B * (a.Hin >> 3) * (a.Win >> 4);
+        const int nMh = a.B * (a.Hout >> 3) * (a.Wout >> 4);
         const int lds_h = getenv("C2W_HALF_ONE_PER_CU") ? 100 * 1024 : H_LDS;  // diagnostic: forbid co-residency
         conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, lds_h, st>>>(a);
         return (int)hipGetLastError();
@@ -736,9 +744,11 @@ int c2w_conv_patch_pair(const C2wConvArgs& a, int dtype, hipStream_t st) {
     return C2W_ERR_BAD_ARG;
 }
 
-bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // images that 8 x 16-pixel tiles cover exactly
-    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && (a.Win & 15) == 0 &&
-           (long long)a.B * (a.Hin >> 3) * (a.Win >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
+bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // OUTPUT grids that 8 x 16-pixel tiles cover exactly; stride 1, or x2 upsampling folded in
+    const bool geom = (a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout) ||
+                      (a.mode == C2W_CONV_UP && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && getenv("C2W_NO_UP_PATCH") == nullptr);
+    return geom && (a.Hout & 7) == 0 && (a.Wout & 15) == 0 &&
+           (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
 }
 
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {

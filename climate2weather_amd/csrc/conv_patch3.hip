@@ -121,13 +121,16 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     }
     const int tn = L % nN, tm = L / nN;
     const int co0 = tn * 128;
-    const int H = p.Hin, W = p.Win;
+    // H x W = the grid the tiles and the taps live on (= the output); with C2W_CONV_UP it is the nearest-neighbour x2 upsampling of the
+    // Hin x Win source map, never materialised: patch pixel (ih, iw) is fetched from source pixel (ih >> 1, iw >> 1) (model/nn.py:184-189)
+    const bool up = p.mode == C2W_CONV_UP;
+    const int H = p.Hout, W = p.Wout, Ws = p.Win;
     const int tw = W >> 4, tpi = (H / TR) * tw;
     const int b = tm / tpi, tt = tm - b * tpi;
     const int ty = tt / tw, tx = tt - ty * tw;
     const int oh0 = ty * TR, ow0 = tx << 4;
 
-    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
 
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
             const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
             const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18 && pr < TR + 2;
             const uint32_t cg = (uint32_t)(lane_ & 7) ^ t3_pswz(px);
-            const uint32_t voff = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (cg << 4) : C2W_OOB;
+            const int spix = up ? (ih >> 1) * Ws + (iw >> 1) : ih * Ws + iw;
+            const uint32_t voff = ok ? (uint32_t)(spix * p.Cin) * ESZ + (cg << 4) : C2W_OOB;
             glds16(rx, smem + pc * 1024, voff, (uint32_t)chunk * 128u);
         }
     };
@@ -328,10 +332,12 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     for (int h = 0; h < CF::NPASS; ++h) {
         if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
         EpiStore<T, 128, T3_NTHR> est;
-        est.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8 * h) * W + ow0, W);
+        const bool pool2 = (p.flags & C2W_CONV_POOL2) != 0;
+        if (!pool2) est.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8 * h) * W + ow0, W);
         __syncthreads();
         const char* const Oh = O + h * 128 * T3_OS;
-        if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
+        if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
+        else if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
         else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
         else est.finish(p, Oh, T3_OS, tid_e);
         if (h + 1 < CF::NPASS) __syncthreads();  // the LayerNorm column sums are re-zeroed for the next block only after everyone read them
@@ -347,7 +353,7 @@ int t3_launch(const C2wConvArgs& a, hipStream_t st) {
         attr = true;
     }
     const int nN = (a.Cout + 127) / 128;
-    const int nM = a.B * (a.Hin / TR) * (a.Win >> 4);
+    const int nM = a.B * (a.Hout / TR) * (a.Wout >> 4);
     conv_patch_t3_kernel<TR, T, NW><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
     return (int)hipGetLastError();
 }
@@ -360,8 +366,8 @@ int t3_launch(const C2wConvArgs& a, hipStream_t st) {
 // workgroups per CU) measured no faster than conv_patch_half_kernel and is not dispatched.
 bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype) {
     static const int mode = getenv("C2W_CONV_T3") ? atoi(getenv("C2W_CONV_T3")) : -1;
-    if ((dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16) || mode == 0 || (a.Hin & 15) != 0 || (a.Win & 15) != 0) return false;
-    const long long wgs = (long long)a.B * (a.Hin >> 4) * (a.Win >> 4) * ((a.Cout + 127) / 128);
+    if ((dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16) || mode == 0 || (a.Hout & 15) != 0 || (a.Wout & 15) != 0) return false;
+    const long long wgs = (long long)a.B * (a.Hout >> 4) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
     return mode == 16 || wgs >= 1024;
 }
 

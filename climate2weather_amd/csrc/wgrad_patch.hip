@@ -55,7 +55,8 @@ struct WpArgs {
     const void* x;
     float* dw;
     float* db;
-    int B, H, W, Cin, Cout, ldy;
+    int B, H, W, Cin, Cout, ldy;  // H x W: the grid of dY = the grid the taps live on
+    int up;                       // C2W_CONV_UP: X is the (H/2) x (W/2) source map of a nearest-neighbour x2 upsampling (patch pixel >> 1)
     int ktiles, ktiles_per_split;
     float* ws;  // optional workspace [split][tile][tap][COT][CIB] fp32: partial sums by plain stores, reduced by a second launch
 };
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     //   dY piece i: slot s = tid + 512 i -> row = s >> 4 (pixel of the tile), chunk = s & 15 (16-B chunk of the 256-B channel row);
     //     the source-side swizzle of a row does not depend on i (rows 32 apart), so offset(i) = offset(0) + i * (two tile rows).
     //   patch piece r: piece number pc = 8 r + wave (pieces past the end repeat the last one) -> patch row pc / 3, 8-pixel group pc % 3.
-    const size_t ximg = (size_t)H * W * p.Cin * ESZ;
+    const int Ws = p.up ? W >> 1 : W;
+    const size_t ximg = (size_t)(p.up ? (H >> 1) * Ws : H * W) * p.Cin * ESZ;
     const size_t yimg = (size_t)H * W * p.ldy * ESZ;
     const uint32_t a_step = PAIR ? (uint32_t)(16 * p.ldy * ESZ) : (uint32_t)(2 * W * p.ldy * ESZ);  // bytes between dY pieces i and i + 1
     auto dy_voff0 = [&](int tid_) -> uint32_t {
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
         } else {
             const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
             const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
-            return sel_oob(ok, (uint32_t)((ih * W + iw) * p.Cin) * ESZ + lanepart);
+            const int spix = p.up ? (ih >> 1) * Ws + (iw >> 1) : ih * W + iw;
+            return sel_oob(ok, (uint32_t)(spix * p.Cin) * ESZ + lanepart);
         }
     };
 
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <int ESZ, bool PAIR>
 static void split_plan(const C2wConvArgs& a, int& ktiles, int& tilesMN, int& nsplit, int& ktiles_per_split) {
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
-    ktiles = PAIR ? ((a.B + 1) >> 1) * (a.Hin >> 3) : a.B * (a.Hin >> 3) * (a.Win >> 4);
+    ktiles = PAIR ? ((a.B + 1) >> 1) * (a.Hout >> 3) : a.B * (a.Hout >> 3) * (a.Wout >> 4);
     tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
     nsplit = 256 / tilesMN;
     if (nsplit > ktiles) nsplit = ktiles;
@@ -476,7 +479,8 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
     WpArgs p;
     p.dy = a.y; p.x = a.x; p.dw = dw; p.db = db;
-    p.B = a.B; p.H = a.Hin; p.W = a.Win; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
+    p.B = a.B; p.H = a.Hout; p.W = a.Wout; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
+    p.up = a.mode == C2W_CONV_UP ? 1 : 0;
     int tilesMN, nsplit;
     split_plan<ESZ, PAIR>(a, p.ktiles, tilesMN, nsplit, p.ktiles_per_split);
     static bool attr_set = false;
@@ -499,10 +503,12 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
 
 static bool wgrad_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per K tile
     static const bool off = getenv("C2W_CONV_PAIR") != nullptr && atoi(getenv("C2W_CONV_PAIR")) == 0;
-    return !off && a.Win == 8 && a.Hin == 8;
+    return !off && a.mode == C2W_CONV_S1 && a.Win == 8 && a.Hin == 8;
 }
 
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
+    if (a.mode == C2W_CONV_UP)  // nearest-neighbour x2 upsampling folded into the patch load
+        return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hout & 7) == 0 && (a.Wout & 15) == 0 && getenv("C2W_NO_UP_PATCH") == nullptr;
     return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && ((a.Win & 15) == 0 || wgrad_pair(a));
 }
 

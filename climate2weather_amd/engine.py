@@ -668,17 +668,12 @@ class Engine:
                 Hl, Wl = Hc, Wc
                 Hc, Wc = Hc * 2, Wc * 2
                 rec_t = lay.convs["unet." + lv.tail_key]
-                if ops.conv_patch_supported(self._geom(B, Hc, Wc, rec_t.kstride, Hc, Wc, rec_t.rows, rec_t.rows, rec_t.rows, CONV_S1), dt):
-                    # materialise the upsampled map once: the conv and its weight gradient then run on the halo-patch kernels
-                    # (measured 905 -> 620 + 150 us forward, 1400 -> 305 us weight gradient at 64^2 -> 128^2, B = 128)
-                    hu = torch.empty((B * Hc * Wc, Cc), dtype=T, device=dev)
-                    ops.upsample2(hl, hu, B, Hl, Wl, Cc, dt)
-                    nxt = lay.levels[i - 1].ascent[0] if lay.levels[i - 1].ascent else None
-                    if nxt is not None and nxt.kind == "res":  # the up-conv also emits the next level's first LayerNorm input
-                        cur, g_t, r_t, h0_carry = conv3("unet." + lv.tail_key, hu, Hc, Wc, Hc, Wc, CONV_S1, res=skips.pop(), want_ln=mod_of(nxt))
-                    else:
-                        cur, g_t, r_t = conv3("unet." + lv.tail_key, hu, Hc, Wc, Hc, Wc, CONV_S1, res=skips.pop())
-                    hl = hu
+                # Upsample(nearest, x2) is never materialised (model/nn.py:184): the halo-patch kernels fetch patch pixel (ih, iw) from
+                # (ih >> 1, iw >> 1) of the low-resolution map (conv and weight gradient alike); grids they do not tile go to the gather
+                # kernel, which folds the upsampling into its per-tap gather.
+                nxt = lay.levels[i - 1].ascent[0] if lay.levels[i - 1].ascent else None
+                if nxt is not None and nxt.kind == "res":  # the up-conv also emits the next level's first LayerNorm input
+                    cur, g_t, r_t, h0_carry = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop(), want_ln=mod_of(nxt))
                 else:
                     cur, g_t, r_t = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop())
                 if train:
@@ -686,9 +681,16 @@ class Engine:
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient
                         self._wg(hl, gy, rec, g, dt)
                         tape.done(rec.w_off)
-                        gu = dgrad(rec, gy, Hu, Wu, Hu, Wu, CONV_S1, Cc)  # gradient w.r.t. the upsampled map
+                        # gradient w.r.t. the low-resolution map = 2x2 sums of the gradient w.r.t. its upsampling (adjoint of Upsample):
+                        # summed in the input-gradient kernel's epilogue where it supports that -- the full-resolution gradient is
+                        # then never written (537 MB at the top level) -- else a pooling pass behind it
+                        gd = self._geom(B, Hu, Wu, rec.dg_ld, Hu, Wu, Cc, Cc, rec.cin, CONV_S1)
                         gl = torch.empty((B * Hl * Wl, Cc), dtype=T, device=dev)
-                        ops.sumpool2(gu, gl, B, Hl, Wl, Cc, dt)
+                        if ops.conv_pool2_supported(gd, dt):
+                            ops.conv(gy, self._wT(rec, dt), None, gl, gd, dt, pool2=True)
+                        else:
+                            gu = dgrad(rec, gy, Hu, Wu, Hu, Wu, CONV_S1, Cc)
+                            ops.sumpool2(gu, gl, B, Hl, Wl, Cc, dt)
                         dx = torch.empty_like(gl)
                         ops.ln_backward(gl, xin, None, None, dx, None, B * Hl * Wl, Hl * Wl, Cc, 0, LN_EPS, self.ln_unbiased, dt)
                         return dx

@@ -45,13 +45,15 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
 
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
-         ln=None, lnf=None):
+         ln=None, lnf=None, pool2: bool = False):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
     dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.
     lnf = dict(y, m, ldm, eps, unbiased): also write y = LN(result + m), the consumer block's normalised input -- only where
     conv_lnfwd_supported(g, dtype) says so."""
     a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf)
+    if pool2:  # y: [B][Hout/2][Wout/2][ldy] <- 2x2 sums of the result (only where conv_pool2_supported says so)
+        a.flags = _lib.CONV_POOL2
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
@@ -59,6 +61,12 @@ def conv_patch_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
     return bool(_lib.load().c2w_conv_patch_supported(ctypes.byref(a), dtype))
+
+
+def conv_pool2_supported(g: dict, dtype: int) -> bool:
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    return bool(_lib.load().c2w_conv_pool2_supported(ctypes.byref(a), dtype))
 
 
 def conv_lnfwd_supported(g: dict, dtype: int) -> bool:

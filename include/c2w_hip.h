@@ -42,6 +42,7 @@ enum {
  * y = max(a, 0), y2 = (a > 0) -- the backward pass multiplies by y2 with C2W_MUL_PLAIN. */
 enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1, C2W_ACT_SILU_PAIR = 2, C2W_ACT_RELU = 3, C2W_ACT_RELU_PAIR = 4 };
 enum { C2W_MUL_PLAIN = 0, C2W_MUL_DSILU = 1 };
+enum { C2W_CONV_POOL2 = 1 }; /* C2wConvArgs.flags */
 
 /* y[q][co] = act( sum_{tap,ci} w[co][tap][ci] * x[src(q,tap)][ci] + bias[co] ) (* mul' ) (+ res)
  * q runs over the B*Hout*Wout output pixels in NHWC raster order. */
@@ -69,7 +70,9 @@ typedef struct C2wConvArgs {
     int32_t ln_ldm;
     int32_t ln_unbiased;
     float ln_eps;
-    int32_t ln_pad_;
+    int32_t flags;      /* C2W_CONV_POOL2: y is [B][Hout/2][Wout/2][ldy] and receives the 2x2 SUMS of the result -- the adjoint of
+                         * Upsample(nearest, x2) (model/nn.py:184) applied to the input gradient of the conv behind it, on chip: the
+                         * full-resolution gradient is never written (see c2w_conv_pool2_supported) */
     /* Optional fused LayerNorm FORWARD of the consumer (see c2w_conv_lnfwd_supported): with lnf_y != NULL the kernel also
      * writes lnf_y = LN_C(y + lnf_m[b]) -- c2w_ln_forward(x = y as stored, m = lnf_m, ldm = ln_ldm, eps = ln_eps,
      * unbiased = ln_unbiased) -- i.e. the next residual block's normalised input (model/nn.py:28,154) leaves the conv that
@@ -81,6 +84,9 @@ typedef struct C2wConvArgs {
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
  * by 8 x 16-pixel tiles), 0 when it takes the general gather kernels. */
 int c2w_conv_patch_supported(const C2wConvArgs* args, int dtype);
+/* 1 when c2w_conv_forward can store the 2x2-pooled result (flags & C2W_CONV_POOL2): halo-patch geometry, stride 1, no
+ * res / mul / y2 / activation / LayerNorm fusion.  Otherwise callers run the conv and c2w_sumpool2. */
+int c2w_conv_pool2_supported(const C2wConvArgs* args, int dtype);
 /* 1 when c2w_conv_forward can also emit the consumer's LayerNorm (lnf_y): same shape conditions as the backward fusion,
  * residual allowed. */
 int c2w_conv_lnfwd_supported(const C2wConvArgs* args, int dtype);

@@ -49,6 +49,8 @@ def _conv_core(X, Wt, g):
 
 
 def conv_patch_supported(g, dtype):
+    if g["mode"] == CONV_UP:
+        return g["Hout"] == 2 * g["Hin"] and g["Hout"] % 8 == 0 and g["Wout"] % 16 == 0
     return g["mode"] == CONV_S1 and g["Hin"] == g["Hout"] and g["Hin"] % 8 == 0 and g["Win"] % 16 == 0
 
 
@@ -62,10 +64,14 @@ def conv_lnbwd_supported(g, dtype):
 
 
 def conv_lnfwd_supported(g, dtype):
-    return g["mode"] == CONV_S1 and g["Cout"] == g["ldy"]
+    return g["mode"] in (CONV_S1, CONV_UP) and g["Cout"] == g["ldy"]
 
 
-def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None):
+def conv_pool2_supported(g, dtype):
+    return conv_patch_supported(g, dtype) and g["mode"] == CONV_S1 and g["Win"] != 8
+
+
+def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False):
     if lnf is not None:  # second output: LN of the stored result (+ the consumer's modulation)
         assert ln is None and mul is None and y2 is None and act == ACT_NONE
         conv(x, w, bias, y, g, dtype, res=res)
@@ -112,6 +118,12 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
         a_ = out.to(T).float()
         _rows(y, npix, ldy)[:, :Cout] = F.relu(a_).to(T)
         _rows(y2, npix, ldy)[:, :Cout] = (a_ > 0).to(T)
+        return
+    if pool2:  # 2x2 sums of the result as it would have been stored: ((g00 + g01) + g10) + g11 in fp32 (sumpool2's order)
+        assert res is None and mul is None and y2 is None and act == ACT_NONE
+        gq = out.to(T).float().view(B, Hout, Wout, Cout)
+        pooled = ((gq[:, 0::2, 0::2] + gq[:, 0::2, 1::2]) + gq[:, 1::2, 0::2]) + gq[:, 1::2, 1::2]
+        _rows(y, npix // 4, ldy)[:, :Cout] = pooled.reshape(npix // 4, Cout).to(T)
         return
     _rows(y, npix, ldy)[:, :Cout] = out.to(T)
     if y2 is not None:

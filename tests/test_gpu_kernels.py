@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import emu_ops as E
-from climate2weather_amd import ops
+from climate2weather_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,8 @@ CONV_CASES = [
     (ops.CONV_S2, 1, 32, 32, 128, 256, 256, 256),
     (ops.CONV_UP, 2, 8, 8, 128, 64, 64, 64),
     (ops.CONV_UP, 1, 16, 16, 64, 128, 128, 128),
+    (ops.CONV_UP, 2, 8, 16, 128, 128, 128, 128),    # upsampling folded into the halo patch: 16x32 output = 2x2 tiles of 8x16, 2 K-chunks (bf16)
+    (ops.CONV_UP, 3, 12, 8, 64, 192, 180, 192),     # 24x16 output: three tiles per image, two channel tiles (second partial)
     (ops.CONV_TS2, 2, 8, 8, 128, 64, 64, 64),       # dgrad of a stride-2 conv: 8x8 dy -> 16x16 dx
     (ops.CONV_TS2, 4, 8, 8, 128, 64, 64, 64),       # same, a quarter of the pixels fills a tile: parity-class tiles (1/2/2/4 taps)
     (ops.CONV_TS2, 8, 16, 8, 64, 192, 192, 192),    # parity classes: 4 tiles per class, 2 images per tile, 2 channel tiles
@@ -139,6 +141,69 @@ def test_conv_16x16_tile_kernel_all_epilogues(dt):
     E.conv(x, w, bias, y_ref, g, dt, res=res, lnf=dict(lnf, y=y2_ref))
     close(y, y_ref, dt, "16x16 tile kernel next to fused LN forward")
     close(y2, y2_ref, dt, "16x16 tile kernel, fused LN forward output")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 128), (3, 24, 16, 128, 192), (1, 8, 16, 64, 64), (16, 128, 128, 128, 128)])
+def test_conv_with_pooled_output(shape, dt):
+    """C2W_CONV_POOL2: the input gradient of the up-conv leaves the kernel as 2x2 sums (the adjoint of Upsample(nearest, x2),
+    model/nn.py:184) -- halo-patch kernels only.  8x16-tile kernel (small shapes, all dtypes) and the 16x16-tile kernel (B = 16 at
+    128x128: 1024 tiles) against conv + sumpool2 of the PyTorch restatement, and bit-equal to the kernels' own two-pass result."""
+    B, H, W, Cin, Cout = shape
+    if dt == F32 and B == 16:
+        pytest.skip("the 16x16-tile kernel is 16-bit only; fp32 covered by the small shapes")
+    g = geom(B, H, W, Cin, H, W, Cout, Cout, Cout, ops.CONV_S1)
+    assert ops.conv_pool2_supported(g, dt)
+    x = rnd((B * H * W, Cin), dt, 1)
+    w = rnd((Cout, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    yp = torch.full((B * H * W // 4, Cout), 7.0, dtype=TD[dt], device=dev())
+    yp_ref = yp.clone()
+    ops.conv(x, w, None, yp, g, dt, pool2=True)
+    E.conv(x, w, None, yp_ref, g, dt, pool2=True)
+    close(yp, yp_ref, dt, "pooled conv output")
+    full = torch.empty((B * H * W, Cout), dtype=TD[dt], device=dev())
+    two = torch.empty_like(yp)
+    ops.conv(x, w, None, full, g, dt)
+    ops.sumpool2(full, two, B, H // 2, W // 2, Cout, dt)
+    assert torch.equal(yp, two)  # same values in the same order as the separate pooling pass
+    assert not ops.conv_pool2_supported(geom(B, H, W, Cin, H // 2, W // 2, Cout, Cout, Cout, ops.CONV_S2), dt)
+    with pytest.raises(_lib.C2wError):
+        ops.conv(x, w, None, yp, geom(B, H, W, Cin, H // 2, W // 2, Cout, Cout, Cout, ops.CONV_S2), dt, pool2=True)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_up_conv_on_the_16x16_tile_kernel_and_its_weight_gradient(dt):
+    """model/nn.py:184-189 (LayerNorm -> Upsample(nearest, x2) -> Conv2d) without the upsampled map: C2W_CONV_UP on the halo-patch
+    kernels fetches patch pixel (ih, iw) from source pixel (ih >> 1, iw >> 1).  At a size that dispatches to conv_patch_t3_kernel<16>
+    (B = 16, 64x64 -> 128x128, 128 -> 128: 1024 tiles) with the epilogues the engine uses there (skip add, next block's LayerNorm
+    emitted), and the weight gradient of the same geometry on wgrad_patch_kernel -- against the PyTorch restatement."""
+    B, Hl, C = 16, 64, 128
+    H = 2 * Hl
+    g = geom(B, Hl, Hl, C, H, H, C, C, C, ops.CONV_UP)
+    assert ops.conv_patch_supported(g, dt) and ops.conv_lnfwd_supported(g, dt)
+    x = rnd((B * Hl * Hl, C), dt, 1)
+    w = rnd((C, 9, C), dt, 2, scale=1.0 / math.sqrt(9 * C))
+    bias = rnd((C,), F32, 3)
+    res = rnd((B * H * H, C), dt, 4)
+    m = rnd((B, C + 64), F32, 6)
+    y, y2 = (torch.full((B * H * H, C), 7.0, dtype=TD[dt], device=dev()) for _ in range(2))
+    y_ref, y2_ref = y.clone(), y2.clone()
+    ops.conv(x, w, bias, y, g, dt, res=res)
+    E.conv(x, w, bias, y_ref, g, dt, res=res)
+    close(y, y_ref, dt, "up-conv + skip on the 16x16 tile kernel")
+    lnf = dict(m=m.view(-1)[32:], ldm=C + 64, eps=1e-5, unbiased=True)
+    ops.conv(x, w, bias, y, g, dt, res=res, lnf=dict(lnf, y=y2))
+    E.conv(x, w, bias, y_ref, g, dt, res=res, lnf=dict(lnf, y=y2_ref))
+    close(y, y_ref, dt, "up-conv next to fused LN forward")
+    close(y2, y2_ref, dt, "up-conv, fused LN forward output")
+    dy = rnd((B * H * H, C), dt, 7)
+    dw = torch.zeros(C * 9 * C, dtype=torch.float32, device=dev())
+    db = torch.zeros(C, dtype=torch.float32, device=dev())
+    dw_ref, db_ref = dw.clone(), db.clone()
+    ops.conv_wgrad(x, dy, dw, g, dt, dbias=db, workspace=ops.new_workspace(dev()))
+    E.conv_wgrad(x, dy, dw_ref, g, dt, dbias=db_ref)
+    close(dw, dw_ref, dt, "up-conv weight gradient (halo patch from the low-resolution map)", tol=1e-2)
+    close(db, db_ref, dt, "up-conv bias gradient", tol=1e-2)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
