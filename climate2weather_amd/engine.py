@@ -167,7 +167,9 @@ class Tape:
         self.steps: List[Callable] = []
         self.gskip: Dict[int, torch.Tensor] = {}
         self.meta: dict = {}
-        self.progress: Optional[Callable[[int], None]] = None  # called with the lowest flat offset whose gradient is final
+        # called with the lowest flat offset whose gradient is final AND whose weights the rest of this backward no longer reads from
+        # the flat parameter buffer (input-gradient operands are copies made before): the trainer may all-reduce and UPDATE that suffix
+        self.progress: Optional[Callable[[int], None]] = None
 
     def done(self, off: int) -> None:
         if self.progress is not None:
@@ -415,8 +417,8 @@ class Engine:
         if tape is not None:
             def bw(gy: torch.Tensor) -> Optional[torch.Tensor]:
                 self._wg(x, gy, rec, g, DTYPE_F32)
-                tape.done(rec.w_off)
                 if not need_dx:
+                    tape.done(rec.w_off)
                     return None
                 if rec.rows >= self.LINEAR_DGRAD_SPLIT_MIN_ROWS and rec.kstride == rec.cin:
                     # few rows, very long reduction (proj: B x 8448 -> 512): as a forward GEMM that is 4 workgroups walking
@@ -432,10 +434,14 @@ class Engine:
                     wmat = self._w(rec, DTYPE_F32)
                     self._on_grad_stream(lambda: ops.conv_wgrad(wmat, gyT, dx, gt, DTYPE_F32, workspace=self.workspace()), gyT, dx)
                     self.join_grad_stream()
+                    # only now: this route reads the layer's weights from the flat buffer itself, and "done" may start the
+                    # optimizer on them (Trainer: the update chases the backward)
+                    tape.done(rec.w_off)
                     return dx
                 dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
                 gd = self._geom(rows, 1, 1, rec.dg_ld, 1, 1, rec.cin, rec.cin, rec.cin, CONV_1X1)
                 ops.conv(gy, self._wT(rec, DTYPE_F32), None, dx, gd, DTYPE_F32)
+                tape.done(rec.w_off)
                 return dx
             tape.steps.append(bw)
         return y
@@ -555,7 +561,6 @@ class Engine:
                     self._wg(h1, gy, r2, g2, dt)
                     da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=d1, mulmode=mulmode)
                     self._wg(h0, da1, r1, g1, dt)
-                    tape.done(r1.w_off)
                     dm = dm_all.view(-1)[b.mod_offset:]
                     # conv1's input gradient feeds LN's backward directly: fused into the conv epilogue where the kernel
                     # holds whole channel rows (128-channel levels in bf16), a separate pass otherwise
@@ -565,6 +570,7 @@ class Engine:
                         dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                         dx = torch.empty_like(dh0)
                         ops.ln_backward(dh0, xin, m, gy, dx, dm, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
+                    tape.done(r1.w_off)  # behind the block's last launch: "done" = gradients final AND weights (copies included) no longer read
                     return dx
                 tape.steps.append(bw)
             return out, hn
@@ -595,9 +601,9 @@ class Engine:
                     delta = torch.empty((npix,), dtype=torch.float32, device=dev)
                     ops.attention_backward(qkv, o, do, lse, delta, dqkv, B, Tn, Cc, dt)
                     self._wg(hl, dqkv, rq, gq, dt)
-                    tape.done(rq.w_off)
                     dhl = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(dqkv, self._wT(rq, dt), None, dhl, self._geom(npix, 1, 1, 3 * Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
+                    tape.done(rq.w_off)
                     dx = torch.empty_like(dhl)
                     ops.ln_backward(dhl, xin, None, gy, dx, None, npix, Tn, Cc, 0, LN_EPS, self.ln_unbiased, dt)
                     return dx
@@ -611,10 +617,9 @@ class Engine:
         if train:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
                 self._wgrad(rec, x0, gy, g, dt)
+                dx0 = dgrad(rec, gy, H, W, H, W, CONV_S1, lay.cin_pad) if want_dx else None
                 tape.done(rec.w_off)
-                if not want_dx:
-                    return None
-                return dgrad(rec, gy, H, W, H, W, CONV_S1, lay.cin_pad)
+                return dx0
             tape.steps.append(bw_head0)
         def mod_of(b: BlockSpec):
             return ("mod", m_all.view(-1)[b.mod_offset:])
@@ -643,9 +648,10 @@ class Engine:
                 if train:
                     def bw_head(gy, xin=xin, g=g_h, rec=r_h, Hp=Hp, Wp=Wp, Hc=Hc, Wc=Wc, lvl=i - 1):
                         self._wg(xin, gy, rec, g, dt)
-                        tape.done(rec.w_off)
                         # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
-                        return dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
+                        dxs = dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
+                        tape.done(rec.w_off)
+                        return dxs
                     tape.steps.append(bw_head)
             cur, _ = run_blocks(lv.descent, cur, Hc, Wc, None, None)
             if i < L - 1:
@@ -680,7 +686,6 @@ class Engine:
                     def bw_tail(gy, xin=xin, hl=hl, g=g_t, rec=r_t, Hl=Hl, Wl=Wl, Hu=Hc, Wu=Wc, Cc=Cc, lvl=i - 1):
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient
                         self._wg(hl, gy, rec, g, dt)
-                        tape.done(rec.w_off)
                         # gradient w.r.t. the low-resolution map = 2x2 sums of the gradient w.r.t. its upsampling (adjoint of Upsample):
                         # summed in the input-gradient kernel's epilogue where it supports that -- the full-resolution gradient is
                         # then never written (537 MB at the top level) -- else a pooling pass behind it
@@ -693,6 +698,7 @@ class Engine:
                             ops.sumpool2(gu, gl, B, Hl, Wl, Cc, dt)
                         dx = torch.empty_like(gl)
                         ops.ln_backward(gl, xin, None, None, dx, None, B * Hl * Wl, Hl * Wl, Cc, 0, LN_EPS, self.ln_unbiased, dt)
+                        tape.done(rec.w_off)
                         return dx
                     tape.steps.append(bw_tail)
             else:
@@ -703,8 +709,9 @@ class Engine:
                         gw = dict(g)
                         gw["Cout"] = rec.rows
                         self._wg(xin, gy, rec, gw, dt)
+                        dxt = dgrad(rec, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                         tape.done(rec.w_off)
-                        return dgrad(rec, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc)
+                        return dxt
                     tape.steps.append(bw_tail0)
         if train:
             tape.meta.update(B=B, C=C, H=H, W=W, dt=dt, out_nhwc=cur, ldm=ldm, Bt=Bt)
@@ -728,12 +735,13 @@ class Engine:
             gz = torch.empty_like(z)
             ops.silu_backward(z, gh, gz, z.numel(), DTYPE_F32)
             self._wg(x, gz, rec, g, DTYPE_F32)
-            tape.done(rec.w_off)
             if not need_dx:
+                tape.done(rec.w_off)
                 return None
             dx = torch.empty((rows, rec.cin), dtype=torch.float32, device=x.device)
             ops.conv(gz, self._wT(rec, DTYPE_F32), None, dx, self._geom(rows, 1, 1, rec.dg_ld, 1, 1, rec.cin, rec.cin, rec.cin, CONV_1X1),
                      DTYPE_F32)
+            tape.done(rec.w_off)
             return dx
         tape.steps.append(bw)
         return h
@@ -744,6 +752,13 @@ class Engine:
         [B*H*W][cout_pad] (padding channels zero).  Parameter gradients are ACCUMULATED into ``flat_grad``."""
         if self.flat_grad is None:
             raise RuntimeError("call ensure_grad_buffer() before backward")
+        # Build the input-gradient operands (transposed copies of ALL weights, read from the flat buffer) before the first launch on
+        # the gradient stream: whoever updates a finished part of the flat buffer from that stream while backward is still running
+        # (Trainer: optimizer chasing the backward) is then ordered behind these reads by the stream's first wait on this one.
+        for grp_lin in (False, True):
+            rec0 = next((r for r in self.layout.convs.values() if r.dg_off >= 0 and r.lin == grp_lin), None)
+            if rec0 is not None:
+                self._wT(rec0, DTYPE_F32 if grp_lin else tape.meta["dt"])
         steps = tape.steps
         n_mlp = 3  # map_layer0, map_layer1, proj were recorded first
         g = gy_nhwc

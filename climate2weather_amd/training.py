@@ -94,18 +94,35 @@ class Trainer:
             end = start
         self._works: list = []
         self._next_bucket = 0
+        self._chase = None  # (lr, step) while the optimizer update chases the backward of the current round
+        # Opt-in (C2W_CHASE_OPT=1 or the attribute): measured on one MI355X it buys nothing -- 50.8-50.9 ms per step either way; the step is
+        # bound by the clock the chip holds under the MFMA load, and the update's HBM stream next to it lowers that clock further.
+        self.chase_optimizer = os.environ.get("C2W_CHASE_OPT", "0") == "1"
 
-    # ------------------------------------------------------------------ gradient all-reduce, overlapped with backward
+    # ------------------------------------------------------------------ all-reduce and optimizer, both chasing the backward
+    # The flat gradient buffer is laid out in reverse finalisation order, so what backward has finished is a growing SUFFIX.  Per
+    # 25-MB bucket of it, as soon as it is final: (multi-GPU) sum it over the ranks with RCCL, then run the fused AdamW + EMA + 16-bit
+    # shadow kernel on exactly that range -- both on the gradient stream, i.e. next to the rest of the backward instead of behind it
+    # (the update is a pure HBM stream of 7 arrays: 0.53 ms per step that the MFMA-bound input-gradient chain hides).  The rest of the
+    # backward never reads the flat parameters again (engine.Tape.progress), only its own copies of them.
     def _on_progress(self, off: int) -> None:
         while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off:
             s, e = self.buckets[self._next_bucket]
             # issued from the stream the gradients are written on (engine.grad_stream): RCCL orders the collective behind the
             # weight-gradient launches of this bucket without stalling the input-gradient chain on the main stream
+            # (every write into the flat gradient buffer is enqueued on that stream, so stream order IS the dependency; no wait on the
+            # main stream: the rest of the backward reads copies of the weights, never the flat buffer the update writes)
             side = self.eng.grad_stream()
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                self._works.append(dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                work = None
+                if self.sync_grads:
+                    work = dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if self._chase is not None:
+                    if work is not None:
+                        work.wait()  # the gradient stream waits for the collective, not the host
+                    self._update_range(s, e, *self._chase)
+                elif work is not None:
+                    self._works.append(work)
             self._next_bucket += 1
 
     def _finish_allreduce(self) -> None:
@@ -114,6 +131,15 @@ class Trainer:
             w.wait()
         self._works.clear()
         self._next_bucket = 0
+
+    def _update_range(self, s: int, e: int, lr: float, step: int) -> None:
+        """Fused AdamW (train.py:176-181) + EMA (src/thor/ema.py:23-27) + 16-bit shadow refresh on flat[s:e], on the current stream."""
+        eng = self.eng
+        shadow = eng.shadows.get(self.dt) if self.dt != DTYPE_F32 else None
+        ema = self.ema_flats[0][s:e] if self.ema_flats else None
+        ops.adamw_ema(eng.flat[s:e], eng.flat_grad[s:e], self.m[s:e], self.v[s:e], ema, shadow[s:e] if shadow is not None else None, e - s,
+                      float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, step,
+                      float(self.ema_rates[0]) if self.ema_rates else 0.0, 1.0 / self.world, scaler=self.scaler)
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, batches, t: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -125,24 +151,29 @@ class Trainer:
             batches = [batches]
         eng = self.eng
         eng.flat_grad.zero_()
-        loss = None
-        for r, x in enumerate(batches):
-            last = r == len(batches) - 1
-            loss = self._forward_backward(x, t if last or t is None else None, eps if last or eps is None else None,
-                                          sync=last and self.sync_grads)
-        if self.sync_grads:
-            self._finish_allreduce()
         lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
         self.step_count += 1
         n = eng.layout.numel
-        shadow = eng.shadow_for(self.dt) if self.dt != DTYPE_F32 else None
-        if self.scaler is not None:  # after the all-reduce: inf/nan survive the sum, so every rank takes the same decision
-            ops.grad_scaler_check(eng.flat_grad, n, self.scaler)
-        ops.adamw_ema(eng.flat, eng.flat_grad, self.m, self.v, self.ema_flats[0] if self.ema_flats else None, shadow, n, float(lr),
-                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
-                      float(self.ema_rates[0]) if self.ema_rates else 0.0, 1.0 / self.world, scaler=self.scaler)
-        if self.scaler is not None:
-            ops.grad_scaler_update(self.scaler, *self.scaler_cfg)
+        shadow = eng.shadow_for(self.dt) if self.dt != DTYPE_F32 else None  # exists (and is current) before the update writes into it
+        # the update chases the backward unless the dynamic loss scale must first see the WHOLE gradient (fp16: inf/nan check)
+        chase = self.chase_optimizer and self.scaler is None
+        loss = None
+        for r, x in enumerate(batches):
+            last = r == len(batches) - 1
+            self._chase = (lr, self.step_count) if (chase and last) else None
+            loss = self._forward_backward(x, t if last or t is None else None, eps if last or eps is None else None,
+                                          sync=last and (self.sync_grads or chase))
+        if self.sync_grads or chase:
+            self._finish_allreduce()
+        self._chase = None
+        if chase:
+            eng.join_grad_stream()  # the last buckets' updates were enqueued after backward's own join
+        else:
+            if self.scaler is not None:  # after the all-reduce: inf/nan survive the sum, so every rank takes the same decision
+                ops.grad_scaler_check(eng.flat_grad, n, self.scaler)
+            self._update_range(0, n, lr, self.step_count)
+            if self.scaler is not None:
+                ops.grad_scaler_update(self.scaler, *self.scaler_cfg)
         for rate, e in zip(self.ema_rates[1:], self.ema_flats[1:]):
             ops.ema_update(e, eng.flat, n, float(rate))
         eng.weights_changed(shadow_fresh=self.dt if shadow is not None else None)

@@ -112,6 +112,25 @@ def test_resume_from_a_reference_made_training_state_checkpoint(emu, golden_dir)
     resume_from_reference_checkpoint(golden_dir, torch.device("cpu"), lambda seed: _tiny(seed=seed))
 
 
+@pytest.mark.parametrize("bucket_mb", [48.0, 0.05])
+def test_optimizer_chasing_the_backward_equals_the_update_after_it(emu, golden_dir, bucket_mb):
+    """Trainer.chase_optimizer: per finished bucket of the flat gradient buffer the fused AdamW + EMA kernel runs while backward is
+    still going (the rest of the backward reads copies of the weights, never the flat buffer: engine.Tape.progress).  Same
+    parameters, moments, EMA and loss as the update behind the backward -- with 22 buckets cutting through layers."""
+    g = _golden(golden_dir, "tiny_net.npz")
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    outs = []
+    for chase in (False, True):
+        net = _tiny()
+        tr = Trainer(net, lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=bucket_mb)
+        tr.chase_optimizer = chase
+        losses = [float(tr.step(x, t=t.reshape(-1), eps=eps)) for _ in range(2)]
+        outs.append((losses, tr.eng.flat.clone(), tr.m.clone(), tr.v.clone(), tr.ema_flats[0].clone()))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
