@@ -47,7 +47,7 @@
 #define C2W_T3_STAGGER 0  // x 8128 cycles: start delay of the second workgroup of every CU (see the kernel entry)
 #endif
 #ifndef C2W_EXP
-#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA
+#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA, 8 no stage barrier
 #endif             // in the loop, 32 no epilogue (accumulators reduced to one store per lane)
 
 namespace {
@@ -214,11 +214,12 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         const int li_ = l & 15;
         return (uint32_t)(CF::PBYTES + (wm * 64 + li_) * 64 + (((uint32_t)(l >> 4) ^ t3_wswz(li_)) << 4));
     };
-    // (the three pixel-fragment bases are recomputed from the lane id where a stage needs one -- six VALU operations per stage -- rather
-    // than held: the two-group schedule has no register left for them, and a spilled one comes back through scratch behind a vmcnt(0))
+    // (experiment builds recompute the three pixel-fragment bases from the lane id where a stage needs one -- six VALU operations per
+    // stage -- rather than hold them: the two-group schedule has no register left, and a spilled one comes back through scratch behind a
+    // vmcnt(0))
     auto offB_at = [&](int kw) {
         int l = lane;
-        asm volatile("" : "+v"(l));
+        if constexpr ((NW == 8 && (C2W_T3_PP) != 0) || C2W_T3_RING == 4) asm volatile("" : "+v"(l));  // default: hoisted and held
         const int px = (l & 15) + kw;
         return (uint32_t)((wn * 4 * NB * T3_PW + px) * 128 + (((uint32_t)(l >> 4) ^ t3_pswz(px)) << 4));
     };
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         // everything but the next stage's (stages') weight pieces has landed
         if constexpr (RING == 3) t3_wait<CF::WPIECES>(s + 1 < NS);
         else t3_wait_n<CF::WPIECES>(NS - 1 - s);
-        __builtin_amdgcn_s_barrier();
+        if constexpr ((C2W_EXP & 8) == 0) __builtin_amdgcn_s_barrier();
         bool ahead = s + DIST < NS;
         if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
             issue_patch(c);
