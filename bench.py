@@ -350,10 +350,10 @@ def run_rank(a):
                         launches_timed=int(round(kf["launches_per_step"] * a.steps)), avg_launch_ms=kf["avg_ms"],
                         flops_per_launch=kf["gflop_per_launch"] * 1e9,
                         traffic=None,
-                        from_profile=dict(note="NOT measured in this run: PMC passes of the same kernel and shape on another box (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
-                                               "correction + WRITE_SIZE); algorithmic bytes are 537 MB in + 537 MB out per launch",
-                                          source="profiles/r01k_pmc_conv_patch3_b128.md", traffic_bytes_per_launch=1.059e9, mfma_busy=0.61,
-                                          clock_ghz_under_load=1.73) if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
+                        from_profile=dict(note="NOT measured in this run: PMC passes of the same kernel and shape (bias-only epilogue) on another box (rocprofv3 --pmc, "
+                                               "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); algorithmic bytes are 537 MB in + 537 MB out per launch",
+                                          source="profiles/r02_pmc_conv_patch3.md", traffic_bytes_per_launch=1.057e9, mfma_busy=0.62,
+                                          clock_ghz_under_load=1.75) if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
                         all_launches=dict(note="forward + input-gradient launches of the same layers; the latter overlap the weight-gradient stream",
                                           launches_timed=int(round(all_n * a.steps)), avg_launch_ms=round(all_ms / all_n, 4) if all_n else None,
                                           achieved=round(all_tf, 1), frac=round(all_tf / MFMA_PEAK_TFLOPS, 4)))

@@ -253,6 +253,9 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     //     22 ds_read_b128 per three stages instead of 36 (LDS bytes read per MFMA 0.23 KB instead of 0.375 KB).
     //   C2W_T3V & 1: the LDS-DMA of stage s + 2 is issued behind the stage's fragment reads instead of in front of them;
     //   C2W_T3V & 4: behind the first half of the stage's MFMAs (the ring slot it fills was released by the stage's barrier).
+#if C2W_EXP & 64
+    uint32_t t3_dummy0 = lane;
+#endif
     u32x4_t bq[4 * NB + 2];
     u32x4_t a_held[4];  // group 1 only: the weight fragments live across the barrier
     // C2W_T3_PP (NW = 8 only): the waves of a workgroup run in two groups, one per SIMD each.  Group 0 reads the fragments of stage
@@ -289,6 +292,9 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
 #pragma unroll
             for (int n = 0; n < 4 * NB; ++n) {
                 hook(n);
+#if C2W_EXP & 64  // 16 independent VALU operations per stage next to the MFMAs: do they take matrix-pipe issue slots?
+                asm volatile("v_add_u32 %0, %0, 1\n\tv_xor_b32 %0, 5, %0\n\tv_add_u32 %0, %0, 3\n\tv_xor_b32 %0, 9, %0" : "+v"(t3_dummy0));
+#endif
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     if constexpr ((C2W_EXP & 1) == 0) {
@@ -401,6 +407,9 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     }
 #undef T3_CHUNK_LOOP
     T3_STAMP(2);
+#if C2W_EXP & 64
+    if (t3_dummy0 == 0x12345u) ((uint32_t*)p.y)[tid] = t3_dummy0;
+#endif
 
     if constexpr ((C2W_EXP & 32) != 0) {
         f32x4_t t = acc[0][0][0];

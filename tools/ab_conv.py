@@ -15,6 +15,8 @@ B = int(os.environ.get("B", "128"))
 ROUNDS = int(os.environ.get("ROUNDS", "7"))
 ACT = int(os.environ.get("ACT", "0"))
 BIAS = int(os.environ.get("BIAS", "1"))
+F16 = int(os.environ.get("F16", "0"))  # 1: fp16 operands (same MFMA rate; some experiment builds only fit the fp16 instantiation)
+TD = torch.float16 if F16 else torch.bfloat16
 S1, S2, UP, TS2, X1 = _lib.CONV_S1, _lib.CONV_S2, _lib.CONV_UP, _lib.CONV_TS2, _lib.CONV_1X1
 
 
@@ -38,20 +40,20 @@ st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for (mode, H, Cin, Cout) in SHAPES:
     Ho = H // 2 if mode == S2 else (H * 2 if mode in (UP, TS2) else H)
     taps = 1 if mode == X1 else 9
-    x = torch.randn(B * H * H, Cin, device=dev).bfloat16()
-    w = (torch.randn(Cout, taps, Cin, device=dev) / math.sqrt(taps * Cin)).bfloat16()
+    x = torch.randn(B * H * H, Cin, device=dev).to(TD)
+    w = (torch.randn(Cout, taps, Cin, device=dev) / math.sqrt(taps * Cin)).to(TD)
     if os.environ.get("ZERO"):  # all-zero operands: same instruction stream, far less switching energy -> shows what the clock governor takes
         x.zero_()
         w.zero_()
     bias = torch.randn(Cout, device=dev)
-    ys = [torch.empty(B * Ho * Ho, Cout, device=dev, dtype=torch.bfloat16) for _ in libs]
+    ys = [torch.empty(B * Ho * Ho, Cout, device=dev, dtype=TD) for _ in libs]
     mac_pix = B * Ho * Ho if mode != TS2 else B * H * H
     gf = 2.0 * mac_pix * Cout * taps * Cin / 1e9
 
     def run(lib, y):
         a = ConvArgs(x.data_ptr(), w.data_ptr(), bias.data_ptr() if BIAS else None, None, None, y.data_ptr(), None, B, H, H, Cin, Ho, Ho, Cout, Cout, Cout,
                      mode, ACT, 0)
-        rc = lib.c2w_conv_forward(ctypes.byref(a), 1, 0, st)
+        rc = lib.c2w_conv_forward(ctypes.byref(a), _lib.DTYPE_F16 if F16 else _lib.DTYPE_BF16, 0, st)
         assert rc == 0, rc
 
     times = [[] for _ in libs]
