@@ -37,6 +37,12 @@
 #define C2W_T3_RING 3  // weight ring slots = stages of LDS-DMA prefetch + 1 (3: 70.7 KB of LDS, 4: 78.8 KB; both two workgroups per CU).
                        // 4 measured 7-15 % SLOWER with eight waves (profiles/r02_experiments.md): the L2 -> LDS latency (~0.76 us) is covered by two stages
 #endif
+#ifndef C2W_T3_DIRECT
+#define C2W_T3_DIRECT 0  // elementwise epilogues of the 16x16 tile stored straight from the accumulators (t3_epi_direct)
+#endif
+#ifndef C2W_T3_EPI2
+#define C2W_T3_EPI2 0  // epilogue of the 16x16 tile: operand rows of both 8-row blocks requested up front
+#endif
 #ifndef C2W_T3_PP
 #define C2W_T3_PP 0  // two-group schedule of the 8-wave kernel (see `stage`): 1 groups = waves 0-3 / 4-7, 2 = even / odd waves
 #endif
@@ -118,7 +124,133 @@ template <int WPIECES> __device__ __forceinline__ void t3_wait_n(int ahead) {
     }
 }
 
-template <int TR, typename T = bf16_t, int NW = 4>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
+
+// ---- elementwise epilogues straight from the accumulators (C2W_T3_DIRECT) ------------------------------------------------------------
+// In the MFMA layout a lane holds 4 consecutive output channels of one pixel (8 B in a 16-bit type); the four co-tiles of a wave are
+// the four 32-B quarters of a pixel's 128-B half row.  Bias / activation / multiplier / residual / second output need nothing from
+// another lane, so a wave can stream its 64 x 64 tile out as 8-B buffer stores the moment ITS MFMAs are done: no LDS staging, no
+// workgroup barrier, early waves store while late ones still multiply.  L2 merges the four quarters (written back to back by one
+// wave) into whole lines before they reach HBM.  Same arithmetic in the same order as epi_acc_to_lds + EpiStore::finish (including
+// the rounding to the storage type between the two), so both paths give the same bits.
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2e_t;
+
+template <typename T, int ACTK, int NB>
+__device__ __forceinline__ void t3_epi_direct(const C2wConvArgs& p, f32x4_t (&acc)[NB][4][4], long long tile_off, int row0, int W, int co0, int co_l,
+                                              int li) {  // co_l: the lane's first channel relative to the tile's first channel co0
+    constexpr int ESZ = 2;
+    const uint32_t span = 0x7ffffff0u;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc((char*)p.y + tile_off, span);
+    const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(p.y2 != nullptr ? (char*)p.y2 + tile_off : nullptr, p.y2 != nullptr ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.res != nullptr ? (const char*)p.res + tile_off : nullptr, p.res != nullptr ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rmul = make_rsrc(p.mul != nullptr ? (const char*)p.mul + tile_off : nullptr, p.mul != nullptr ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias != nullptr ? p.bias + co0 : nullptr, p.bias != nullptr ? (uint32_t)(p.wrows - co0) * 4u : 0u);  // no bias / rows past wrows read 0
+    const bool has_res = p.res != nullptr, has_mul = p.mul != nullptr;
+    const uint32_t pitch = (uint32_t)p.ldy * ESZ;
+    const uint32_t vlane = (uint32_t)li * pitch + (uint32_t)co_l * ESZ;
+    uint32_t vo[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) vo[m] = co0 + co_l + m * 16 < p.Cout ? vlane + m * 32 : C2W_OOB;
+    constexpr int NR = 4 * NB;
+    u32x2e_t R[2][4], M[2][4];
+    auto load_row = [&](int n, int buf) {
+        const int soff = (row0 + n) * W * (int)pitch;
+        if (has_res) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) R[buf][m] = __builtin_amdgcn_raw_buffer_load_b64(rres, vo[m], soff, 0);
+        }
+        if (has_mul) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) M[buf][m] = __builtin_amdgcn_raw_buffer_load_b64(rmul, vo[m], soff, 0);
+        }
+    };
+    {   // the bias goes into the accumulators once (16 registers that would otherwise live through all rows)
+        f32x4_t bv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bv[m] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, (co_l + m * 16) * 4, 0, 0));
+        load_row(0, 0);
+        load_row(1, 1);
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n >> 2][m][n & 3] += bv[m];
+    }
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int soff = (row0 + n) * W * (int)pitch;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[n >> 2][m][n & 3][r];
+                if constexpr (ACTK == 1) v[r] = silu_f(v[r]);
+                if constexpr (ACTK == 2) v[r] = fmaxf(v[r], 0.f);
+            }
+            u32x2e_t pk = (u32x2e_t){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+            if (has_mul || has_res) {
+                float f[4];
+                unpack2<T>(pk[0], f[0], f[1]);
+                unpack2<T>(pk[1], f[2], f[3]);
+                if (has_mul) {
+                    float gm[4];
+                    unpack2<T>(M[n & 1][m][0], gm[0], gm[1]);
+                    unpack2<T>(M[n & 1][m][1], gm[2], gm[3]);
+                    if (p.mulmode == C2W_MUL_DSILU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] *= dsilu_f(gm[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] *= gm[r];
+                    }
+                }
+                if (has_res) {
+                    float gr[4];
+                    unpack2<T>(R[n & 1][m][0], gr[0], gr[1]);
+                    unpack2<T>(R[n & 1][m][1], gr[2], gr[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] += gr[r];
+                }
+                pk = (u32x2e_t){pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3])};
+            }
+            if ((p.act == C2W_ACT_SILU_PAIR || p.act == C2W_ACT_RELU_PAIR) && p.y2 != nullptr) {
+                float a_[4], h_[4], d_[4];
+                unpack2<T>(pk[0], a_[0], a_[1]);
+                unpack2<T>(pk[1], a_[2], a_[3]);
+                if (p.act == C2W_ACT_SILU_PAIR) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sg = sigmoid_f(a_[r]);
+                        h_[r] = a_[r] * sg;
+                        d_[r] = sg + h_[r] * (1.0f - sg);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h_[r] = fmaxf(a_[r], 0.f);
+                        d_[r] = a_[r] > 0.f ? 1.f : 0.f;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2e_t){pack2<T>(h_[0], h_[1]), pack2<T>(h_[2], h_[3])}, ry, vo[m], soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2e_t){pack2<T>(d_[0], d_[1]), pack2<T>(d_[2], d_[3])}, ry2, vo[m], soff, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(pk, ry, vo[m], soff, 0);
+                if (p.y2 != nullptr) {
+                    float f2[4];
+                    unpack2<T>(pk[0], f2[0], f2[1]);
+                    unpack2<T>(pk[1], f2[2], f2[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f2[r] = silu_f(f2[r]);
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2e_t){pack2<T>(f2[0], f2[1]), pack2<T>(f2[2], f2[3])}, ry2, vo[m], soff, 0);
+                }
+            }
+        }
+        if (n + 2 < NR) load_row(n + 2, n & 1);
+    }
+}
+
+// DIRECT: the instantiation whose epilogue is t3_epi_direct (picked by the launcher for the flavours it covers; a kernel of its own
+// because the register allocator, given both epilogues behind one loop, spills accumulators INSIDE the loop)
+template <int TR, typename T = bf16_t, int NW = 4, bool DIRECT = false>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
 __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv_patch_t3_kernel(const C2wConvArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     typedef T3Cfg<TR, NW> CF;
@@ -422,6 +554,16 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         if (t[0] + t[1] + t[2] + t[3] == 12345.678f) ((float*)p.y)[tid] = t[0];
         return;
     }
+    if constexpr (DIRECT) {
+        static_assert(TR == 16, "16x16 tiles only");
+        int lane_d = tid;
+        asm volatile("" : "+v"(lane_d));
+        lane_d &= 63;
+        const long long tile_off = ((((long long)b * H + oh0) * W + ow0) * p.ldy + co0) * ESZ;
+        const int co_l = wm * 64 + (lane_d >> 4) * 4;  // relative to the tile's first channel
+        t3_epi_direct<T, 0, NB>(p, acc, tile_off, wn * 4 * NB, W, co0, co_l, lane_d & 15);
+        return;
+    }
     // epilogue: the residual / multiplier rows are fetched AFTER the accumulators have left the registers (the half-tile
     // kernel prefetches them next to live accumulators; that does not fit here) -- the co-resident workgroups cover the
     // exposed latency.  Output rows go through LDS in blocks of 128 (= 8 tile rows), one EpiStore pass each.
@@ -441,8 +583,39 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T3_STAMP(7);
 #endif
+#if C2W_T3_EPI2
+    // both 8-row blocks' residual / multiplier rows are requested before the first block is finished: the second block's HBM latency
+    // runs behind the first block's arithmetic and stores (the accumulators have left the registers, so both sets fit)
+    if constexpr (CF::NPASS == 2) {
+        const bool pool2 = (p.flags & C2W_CONV_POOL2) != 0;
+        EpiStore<T, 128, T3_NTHR> est0, est1;
+        if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
+        if (!pool2) {
+            est0.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0) * W + ow0, W);
+            est1.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8) * W + ow0, W);
+        }
+        __syncthreads();
+        T3_STAMP(5);
 #pragma unroll
-    for (int h = 0; h < CF::NPASS; ++h) {
+        for (int h = 0; h < 2; ++h) {
+            auto& est = h == 0 ? est0 : est1;
+            const char* const Oh = O + h * 128 * T3_OS;
+            if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
+            else if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
+            else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+            else est.finish(p, Oh, T3_OS, tid_e);
+            if (h == 0 && p.ln_x != nullptr) {  // the LayerNorm column sums are re-zeroed for the second block only after everyone read them
+                __syncthreads();
+                if (tid_e < 128) red[tid_e] = 0.f;
+                __syncthreads();
+            }
+            if (h == 0) T3_STAMP(6);
+        }
+    } else
+#endif
+    {
+#pragma unroll
+        for (int h = 0; h < CF::NPASS; ++h) {
         if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
         EpiStore<T, 128, T3_NTHR> est;
         const bool pool2 = (p.flags & C2W_CONV_POOL2) != 0;
@@ -455,6 +628,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
         else est.finish(p, Oh, T3_OS, tid_e);
         if (h + 1 < CF::NPASS) __syncthreads();  // the LayerNorm column sums are re-zeroed for the next block only after everyone read them
+    }
     }
 #if C2W_EXP & 16
     T3_STAMP(3);
@@ -469,18 +643,32 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
 #endif
 }
 
-template <int TR, typename T, int NW>
-int t3_launch(const C2wConvArgs& a, hipStream_t st) {
+// the flavours t3_epi_direct covers: everything elementwise whose activation is none or one of the pair forms
+inline bool t3_direct_flavour(const C2wConvArgs& a) {
+    return a.ln_x == nullptr && a.lnf_y == nullptr && (a.flags & C2W_CONV_POOL2) == 0 && a.act != C2W_ACT_SILU && a.act != C2W_ACT_RELU;
+}
+
+template <int TR, typename T, int NW, bool DIRECT>
+int t3_launch_as(const C2wConvArgs& a, hipStream_t st) {
     typedef T3Cfg<TR, NW> CF;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr = true;
     }
     const int nN = (a.Cout + 127) / 128;
     const int nM = a.B * (a.Hout / TR) * (a.Wout >> 4);
-    conv_patch_t3_kernel<TR, T, NW><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
+    conv_patch_t3_kernel<TR, T, NW, DIRECT><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
     return (int)hipGetLastError();
+}
+
+template <int TR, typename T, int NW>
+int t3_launch(const C2wConvArgs& a, hipStream_t st) {
+#if C2W_T3_DIRECT
+    static const bool off = getenv("C2W_T3_NO_DIRECT") != nullptr;
+    if (TR == 16 && !off && t3_direct_flavour(a)) return t3_launch_as<16, T, NW, true>(a, st);
+#endif
+    return t3_launch_as<TR, T, NW, false>(a, st);
 }
 
 }  // namespace
