@@ -130,6 +130,13 @@ class DeviceWindowFeed:
         self._ar = torch.arange(self.window, device=device)
 
     def next_batch(self, batch: int) -> torch.Tensor:
-        idx = torch.tensor([next(self.sampler) for _ in range(batch)], device=self.data.device)
+        idx = torch.tensor([next(self.sampler) for _ in range(batch)], dtype=torch.int64)
+        if self.data.is_cuda:
+            # pinned + asynchronous: a pageable host -> device copy blocks the host until the stream reaches it, i.e. until the PREVIOUS
+            # training step has finished on the GPU -- the launch queue then runs dry once per step (0.5 ms of 50.6, rocprof trace).
+            # The pinned block belongs to torch's caching host allocator, which does not hand it out again before the copy has run.
+            idx = idx.pin_memory().to(self.data.device, non_blocking=True)
+        else:
+            idx = idx.to(self.data.device)
         frames = self.data[(idx[:, None] + self._ar[None, :])]  # (B, w, F, H, W)
         return frames.flatten(1, 2)

@@ -95,6 +95,10 @@ class Trainer:
         self._works: list = []
         self._next_bucket = 0
         self._chase = None  # (lr, step) while the optimizer update chases the backward of the current round
+        # Host run-ahead is bounded to ONE step: step k is enqueued while step k - 1 runs (no launch bubble at the step boundary), but
+        # not before step k - 2 has finished -- further ahead, the blocks the gradient stream still holds (record_stream) are not
+        # reusable yet and the caching allocator answers every request with a fresh, synchronising hipMalloc (measured: 210 ms/step).
+        self._step_done: List[torch.cuda.Event] = []
         # Opt-in (C2W_CHASE_OPT=1 or the attribute): measured on one MI355X it buys nothing -- 50.8-50.9 ms per step either way; the step is
         # bound by the clock the chip holds under the MFMA load, and the update's HBM stream next to it lowers that clock further.
         self.chase_optimizer = os.environ.get("C2W_CHASE_OPT", "0") == "1"
@@ -150,6 +154,8 @@ class Trainer:
         if isinstance(batches, torch.Tensor):
             batches = [batches]
         eng = self.eng
+        if len(self._step_done) >= 2:
+            self._step_done.pop(0).synchronize()
         eng.flat_grad.zero_()
         lr = self.lr_fn(self.cur_ndata) if self.lr_fn is not None else self.lr
         self.step_count += 1
@@ -179,6 +185,10 @@ class Trainer:
         eng.weights_changed(shadow_fresh=self.dt if shadow is not None else None)
         B = sum(b.shape[0] for b in batches)
         self.cur_ndata += self.batch_size if self.batch_size is not None else B * self.world
+        if eng.flat.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_done.append(ev)
         return loss
 
     def _forward_backward(self, x, t, eps, sync: bool) -> torch.Tensor:

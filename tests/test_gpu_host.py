@@ -321,6 +321,13 @@ def test_graph_replayed_score_function_equals_eager(golden_dir):
         outs.append(pipe.sample(sf, torch.from_numpy(s["cond_c0.noise"]), steps=4, corrections=0, tau=0.5, device=dev, show_progressbar=False))
         if graphs:
             assert len(sf._graphs) == 1 and len(next(iter(sf._graphs.values()))["graphs"]) == 2
+            # a second trajectory (another tensor, another address: the next ensemble member) replays the SAME captures
+            first = next(iter(sf._graphs.values()))["graphs"]
+            keep = torch.empty(1 << 20, device=dev)  # shifts the allocator so that the new trajectory cannot land on the old address
+            again = pipe.sample(sf, torch.from_numpy(s["cond_c0.noise"]).clone(), steps=4, corrections=0, tau=0.5, device=dev, show_progressbar=False)
+            assert next(iter(sf._graphs.values()))["graphs"] is first and len(sf._graphs) == 1
+            assert torch.equal(again, outs[1])
+            del keep
     assert torch.equal(outs[0], outs[1])
     ref = torch.from_numpy(s["cond_c0.x"])
     assert (outs[1].cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
