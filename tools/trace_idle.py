@@ -1,14 +1,19 @@
 """GPU idle time per training step from a rocprofv3 --kernel-trace CSV: wall time between optimizer launches minus the union of the
 kernel intervals, the gaps by size and the kernels on both sides of the largest ones.
 
-    python tools/trace_idle.py gpurun_out/prof/xyz_kernel_trace.csv
+    python tools/trace_idle.py gpurun_out/prof/xyz_kernel_trace.csv [marker kernel substring]
 """
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:80]) for r in rows)
-ends = [e for s, e, n in ev if "adamw_ema" in n]
-n = min(4, len(ends) - 1)
-t0, t1 = ends[-1 - n], ends[-1]
+marker = sys.argv[2] if len(sys.argv) > 2 else "adamw_ema"  # a kernel that runs once per step
+ends = [e for s, e, n in ev if marker in n]
+if len(ends) >= 2:
+    n = min(4, len(ends) - 1)
+    t0, t1 = ends[-1 - n], ends[-1]
+else:  # no per-step marker: the second half of the trace as one window
+    n = 1
+    t0, t1 = ev[len(ev) // 2][0], ev[-1][1]
 sel = [(s, e, k) for s, e, k in ev if s >= t0 and e <= t1]
 busy, (cs, ce, ck) = 0, sel[0]
 gaps = []
