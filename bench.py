@@ -371,6 +371,27 @@ def run_rank(a):
             out["mfma_frac_whole_step"] = round(tf / world / MFMA_PEAK_TFLOPS, 4)
 
     extras = not a.no_extras
+    # ---- what a plain dense GEMM of the vendor library reaches on THIS chip in THIS run (outside the headline region): the clock the
+    # power governor holds under matrix load caps every bf16 kernel well below the 2.5 PFLOP/s spec peak `roofline.frac` is priced at
+    if extras and out is not None and out.get("roofline") and a.precision in ("bf16", "fp16"):
+        td = torch.bfloat16 if a.precision == "bf16" else torch.float16
+        n = 8192
+        ga, gb = torch.randn(n, n, device=dev).to(td), torch.randn(n, n, device=dev).to(td)
+        for _ in range(3):
+            torch.matmul(ga, gb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            torch.matmul(ga, gb)
+        e1.record()
+        torch.cuda.synchronize()
+        gemm_tf = 2.0 * n ** 3 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12
+        out["roofline"]["vendor_gemm_reference"] = dict(
+            note=f"torch.matmul (hipBLASLt) {n}^3 {a.precision}, random operands, timed in this run after the headline region: the practical dense "
+                 "matrix-pipe rate of this chip at the clock it holds; NOT the peak `frac` is priced at",
+            tflops=round(gemm_tf, 1), frac_of_spec_peak=round(gemm_tf / MFMA_PEAK_TFLOPS, 4),
+            dominant_kernel_vs_vendor_gemm=round(out["roofline"]["achieved"] / gemm_tf, 4))
+        del ga, gb
     # ---- by_kernel (outside the headline region): every implicit-GEMM launch of `kernel_steps` more steps, streams serialised
     if extras and a.kernel_steps > 0:
         timer.events.clear()

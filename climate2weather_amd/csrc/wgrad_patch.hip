@@ -25,7 +25,7 @@
 #endif
 #ifndef C2W_EXP
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 LDS-DMA after the first tile
-#endif             // reads out of range (issued, nothing fetched), 8 not issued at all, 32 no epilogue
+#endif             // reads out of range (issued, nothing fetched), 8 not issued at all, 32 no epilogue, 64 every tile's loads read the split's first two tiles (L2 hits)
 
 
 namespace {
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     };
     auto srcA = [&](int t, int sa) {  // dY tile of K tile t -> dY slot sa
         int b, oh0, ow0;
+        if constexpr ((C2W_EXP & 64) != 0) t = t0 + ((t - t0) & 1);  // every load hits one of two tiles: L2-resident sources
         tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;  // a missing partner image reads as zeros (out of the descriptor's range)
         TileSrc s;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     };
     auto srcP = [&](int t, int sp) {  // input halo patch of K tile t -> patch slot sp
         int b, oh0, ow0;
+        if constexpr ((C2W_EXP & 64) != 0) t = t0 + ((t - t0) & 1);
         tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;
         TileSrc s;
