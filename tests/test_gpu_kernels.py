@@ -686,3 +686,54 @@ def test_wgrad_random_shapes_vs_restatement():
         what = f"random wgrad #{it}: mode={mode} dt={dt} B={B} {Hin}x{Win} {Cin}->{Cw}/{ldy}"
         close(dw, dw_ref, dt, what, tol=1e-4 if dt == F32 else 1e-2)
         close(db, db_ref, dt, what + " bias", tol=1e-4 if dt == F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_big_kernels_are_run_to_run_identical_at_bench_size(dt):
+    """The hand-counted vmcnt / lgkmcnt waits of conv_patch_t3_kernel and wgrad_patch_kernel leave no room for a race to hide in a
+    single comparison: at the bench's own size (B = 128, 128 -> 128 @128x128, 8192 / 256 workgroups) forty launches each, alone and
+    with the other kernel running beside them on a second stream, must reproduce the first result bit for bit (the split-K sums go
+    through the workspace and are added in a fixed order), and that result must satisfy the size-independent property the domain
+    offers: linearity in the weights / in dy."""
+    B, H, C = 128, 128, 128
+    g = geom(B, H, H, C, H, H, C, C, C, ops.CONV_S1)
+    x = rnd((B * H * H, C), dt, 1)
+    w = rnd((C, 9, C), dt, 2, scale=1.0 / math.sqrt(9 * C))
+    bias = torch.randn(C, device=dev())
+    dy = rnd((B * H * H, C), dt, 3)
+    y0 = torch.empty_like(x)
+    ops.conv(x, w, bias, y0, g, dt)
+    ws = ops.new_workspace(dev())
+    dw0 = torch.zeros(C * 9 * C, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(x, dy, dw0, g, dt, workspace=ws)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    ws2 = ops.new_workspace(dev())
+    y, dw = torch.empty_like(y0), torch.empty_like(dw0)
+    for it in range(40):
+        concurrent = it % 2 == 1
+        y.zero_()
+        dw.zero_()
+        torch.cuda.synchronize()
+        if concurrent:
+            with torch.cuda.stream(side):
+                ops.conv_wgrad(x, dy, dw, g, dt, workspace=ws2)
+            ops.conv(x, w, bias, y, g, dt)
+        else:
+            ops.conv(x, w, bias, y, g, dt)
+            ops.conv_wgrad(x, dy, dw, g, dt, workspace=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y0), f"conv launch {it} (concurrent={concurrent}) differs from the first"
+        assert torch.equal(dw, dw0), f"weight-gradient launch {it} (concurrent={concurrent}) differs from the first"
+    # linearity: conv(x; 2w, 2b) = 2 conv(x; w, b) exactly in a binary floating-point format (normal range); dW(x, 2 dy) = 2 dW(x, dy)
+    y2 = torch.empty_like(y0)
+    ops.conv(x, (w.float() * 2).to(TD[dt]), bias * 2, y2, g, dt)
+    dw2 = torch.zeros_like(dw0)
+    ops.conv_wgrad(x, (dy.float() * 2).to(TD[dt]), dw2, g, dt, workspace=ws)
+    torch.cuda.synchronize()
+    if dt == BF16:
+        assert torch.equal(y2.float(), y0.float() * 2)
+        assert torch.equal(dw2, dw0 * 2)
+    else:  # fp16: results below 2^-14 are subnormal and carry fewer bits than their doubles (measured: every mismatch is one of those)
+        close(y2.float(), y0.float() * 2, dt, "conv linearity", tol=2e-3)
+        close(dw2, dw0 * 2, dt, "weight-gradient linearity", tol=2e-3)
