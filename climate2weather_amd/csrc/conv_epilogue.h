@@ -8,6 +8,19 @@
 #pragma once
 #include "conv_geom.h"
 
+#ifndef C2W_EPI_NT
+#define C2W_EPI_NT 1  // the epilogues' 16-B output stores carry the non-temporal hint (written once, read by a later kernel, never by
+                      // this one): 1-2 % on isolated launches of every flavour, 0.2 % on the step (profiles/r02_ab_conv_epilogues.txt)
+#endif
+__device__ __forceinline__ void epi_st(char* ptr, const u32x4_t& v) {
+#if C2W_EPI_NT
+    __builtin_nontemporal_store(v, (u32x4_t*)ptr);
+#else
+    *(u32x4_t*)ptr = v;
+#endif
+}
+
+
 // bias of the 16 output channels this lane's accumulator rows cover (wave tile 64 co: 4 m-tiles x rows 4*lg..4*lg+3)
 __device__ __forceinline__ void epi_load_bias(const C2wConvArgs& p, int co_base, float (&bv)[4][4]) {
     const bool has = p.bias != nullptr;
@@ -242,7 +255,7 @@ struct EpiStore {
             u32x4_t out;
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[k] = pack2<T>(o[k][0], o[k][1]);
-            if (off[i] >= 0) *(u32x4_t*)((char*)p.y + off[i]) = out;
+            if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
         }
         if (p.ln_dm != nullptr) {
 #pragma unroll
@@ -299,7 +312,7 @@ struct EpiStore {
                     out[k] = pack2<T>(u[k][0], u[k][1]);
                 }
             }
-            if (off[i] >= 0) *(u32x4_t*)((char*)p.y + off[i]) = out;
+            if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
             unpack2(out, u);  // the values as stored (bf16), like the separate LN pass would read them
             f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
@@ -318,7 +331,7 @@ struct EpiStore {
             u32x4_t ln;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ln[k] = pack2<T>(u[k][0] * rs, u[k][1] * rs);
-            if (off[i] >= 0) *(u32x4_t*)((char*)p.lnf_y + off[i]) = ln;
+            if (off[i] >= 0) epi_st((char*)p.lnf_y + off[i], ln);
         }
     }
 
@@ -420,8 +433,8 @@ struct EpiStore {
                         d_[e] = sg + h_[e] * (1.0f - sg);
                     }
                     if (o >= 0) {
-                        *(u32x4_t*)((char*)p.y + o) = pack16<T>(h_);
-                        *(u32x4_t*)((char*)p.y2 + o) = pack16<T>(d_);
+                        epi_st((char*)p.y + o, pack16<T>(h_));
+                        epi_st((char*)p.y2 + o, pack16<T>(d_));
                     }
                 } else if (p.act == C2W_ACT_RELU_PAIR && p.y2 != nullptr) {  // y = max(a, 0), y2 = (a > 0)
                     float a_[PER16], h_[PER16], d_[PER16];
@@ -432,17 +445,17 @@ struct EpiStore {
                         d_[e] = a_[e] > 0.f ? 1.f : 0.f;
                     }
                     if (o >= 0) {
-                        *(u32x4_t*)((char*)p.y + o) = pack16<T>(h_);
-                        *(u32x4_t*)((char*)p.y2 + o) = pack16<T>(d_);
+                        epi_st((char*)p.y + o, pack16<T>(h_));
+                        epi_st((char*)p.y2 + o, pack16<T>(d_));
                     }
                 } else if (o >= 0) {
-                    *(u32x4_t*)((char*)p.y + o) = v[i];
+                    epi_st((char*)p.y + o, v[i]);
                     if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
                         float f2[PER16];
                         unpack16<T>(v[i], f2);
 #pragma unroll
                         for (int e = 0; e < PER16; ++e) f2[e] = silu_f(f2[e]);
-                        *(u32x4_t*)((char*)p.y2 + o) = pack16<T>(f2);
+                        epi_st((char*)p.y2 + o, pack16<T>(f2));
                     }
                 }
             }
