@@ -613,7 +613,15 @@ class Engine:
         # ---- descent
         Hc, Wc = H, W
         lv0 = lay.levels[0]
-        cur, g_h0, r_h0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1)
+        def mod_of(b: BlockSpec):
+            return ("mod", m_all.view(-1)[b.mod_offset:])
+
+        # the network-input conv emits the first residual block's LayerNorm input from its epilogue, like every block's second conv
+        first0 = lv0.descent[0] if lv0.descent and not os.environ.get("C2W_NO_HEAD_LN") else None  # env: diagnostic A/B
+        cur, g_h0, r_h0, hn0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1,
+                                     want_ln=mod_of(first0) if first0 is not None and first0.kind == "res" else ("plain", None))
+        if first0 is None or first0.kind != "res":
+            hn0 = None
         if train:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
                 self._wgrad(rec, x0, gy, g, dt)
@@ -621,9 +629,6 @@ class Engine:
                 tape.done(rec.w_off)
                 return dx0
             tape.steps.append(bw_head0)
-        def mod_of(b: BlockSpec):
-            return ("mod", m_all.view(-1)[b.mod_offset:])
-
         def run_blocks(blocks, cur, Hc, Wc, h0, tail_ln):
             """The blocks of one level side in order.  Each residual block asks its producer -- the previous block's second
             conv -- for its LayerNorm input; ``tail_ln`` is what the consumer after the last block wants.  Returns the
@@ -653,7 +658,7 @@ class Engine:
                         tape.done(rec.w_off)
                         return dxs
                     tape.steps.append(bw_head)
-            cur, _ = run_blocks(lv.descent, cur, Hc, Wc, None, None)
+            cur, _ = run_blocks(lv.descent, cur, Hc, Wc, hn0 if i == 0 else None, None)
             if i < L - 1:
                 skips.append(cur)
         # ---- ascent
