@@ -468,7 +468,7 @@ def run_rank(a):
         dist.destroy_process_group()
 
 
-def deep_variant(dev, B=16):
+def deep_variant(dev, B=32):
     """BASELINE configs[4]: 5 variables x 16 frames = 80 channels, 256x256 windows (473.03 GFLOP forward per window), fp16 -- the
     training step and the forward -- and its sampler step (k = 7 -> window 15 -> 75 channels: the reference's windows are odd,
     SURVEY.md section 0) as eager launches and as a hipGraph replay."""
