@@ -299,7 +299,7 @@ def run_rank(a):
     timer.install()
 
     def one_step():
-        return trainer.step(feed.next_batch(a.batch))
+        return trainer.step(feed.next_batch(a.batch, lazy=True))  # the windows are read in place by the input conversion
 
     for _ in range(a.warmup):
         one_step()

@@ -56,6 +56,7 @@ _PROTOS = {
     "c2w_mse_loss_grad_scaled": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p],
     "c2w_philox_normal": [c_void_p, c_longlong, c_ulonglong, c_void_p],
     "c2w_nchw_to_nhwc_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_windows_to_nhwc_noise": [c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_mse_loss_grad_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p],
     "c2w_timestep_embedding": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],

@@ -443,12 +443,17 @@ __device__ __forceinline__ void lt_load_planes(float* tile, int C, int ldc, int 
 template <typename T, bool PHILOX = false>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                                  const float* __restrict__ musig, T* __restrict__ y, int B, int C, int HW,
-                                                                 int ldc, long long img_stride, uint32_t k0 = 0, uint32_t k1 = 0) {
+                                                                 int ldc, long long img_stride, uint32_t k0 = 0, uint32_t k1 = 0,
+                                                                 const long long* __restrict__ img_off = nullptr) {
     constexpr int P = Elem<T>::PER16;
     extern __shared__ float lt_tile[];
     const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
+    const float* const x_all = x;
     for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
         const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
+        // img_off: image b starts img_off[b] floats into x (windows picked out of a dataset array).  The element index the noise
+        // stream is addressed with stays the dense one, b * img_stride + ..., whatever the image's place in memory.
+        if (img_off != nullptr) x = x_all + (img_off[b] - (long long)b * img_stride);
         float mu = 1.f, sg = 0.f;
         if (eps || PHILOX) { mu = musig[2 * b]; sg = musig[2 * b + 1]; }
         struct Ld {
@@ -891,6 +896,17 @@ extern "C" int c2w_nchw_to_nhwc_noise(const float* x, unsigned long long seed, c
     const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
     DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T, true><<<nblk, 256, lds, (hipStream_t)stream>>>(
                           x, nullptr, musig, (T*)y, B, C, HW, ldc, (long long)C * HW, (uint32_t)seed, (uint32_t)(seed >> 32))));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_windows_to_nhwc_noise(const float* data, const long long* img_off, unsigned long long seed, const float* musig, void* y,
+                                         int B, int C, int HW, int ldc, int dtype, void* stream) {
+    if (!data || !img_off || !y || !musig || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (lds > 64 * 1024) return C2W_ERR_UNSUPPORTED;  // caller gathers the windows and takes the dense path
+    const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
+    DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T, true><<<nblk, 256, lds, (hipStream_t)stream>>>(
+                          data, nullptr, musig, (T*)y, B, C, HW, ldc, (long long)C * HW, (uint32_t)seed, (uint32_t)(seed >> 32), img_off)));
     return (int)hipGetLastError();
 }
 

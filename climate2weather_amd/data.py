@@ -119,6 +119,28 @@ class COSMODataset(torch.utils.data.Dataset):
         return x.flatten(0, 1) if self._flatten else x
 
 
+class WindowBatch:
+    """A training batch that has not been gathered: ``data`` (N, F, H, W) fp32 on the device and the first frame of each of the B
+    windows.  Window b is the w * F * H * W contiguous floats from frame ``first[b]`` on (dataset.py:114-126 reshapes exactly that
+    block), so the trainer's input conversion reads it in place (ops.windows_to_nhwc_noise) and the (B, w*F, H, W) tensor is never
+    written.  ``materialize()`` is the plain tensor for every other consumer."""
+
+    def __init__(self, data: torch.Tensor, first: torch.Tensor, window: int):
+        self.data, self.first, self.window = data, first, window
+        n, f, h, w = data.shape
+        self.shape = torch.Size((first.numel(), window * f, h, w))
+        self.device, self.dtype, self.is_cuda = data.device, data.dtype, data.is_cuda
+        self._ar = None
+
+    def offsets(self) -> torch.Tensor:
+        """float offset of every window inside ``data`` (int64, on the device)"""
+        return self.first * (self.data.stride(0))
+
+    def materialize(self) -> torch.Tensor:
+        ar = torch.arange(self.window, device=self.data.device)
+        return self.data[(self.first[:, None] + ar[None, :])].flatten(1, 2)
+
+
 class DeviceWindowFeed:
     """Whole (normalised) array resident in HBM; a batch is an index gather on the device -- no DataLoader workers, no
     pinned staging, no H2D copy per step.  8 y x 8760 h x 4 x 128^2 fp32 = 18 GB fits MI355X's 288 GB many times."""
@@ -129,7 +151,8 @@ class DeviceWindowFeed:
         self.sampler = iter(InfiniteSampler(dataset, rank, num_replicas, shuffle, seed, start_idx))
         self._ar = torch.arange(self.window, device=device)
 
-    def next_batch(self, batch: int) -> torch.Tensor:
+    def next_batch(self, batch: int, lazy: bool = False):
+        """``lazy``: return a WindowBatch (indices only) instead of the gathered (B, w*F, H, W) tensor; Trainer.step takes either."""
         idx = torch.tensor([next(self.sampler) for _ in range(batch)], dtype=torch.int64)
         if self.data.is_cuda:
             # pinned + asynchronous: a pageable host -> device copy blocks the host until the stream reaches it, i.e. until the PREVIOUS
@@ -138,5 +161,7 @@ class DeviceWindowFeed:
             idx = idx.pin_memory().to(self.data.device, non_blocking=True)
         else:
             idx = idx.to(self.data.device)
+        if lazy:
+            return WindowBatch(self.data, idx, self.window)
         frames = self.data[(idx[:, None] + self._ar[None, :])]  # (B, w, F, H, W)
         return frames.flatten(1, 2)

@@ -472,7 +472,8 @@ class Engine:
             if lv.channels % ck:
                 raise ValueError(f"hidden_channels must be multiples of {ck} for this compute dtype")
         train = tape is not None
-        if x_nhwc is None:
+        lazy = x_nhwc is None and hasattr(x, "materialize")  # data.WindowBatch: windows still inside the dataset array
+        if x_nhwc is None and not lazy:
             x = x.contiguous().float()
         tt = t.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
         Bt = tt.numel()
@@ -497,7 +498,16 @@ class Engine:
             x0 = x_nhwc
         else:
             x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
-            if noise is not None and isinstance(noise[0], int):  # regenerated noise: (seed, musig)
+            regen = noise is not None and isinstance(noise[0], int)  # regenerated noise: (seed, musig)
+            done = False
+            if lazy:  # windows still inside the dataset array: convert them in place where the fused kernel takes the shape
+                done = regen and x.data.is_contiguous() and x.data.dtype == torch.float32 and \
+                    ops.windows_to_nhwc_noise(x.data, x.offsets(), noise[0], noise[1], x0, B, C, H * W, lay.cin_pad, dt)
+                if not done:
+                    x = x.materialize().contiguous().float()
+            if done:
+                pass
+            elif regen:
                 if not ops.nchw_to_nhwc_noise(x, noise[0], noise[1], x0, B, C, H * W, lay.cin_pad, dt):
                     eps = torch.empty_like(x)
                     ops.philox_normal(eps, eps.numel(), noise[0])

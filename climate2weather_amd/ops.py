@@ -165,6 +165,16 @@ def nchw_to_nhwc_noise(x, seed, musig, y, B, C, HW, ldc, dtype) -> bool:
     return True
 
 
+def windows_to_nhwc_noise(data, img_off, seed, musig, y, B, C, HW, ldc, dtype) -> bool:
+    """nchw_to_nhwc_noise reading image b from ``data`` at float offset ``img_off[b]`` (int64 device tensor): the training batch is
+    never gathered.  False if the shape is not supported (caller gathers and takes the dense path)."""
+    rc = _lib.load().c2w_windows_to_nhwc_noise(_p(data), _p(img_off), int(seed), _p(musig), _p(y), B, C, HW, ldc, dtype, _stream())
+    if rc == -3:
+        return False
+    check(rc, "c2w_windows_to_nhwc_noise")
+    return True
+
+
 def mse_loss_grad_noise(y, seed, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=None) -> bool:
     rc = _lib.load().c2w_mse_loss_grad_noise(_p(y), int(seed), _p(dy), _p(loss_sum), B, C, HW, ldc, gscale, _p(scaler), dtype, _stream())
     if rc == -3:

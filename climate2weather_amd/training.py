@@ -147,11 +147,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, batches, t: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``batches``: one (B,C,H,W) fp32 GPU tensor, or a list of them = gradient-accumulation rounds
+        """``batches``: one (B,C,H,W) fp32 GPU tensor (or data.WindowBatch), or a list of them = gradient-accumulation rounds
         (training_loop.py:373-378: gradients of the rounds are summed, only the last round synchronises).
         ``t`` (B,) and ``eps`` (B,C,H,W) may be injected (tests); otherwise drawn as src/thor/pipelines.py:29-31 does.
         Returns the last round's loss (device scalar, like the value the reference logs)."""
-        if isinstance(batches, torch.Tensor):
+        if not isinstance(batches, (list, tuple)):  # one tensor, or one data.WindowBatch (windows still inside the dataset array)
             batches = [batches]
         eng = self.eng
         if len(self._step_done) >= 2:
@@ -219,7 +219,7 @@ class Trainer:
         gs = 2.0 * self.loss_scaling / n
         if seed is None or not ops.mse_loss_grad_noise(y, seed, dy, self.loss_sum, B, C, H * W, lay.cout_pad, gs, self.dt, scaler=self.scaler):
             if eps is None:  # shape outside the fused kernel: materialise the same stream
-                eps = torch.empty_like(x)
+                eps = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
                 ops.philox_normal(eps, eps.numel(), seed)
             ops.mse_loss_grad(y, eps, dy, self.loss_sum, B, C, H * W, lay.cout_pad, gs, self.dt, scaler=self.scaler)
         eng.backward(tape, dy)

@@ -156,6 +156,11 @@ int c2w_mse_loss_grad_scaled(const void* y, const float* eps, void* dy, float* l
 int c2w_philox_normal(float* out, long long n, unsigned long long seed, void* stream);
 int c2w_nchw_to_nhwc_noise(const float* x, unsigned long long seed, const float* musig, void* y, int B, int C, int HW, int ldc,
                            int dtype, void* stream);
+/* The same with the B images picked out of a dataset array: image b is the C*HW contiguous floats at data + img_off[b] (a window of
+ * consecutive frames: dataset.py:114-126; img_off[b] a multiple of 4).  The noise stream is addressed with the dense (B,C,H,W) index,
+ * so the result equals c2w_nchw_to_nhwc_noise on the gathered batch bit for bit -- the batch tensor itself is never written. */
+int c2w_windows_to_nhwc_noise(const float* data, const long long* img_off, unsigned long long seed, const float* musig, void* y, int B, int C,
+                              int HW, int ldc, int dtype, void* stream);
 int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
                             float gscale, const float* scaler_state, int dtype, void* stream);
 /* model/score.py:14-34 */

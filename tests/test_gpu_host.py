@@ -635,3 +635,49 @@ def test_device_window_feed_yields_the_reference_batches(start_idx):
     sb = sfeed.next_batch(4)
     for j in range(4):
         assert torch.equal(sb[j].cpu(), oh.window_item(sds.data, so[j], 3))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_lazy_window_batches_train_like_gathered_ones(prec):
+    """DeviceWindowFeed.next_batch(lazy=True) hands the trainer the window indices only; the input conversion reads the windows in
+    place (c2w_windows_to_nhwc_noise) and addresses the noise stream with the dense (B,C,H,W) index, so the step is the SAME step:
+    identical loss and identical weights after two optimizer steps, and the lazy batch materialises to the gathered batch
+    (dataset.py:114-126 via oracle/host.py::window_item)."""
+    from climate2weather_amd.data import DeviceWindowFeed, SyntheticWindowDataset, WindowBatch
+    dev = torch.device("cuda", 0)
+    cfg = dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    ds = SyntheticWindowDataset(n_frames=24, n_vars=2, height=32, width=32, window=3, seed=0)
+    outs = []
+    for lazy in (False, True):
+        torch.manual_seed(5)
+        net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg).to(dev)
+        tr = Trainer(net, lr=1e-3, precision=prec, ema_rates=[0.999], seed=77)
+        feed = DeviceWindowFeed(ds, dev, rank=0, num_replicas=1, seed=3)
+        losses = []
+        for _ in range(2):
+            batch = feed.next_batch(5, lazy=lazy)
+            if lazy:
+                assert isinstance(batch, WindowBatch) and tuple(batch.shape) == (5, 6, 32, 32)
+                order = batch.first.cpu().tolist()
+                m = batch.materialize()
+                for j, i in enumerate(order):
+                    assert torch.equal(m[j].cpu(), oh.window_item(ds.data, i, 3))
+            losses.append(float(tr.step(batch)))
+        outs.append((losses, tr.eng.flat.clone(), tr.last_noise_seed))
+    assert outs[0][2] == outs[1][2]  # same noise seeds drawn
+    # the loss and the LayerNorm modulation gradients are summed with fp32 atomics: two runs of the SAME step agree to rounding, not bits
+    assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-4), (outs[0][0], outs[1][0])
+    dw = (outs[0][1] - outs[1][1]).abs()  # Adam's g / (|g| + eps) is ill-conditioned where |g| ~ eps: bound by the two steps taken,
+    assert dw.max().item() <= 2 * 1e-3 and dw.mean().item() <= 1e-5  # and require agreement on average far below one step (1e-3)
+    # what the two paths hand the network is identical bit for bit: the in-place conversion vs the conversion of the gathered batch
+    batch = DeviceWindowFeed(ds, dev, rank=0, num_replicas=1, seed=9).next_batch(5, lazy=True)
+    dt = DTYPE_F32 if prec == "fp32" else DTYPE_BF16
+    td = torch.float32 if prec == "fp32" else torch.bfloat16
+    musig = torch.rand(5, 2, device=dev)
+    ld = 64 if prec != "fp32" else 32
+    a = torch.zeros(5 * 32 * 32, ld, dtype=td, device=dev)
+    b = torch.zeros_like(a)
+    assert ops.windows_to_nhwc_noise(batch.data, batch.offsets(), 123456789, musig, a, 5, 6, 32 * 32, ld, dt)
+    assert ops.nchw_to_nhwc_noise(batch.materialize().contiguous(), 123456789, musig, b, 5, 6, 32 * 32, ld, dt)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float(a.float().abs().sum()) > 0

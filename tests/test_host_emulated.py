@@ -389,6 +389,9 @@ def test_data_feed_and_seam(golden_dir):
     batch = feed.next_batch(4)
     for j, idx in enumerate(full[:4]):
         assert torch.equal(batch[j], ds[idx])
+    lazy = DeviceWindowFeed(ds, torch.device("cpu"), rank=0, num_replicas=1, seed=0).next_batch(4, lazy=True)  # indices only
+    assert tuple(lazy.shape) == (4, 6, 8, 8) and lazy.first.tolist() == full[:4] and torch.equal(lazy.materialize(), batch)
+    assert lazy.offsets().tolist() == [i * 2 * 64 for i in full[:4]]  # float offset of each window inside the (N, F, H, W) array
     assert c2w_util.set_random_seed(42, 0) == kat["seed_hash"]["42,0"]
     assert linear_learning_rate_schedule(250, 1000, 1e-4) == pytest.approx(kat["lr_linear"][1])
     net = c2w_util.construct_class_by_name(class_name="climate2weather_amd.score.ScoreUNet", channels=6, spatial=2,
