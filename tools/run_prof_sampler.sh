@@ -1,3 +1,4 @@
+# sampler leg: steps/s at the shipped trajectory lengths, eager and hipGraph-replayed, and the GPU idle time per sampler step from a kernel trace
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python tools/bench_sampler.py --lengths 49,140 --steps 16
 python tools/bench_sampler.py --lengths 49 --steps 16 --graph 1
