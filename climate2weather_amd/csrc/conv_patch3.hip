@@ -40,8 +40,14 @@
 #ifndef C2W_T3_DIRECT
 #define C2W_T3_DIRECT 0  // elementwise epilogues of the 16x16 tile stored straight from the accumulators (t3_epi_direct)
 #endif
+#ifndef C2W_T3_SPLIT_EPI
+#define C2W_T3_SPLIT_EPI 1  // one kernel instantiation per epilogue family (LayerNorm emission / LayerNorm backward / elementwise): by
+                           // itself +-0; it is what lets the two-block operand prefetch below fit its registers
+#endif
 #ifndef C2W_T3_EPI2
-#define C2W_T3_EPI2 0  // epilogue of the 16x16 tile: operand rows of both 8-row blocks requested up front
+#define C2W_T3_EPI2 14  // epilogue of the 16x16 tile: operand rows of both 8-row blocks requested up front.  Bit 0: in the all-in-one
+                        // kernel (54 spilled registers, 11-17 % slower); bits 1-3: in the per-family instantiations (no spills; LayerNorm
+                        // flavours 1-2.5 % faster, the step 49.09 -> 48.95 ms; profiles/r02_ab_conv_epilogues.txt)
 #endif
 #ifndef C2W_T3_PP
 #define C2W_T3_PP 0  // two-group schedule of the 8-wave kernel (see `stage`): 1 groups = waves 0-3 / 4-7, 2 = even / odd waves
@@ -250,7 +256,7 @@ __device__ __forceinline__ void t3_epi_direct(const C2wConvArgs& p, f32x4_t (&ac
 
 // DIRECT: the instantiation whose epilogue is t3_epi_direct (picked by the launcher for the flavours it covers; a kernel of its own
 // because the register allocator, given both epilogues behind one loop, spills accumulators INSIDE the loop)
-template <int TR, typename T = bf16_t, int NW = 4, bool DIRECT = false>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
+template <int TR, typename T = bf16_t, int NW = 4, int EPI = 0>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
 __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv_patch_t3_kernel(const C2wConvArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     typedef T3Cfg<TR, NW> CF;
@@ -554,6 +560,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         if (t[0] + t[1] + t[2] + t[3] == 12345.678f) ((float*)p.y)[tid] = t[0];
         return;
     }
+    constexpr bool DIRECT = EPI == 1;
     if constexpr (DIRECT) {
         static_assert(TR == 16, "16x16 tiles only");
         int lane_d = tid;
@@ -586,8 +593,8 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
 #if C2W_T3_EPI2
     // both 8-row blocks' residual / multiplier rows are requested before the first block is finished: the second block's HBM latency
     // runs behind the first block's arithmetic and stores (the accumulators have left the registers, so both sets fit)
-    if constexpr (CF::NPASS == 2) {
-        const bool pool2 = (p.flags & C2W_CONV_POOL2) != 0;
+    if constexpr (CF::NPASS == 2 && (((C2W_T3_EPI2) >> (EPI == 0 ? 0 : EPI - 1)) & 1) != 0) {  // C2W_T3_EPI2: bit 0 the all-in-one kernel, bits 1 / 2 / 3 the EPI = 2 / 3 / 4 instantiations
+        const bool pool2 = EPI == 0 && (p.flags & C2W_CONV_POOL2) != 0;
         EpiStore<T, 128, T3_NTHR> est0, est1;
         if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
         if (!pool2) {
@@ -600,11 +607,14 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         for (int h = 0; h < 2; ++h) {
             auto& est = h == 0 ? est0 : est1;
             const char* const Oh = O + h * 128 * T3_OS;
-            if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
+            if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+            else if constexpr (EPI == 3) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
+            else if constexpr (EPI == 4) est.finish(p, Oh, T3_OS, tid_e);
+            else if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
             else if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
             else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
             else est.finish(p, Oh, T3_OS, tid_e);
-            if (h == 0 && p.ln_x != nullptr) {  // the LayerNorm column sums are re-zeroed for the second block only after everyone read them
+            if (h == 0 && (EPI == 3 || (EPI == 0 && p.ln_x != nullptr))) {  // the LayerNorm column sums are re-zeroed for the second block only after everyone read them
                 __syncthreads();
                 if (tid_e < 128) red[tid_e] = 0.f;
                 __syncthreads();
@@ -618,12 +628,16 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         for (int h = 0; h < CF::NPASS; ++h) {
         if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
         EpiStore<T, 128, T3_NTHR> est;
-        const bool pool2 = (p.flags & C2W_CONV_POOL2) != 0;
+        const bool pool2 = EPI == 0 && (p.flags & C2W_CONV_POOL2) != 0;
         if (!pool2) est.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8 * h) * W + ow0, W);
         __syncthreads();
         T3_STAMP(5 + h);
         const char* const Oh = O + h * 128 * T3_OS;
-        if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
+        // EPI 2 / 3 / 4: instantiations that carry one epilogue only (picked by the launcher, C2W_T3_SPLIT_EPI)
+        if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+        else if constexpr (EPI == 3) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
+        else if constexpr (EPI == 4) est.finish(p, Oh, T3_OS, tid_e);
+        else if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
         else if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
         else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
         else est.finish(p, Oh, T3_OS, tid_e);
@@ -648,17 +662,17 @@ inline bool t3_direct_flavour(const C2wConvArgs& a) {
     return a.ln_x == nullptr && a.lnf_y == nullptr && (a.flags & C2W_CONV_POOL2) == 0 && a.act != C2W_ACT_SILU && a.act != C2W_ACT_RELU;
 }
 
-template <int TR, typename T, int NW, bool DIRECT>
+template <int TR, typename T, int NW, int EPI>
 int t3_launch_as(const C2wConvArgs& a, hipStream_t st) {
     typedef T3Cfg<TR, NW> CF;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr = true;
     }
     const int nN = (a.Cout + 127) / 128;
     const int nM = a.B * (a.Hout / TR) * (a.Wout >> 4);
-    conv_patch_t3_kernel<TR, T, NW, DIRECT><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
+    conv_patch_t3_kernel<TR, T, NW, EPI><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -666,9 +680,16 @@ template <int TR, typename T, int NW>
 int t3_launch(const C2wConvArgs& a, hipStream_t st) {
 #if C2W_T3_DIRECT
     static const bool off = getenv("C2W_T3_NO_DIRECT") != nullptr;
-    if (TR == 16 && !off && t3_direct_flavour(a)) return t3_launch_as<16, T, NW, true>(a, st);
+    if (TR == 16 && !off && t3_direct_flavour(a)) return t3_launch_as<16, T, NW, 1>(a, st);
 #endif
-    return t3_launch_as<TR, T, NW, false>(a, st);
+#if C2W_T3_SPLIT_EPI
+    if (TR == 16 && (a.flags & C2W_CONV_POOL2) == 0) {
+        if (a.lnf_y != nullptr) return t3_launch_as<16, T, NW, 2>(a, st);
+        if (a.ln_x != nullptr) return t3_launch_as<16, T, NW, 3>(a, st);
+        return t3_launch_as<16, T, NW, 4>(a, st);
+    }
+#endif
+    return t3_launch_as<TR, T, NW, 0>(a, st);
 }
 
 }  // namespace
