@@ -43,7 +43,10 @@ for (mode, H, Cin, Cout) in SHAPES:
     gf = 2.0 * B * Ho * Ho * Cout * taps * Cin / 1e9
 
     def run(lib, dw):
-        rc = lib.c2w_conv_wgrad(ctypes.byref(a), ctypes.c_void_p(dw.data_ptr()), None, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, 1, st)
+        if os.environ.get("WS", "1") == "0":  # no workspace: split-K partial sums by fp32 atomics
+            rc = lib.c2w_conv_wgrad(ctypes.byref(a), ctypes.c_void_p(dw.data_ptr()), None, None, 0, 1, st)
+        else:
+            rc = lib.c2w_conv_wgrad(ctypes.byref(a), ctypes.c_void_p(dw.data_ptr()), None, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, 1, st)
         assert rc == 0, rc
 
     times = [[] for _ in libs]
