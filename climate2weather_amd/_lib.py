@@ -16,6 +16,7 @@ CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
 CONV_POOL2 = 1  # ConvArgs.flags
+KERNEL_GATHER, KERNEL_PATCH_8X16, KERNEL_PATCH_16X16, KERNEL_PATCH_PAIR, KERNEL_PATCH_TS2 = 0, 1, 2, 3, 4  # c2w_conv_dispatch
 
 
 class C2wError(RuntimeError):
@@ -40,6 +41,8 @@ _PROTOS = {
     "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_pool2_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_dispatch": [POINTER(ConvArgs), c_int],
+    "c2w_conv_wgrad_dispatch": [POINTER(ConvArgs), c_int],
     "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_ulonglong, c_int, c_void_p],
     "c2w_conv_wgrad_workspace_bytes": [POINTER(ConvArgs), c_int],

@@ -373,6 +373,15 @@ extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr ? 1 : 0;
 }
 
+extern "C" int c2w_conv_dispatch(const C2wConvArgs* a, int dtype) {
+    if (a == nullptr) return C2W_ERR_BAD_ARG;
+    const bool gather = getenv("C2W_FORCE_GATHER") != nullptr;
+    if (!gather && c2w_conv_patch_eligible(*a)) return c2w_conv_patch3_wanted(*a, dtype) ? C2W_KERNEL_PATCH_16X16 : C2W_KERNEL_PATCH_8X16;
+    if (!gather && c2w_conv_pair_eligible(*a)) return C2W_KERNEL_PATCH_PAIR;
+    if (!gather && c2w_conv_ts2_patch_eligible(*a)) return C2W_KERNEL_PATCH_TS2;
+    return C2W_KERNEL_GATHER;
+}
+
 extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void* stream) {
     if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return C2W_ERR_BAD_ARG;
     const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;

@@ -437,6 +437,13 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, voi
     return launch_dtype<f16_t>(*a, dw, dbias, ws, wsb, st);
 }
 
+extern "C" int c2w_conv_wgrad_dispatch(const C2wConvArgs* a, int dtype) {
+    const int rc = wgrad_check(a, dtype);
+    if (rc != 0) return rc;
+    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return a->Win == 8 ? C2W_KERNEL_PATCH_PAIR : C2W_KERNEL_PATCH_8X16;
+    return C2W_KERNEL_GATHER;
+}
+
 // Bytes of scratch c2w_conv_wgrad would use for this geometry (0: the launch does not split its reduction), or a negative status.
 extern "C" long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* a, int dtype) {
     const int rc = wgrad_check(a, dtype);

@@ -627,11 +627,11 @@ class Engine:
             return ("mod", m_all.view(-1)[b.mod_offset:])
 
         # the network-input conv emits the first residual block's LayerNorm input from its epilogue, like every block's second conv
-        first0 = lv0.descent[0] if lv0.descent and not os.environ.get("C2W_NO_HEAD_LN") else None  # env: diagnostic A/B
-        cur, g_h0, r_h0, hn0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1,
-                                     want_ln=mod_of(first0) if first0 is not None and first0.kind == "res" else ("plain", None))
-        if first0 is None or first0.kind != "res":
-            hn0 = None
+        first0 = lv0.descent[0] if lv0.descent else None
+        if first0 is not None and first0.kind == "res":
+            cur, g_h0, r_h0, hn0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1, want_ln=mod_of(first0))
+        else:  # nothing consumes a LayerNorm of the head conv's output: do not ask the kernel for one
+            (cur, g_h0, r_h0), hn0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1), None
         if train:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
                 self._wgrad(rec, x0, gy, g, dt)

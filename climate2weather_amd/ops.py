@@ -81,6 +81,26 @@ def conv_lnbwd_supported(g: dict, dtype: int) -> bool:
     return bool(_lib.load().c2w_conv_lnbwd_supported(ctypes.byref(a), dtype))
 
 
+def conv_dispatch(g: dict, dtype: int, pool2: bool = False, fused_ln: bool = False) -> int:
+    """Kernel family (``_lib.KERNEL_*``) c2w_conv_forward runs this geometry on; ``fused_ln``: with a LayerNorm epilogue requested."""
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    if pool2:
+        a.flags = _lib.CONV_POOL2
+    if fused_ln:
+        a.lnf_y = ctypes.c_void_p(16)  # only tested against NULL
+    return int(_lib.load().c2w_conv_dispatch(ctypes.byref(a), dtype))
+
+
+def conv_wgrad_dispatch(g: dict, dtype: int) -> int:
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    rc = int(_lib.load().c2w_conv_wgrad_dispatch(ctypes.byref(a), dtype))
+    if rc < 0:
+        check(rc, "c2w_conv_wgrad_dispatch")
+    return rc
+
+
 def conv_wgrad(x, dy, dw, g: dict, dtype: int, dbias=None, workspace: Optional[torch.Tensor] = None):
     """c2w_conv_wgrad: dw += dY^T . gather(x); dbias (optional) += column sums of dY.
     ``workspace``: fp32 scratch tensor for the split-K partial sums (``new_workspace``), handed over per call; one per stream.

@@ -235,6 +235,10 @@ class _WindowScore(AbstractScoreFunction):
 
     def _score_graphed(self, xd, t, eng, dt, lay, k, w, nwin, bs):
         L, F, H, W = xd.shape
+        # replay never re-enters eng.forward(): re-read the Parameters' version counters here, so that weights written through the
+        # Parameter objects since the capture (load_state_dict, torch.optim steps, EMA copies) invalidate the captured graphs and the
+        # 16-bit shadow they read is rebuilt by the eager warm-up below
+        eng.refresh_version()
         key = (L, F, H, W, bs, dt, eng._version())
         st = self._graphs.get(key) if hasattr(self, "_graphs") else None
         if st is None:

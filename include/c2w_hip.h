@@ -94,6 +94,15 @@ int c2w_conv_lnfwd_supported(const C2wConvArgs* args, int dtype);
  * image the halo-patch kernel tiles, no mul / act / y2), else 0.  Callers fall back to conv + c2w_ln_backward. */
 int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);
 
+/* Which kernel family c2w_conv_forward (naive == 0) / c2w_conv_wgrad run these arguments on -- a pure function of the geometry,
+ * the dtype and the fusion fields; the parity tests assert with it that a case reaches the kernel it is meant to cover.
+ * GATHER: conv_igemm / wgrad gather kernels; PATCH_8X16: conv_patch_half_kernel / wgrad_patch_kernel; PATCH_16X16:
+ * conv_patch_t3_kernel<16> (16-bit launches of >= 1024 workgroups); PATCH_PAIR: 8-pixel-wide images, two per tile; PATCH_TS2: the
+ * stride-2 input gradient per output-parity class. */
+enum { C2W_KERNEL_GATHER = 0, C2W_KERNEL_PATCH_8X16 = 1, C2W_KERNEL_PATCH_16X16 = 2, C2W_KERNEL_PATCH_PAIR = 3, C2W_KERNEL_PATCH_TS2 = 4 };
+int c2w_conv_dispatch(const C2wConvArgs* args, int dtype);
+int c2w_conv_wgrad_dispatch(const C2wConvArgs* args, int dtype);
+
 /* naive == 0: product path (halo-patch MFMA kernel for 3x3 stride-1 on 16x16-tileable images, general gather MFMA
  * kernel otherwise); naive == 2: force the gather MFMA kernel; naive == 1: one-thread-per-output direct convolution
  * with identical semantics (debug cross-check only). */

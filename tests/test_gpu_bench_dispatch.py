@@ -1,0 +1,346 @@
+"""Parity at the dispatch the bench times.
+
+bench.py runs the default network at B = 128, C = 65 in bf16; at that batch the dispatcher (c2w_conv_dispatch) sends the 128^2, 64^2
+and 32^2 levels, three of the four up-convs and the padded edge convs to conv_patch_t3_kernel<16> (>= 1024 workgroups), the weight
+gradients to wgrad_patch_kernel with one-round split counts, the 8x8 level to the paired tiles.  The per-kernel tests of
+test_gpu_kernels.py stay small (seconds on any box) and therefore reach the 16x16-tile kernel at one shape only; this file covers
+
+  (a) every (kernel family, geometry, epilogue) combination of THAT step -- model/nn.py:146-159 (residual block), :165-194 (head /
+      down / up / out convs), :31-85 (attention block) -- against the plain PyTorch restatement (tests/emu_ops.py) on the same seeded
+      inputs, each case asserting the kernel family it reaches;
+  (b) Trainer's own forward + backward (training_loop.py:376-378) at B = 128, C = 65 in bf16 and fp16 against the CPU oracle's
+      gradients computed on the box in chunks: loss, all 228 gradients.
+
+Tolerances: as in test_gpu_kernels.py (of the output scale): bf16 2e-2, fp16 4e-3, weight gradients 1e-2 / 2e-3.
+"""
+import math
+import os
+
+import pytest
+import torch
+
+import emu_ops as E
+from climate2weather_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+BF16, F16, F32 = ops.DTYPE_BF16, ops.DTYPE_F16, ops.DTYPE_F32
+TD = ops.TORCH_DTYPE
+TOL = {BF16: 2e-2, F16: 4e-3}
+TOL_W = {BF16: 1e-2, F16: 2e-3}
+S1, S2, UP, TS2, K1 = ops.CONV_S1, ops.CONV_S2, ops.CONV_UP, ops.CONV_TS2, ops.CONV_1X1
+T3, HALF, PAIR, TS2P, GATHER = _lib.KERNEL_PATCH_16X16, _lib.KERNEL_PATCH_8X16, _lib.KERNEL_PATCH_PAIR, _lib.KERNEL_PATCH_TS2, _lib.KERNEL_GATHER
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator(device=dev()).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=dev()) * scale).to(TD[dt])
+
+
+def close(a, b, tol, what):
+    a, b = a.float(), b.float()
+    s = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert math.isfinite(err) and err <= tol * s, f"{what}: max err {err:.3e} vs scale {s:.3e}"
+
+
+def geom(B, Hin, Win, Cin, Hout, Wout, Cout, ldy, wrows, mode):
+    return dict(B=B, Hin=Hin, Win=Win, Cin=Cin, Hout=Hout, Wout=Wout, Cout=Cout, ldy=ldy, wrows=wrows, mode=mode)
+
+
+def out_hw(mode, H):
+    return H // 2 if mode == S2 else 2 * H if mode in (UP, TS2) else H
+
+
+# (name, kernel family, mode, B, Hin, Cin, Cout, wrows, cin_real, epilogues)
+# Epilogue names: bias, silu (inference), pair (training: silu + silu'), res, lnf (consumer's LayerNorm emitted; "mod" = with the
+# modulation rows), lnb (LayerNorm backward fused), mulp (x stored silu' -- conv2's input gradient), pool (2x2 sums: the up-conv's
+# input gradient).  B is the smallest batch at which the launch has the bench's kernel selection (>= 1024 workgroups for the 16x16
+# tiles; for the gather kernel the 256-pixel-tile form).
+FWD_CASES = [
+    # residual blocks (model/nn.py:146-159): conv1 / conv2 / their input gradients
+    ("res 128@64^2", T3, S1, 64, 64, 128, 128, 128, 128, ["bias+pair", "bias+res+lnf", "mulp", "res+lnb", "bias+silu"]),
+    ("res 256@32^2 (two co tiles, 4 K chunks)", T3, S1, 128, 32, 256, 256, 256, 256, ["bias+pair", "bias+res", "mulp", "plain", "bias+silu"]),
+    ("res 384@16^2", HALF, S1, 128, 16, 384, 384, 384, 384, ["bias+pair", "bias+res", "mulp", "plain"]),
+    ("res 512@8^2 (paired images)", PAIR, S1, 128, 8, 512, 512, 512, 512, ["bias+pair", "bias+res", "mulp", "plain"]),
+    # up-convs (model/nn.py:183-189) with the skip add (:238) and, where the consumer is a 128-channel block, its LayerNorm
+    ("up 512->384 8^2->16^2", HALF, UP, 128, 8, 512, 384, 384, 512, ["bias+res"]),
+    ("up 384->256 16^2->32^2", T3, UP, 128, 16, 384, 256, 256, 384, ["bias+res"]),
+    ("up 256->128 32^2->64^2", T3, UP, 64, 32, 256, 128, 128, 256, ["bias+res", "bias+res+lnf"]),
+    # input gradients of the up-convs, leaving the kernel as 2x2 sums (adjoint of Upsample, model/nn.py:184)
+    ("up-conv dgrad 256->384 @32^2 pooled (three co tiles)", T3, S1, 128, 32, 256, 384, 384, 256, ["pool"]),
+    ("up-conv dgrad 128->256 @64^2 pooled", T3, S1, 32, 64, 128, 256, 256, 128, ["pool"]),
+    ("up-conv dgrad 384->512 @16^2 pooled", HALF, S1, 128, 16, 384, 512, 512, 384, ["pool"]),
+    # edge convs (model/nn.py:193-194) at C = 65: K padded 65 -> 128 with zero channels; 65 real output rows in a 128-wide buffer
+    ("network input 65(128)->128 @128^2", T3, S1, 16, 128, 128, 128, 128, 65, ["bias+lnf", "bias"]),
+    ("network output 128->65(128) @128^2", T3, S1, 16, 128, 128, 128, 65, 128, ["bias"]),
+    # stride-2 family (model/nn.py:169-174): forward on the gather kernel, input gradient per output-parity class (+ skip gradient)
+    ("down 128->128 128^2->64^2", GATHER, S2, 16, 128, 128, 128, 128, 128, ["bias"]),
+    ("down 256->384 32^2->16^2", GATHER, S2, 128, 32, 256, 384, 384, 256, ["bias"]),
+    ("down dgrad 128->128 64^2->128^2", TS2P, TS2, 16, 64, 128, 128, 128, 128, ["res"]),
+    ("down dgrad 384->256 16^2->32^2", TS2P, TS2, 128, 16, 384, 256, 256, 384, ["res"]),
+    ("down dgrad 512->384 8^2->16^2", GATHER, TS2, 128, 8, 512, 384, 384, 512, ["res"]),
+]
+
+
+def _run_conv_case(case, dt, ep):
+    name, fam, mode, B, Hin, Cin, Cout, wrows, cin_real, _ = case
+    Hout = out_hw(mode, Hin)
+    g = geom(B, Hin, Hin, Cin, Hout, Hout, Cout, Cout, wrows, mode)
+    parts = ep.split("+")
+    pool = "pool" in parts
+    want_lnf, want_lnb = "lnf" in parts, "lnb" in parts
+    assert ops.conv_dispatch(g, dt, pool2=pool, fused_ln=want_lnf or want_lnb) == fam, f"{name}: not on the kernel family this case is for"
+    npix_in, npix = B * Hin * Hin, B * Hout * Hout
+    x = rnd((npix_in, Cin), dt, 1)
+    w = rnd((wrows, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * cin_real))
+    if cin_real < Cin:  # the padded network-input operand: channels >= 65 are zero in both operands (engine._w, nchw_to_nhwc)
+        x[:, cin_real:] = 0
+        w[:, :, cin_real:] = 0
+    bias = rnd((wrows,), F32, 3) if "bias" in parts else None
+    res = rnd((npix, Cout), dt, 4) if "res" in parts else None
+    m = rnd((B, Cout + 64), F32, 6)
+    rows_out = npix // 4 if pool else npix
+    y = torch.full((rows_out, Cout), 7.0, dtype=TD[dt], device=dev())
+    y_ref = y.clone()
+    kw, kw_ref, extra = {}, {}, []
+    if "silu" in parts:
+        kw["act"] = ops.ACT_SILU
+    if "pair" in parts:
+        y2, y2_ref = torch.full_like(y, 3.0), torch.full_like(y, 3.0)
+        kw, kw_ref = dict(act=ops.ACT_SILU_PAIR, y2=y2), dict(act=ops.ACT_SILU_PAIR, y2=y2_ref)
+        extra.append((y2, y2_ref, "silu' output"))
+    if "mulp" in parts:
+        kw["mul"] = rnd((npix, Cout), dt, 5)
+        kw["mulmode"] = ops.MUL_PLAIN
+    if pool:
+        kw["pool2"] = True
+    if want_lnf:
+        assert ops.conv_lnfwd_supported(g, dt)
+        hn, hn_ref = torch.full_like(y, 3.0), torch.full_like(y, 3.0)
+        lnf = dict(m=m.view(-1)[32:], ldm=Cout + 64, eps=1e-5, unbiased=True)
+        kw, kw_ref = dict(lnf=dict(lnf, y=hn)), dict(lnf=dict(lnf, y=hn_ref))
+        extra.append((hn, hn_ref, "fused LayerNorm output"))
+    if want_lnb:
+        assert ops.conv_lnbwd_supported(g, dt)
+        dm, dm_ref = torch.zeros_like(m), torch.zeros_like(m)
+        ln = dict(x=rnd((npix, Cout), dt, 7), m=m.view(-1)[32:], ldm=Cout + 64, eps=1e-5, unbiased=True)
+        kw, kw_ref = dict(ln=dict(ln, dm=dm.view(-1)[32:])), dict(ln=dict(ln, dm=dm_ref.view(-1)[32:]))
+    if not kw_ref:
+        kw_ref = kw
+    ops.conv(x, w, bias, y, g, dt, res=res, **kw)
+    E.conv(x, w, bias, y_ref, g, dt, res=res, **kw_ref)
+    torch.cuda.synchronize()
+    close(y, y_ref, TOL[dt], f"{name} [{ep}]")
+    for a, b, what in extra:
+        close(a, b, TOL[dt], f"{name} [{ep}] {what}")
+    if want_lnb:
+        close(dm, dm_ref, 1e-2, f"{name} [{ep}] modulation gradient")
+    if wrows < Cout:
+        assert y[:, wrows:].abs().max().item() == 0.0, f"{name}: padded output rows must stay zero"
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("case", FWD_CASES, ids=[c[0] for c in FWD_CASES])
+def test_conv_kernels_at_the_bench_dispatch(case, dt):
+    for ep in case[-1]:
+        _run_conv_case(case, dt, ep)
+
+
+# (name, kernel family, mode, B, Hin, Cin, rows, ldy, cin_real)
+WGRAD_CASES = [
+    ("128->128 @128^2, B = 128 (the dominant weight gradient at the bench's split count)", HALF, S1, 128, 128, 128, 128, 128, 128),
+    ("128->128 @64^2", HALF, S1, 128, 64, 128, 128, 128, 128),
+    ("256->256 @32^2", HALF, S1, 128, 32, 256, 256, 256, 256),
+    ("384->384 @16^2", HALF, S1, 128, 16, 384, 384, 384, 384),
+    ("512->512 @8^2 (paired images)", PAIR, S1, 128, 8, 512, 512, 512, 512),
+    ("up 512->384 8^2->16^2", HALF, UP, 128, 8, 512, 384, 384, 512),
+    ("up 384->256 16^2->32^2", HALF, UP, 128, 16, 384, 256, 256, 384),
+    ("up 256->128 32^2->64^2", HALF, UP, 128, 32, 256, 128, 128, 256),
+    ("up 128->128 64^2->128^2", HALF, UP, 32, 64, 128, 128, 128, 128),
+    ("network input 65(128)->128 @128^2", HALF, S1, 32, 128, 128, 128, 128, 65),
+    ("network output 128->65 @128^2 (65 gradient rows of a 128-wide dY)", HALF, S1, 32, 128, 128, 65, 128, 128),
+    ("down 128->128 128^2->64^2", GATHER, S2, 32, 128, 128, 128, 128, 128),
+    ("down 384->512 16^2->8^2", GATHER, S2, 128, 16, 384, 512, 512, 384),
+]
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_weight_gradient_kernels_at_the_bench_dispatch(case, dt):
+    """c2w_conv_wgrad with the per-call workspace (the engine's path: split-K partial sums stored, then reduced in a fixed order) on the
+    geometries and batch of the bench's step, against autograd of the PyTorch restatement; a second run must reproduce the first bit
+    for bit."""
+    name, fam, mode, B, Hin, Cin, rows, ldy, cin_real = case
+    Hout = out_hw(mode, Hin)
+    g = geom(B, Hin, Hin, Cin, Hout, Hout, rows, ldy, rows, mode)
+    assert ops.conv_wgrad_dispatch(g, dt) == fam, name
+    x = rnd((B * Hin * Hin, Cin), dt, 1)
+    if cin_real < Cin:
+        x[:, cin_real:] = 0
+    dy = rnd((B * Hout * Hout, ldy), dt, 2)
+    if rows < ldy:
+        dy[:, rows:] = 0  # what mse_loss_grad leaves in the padding channels
+    ws = ops.new_workspace(dev())
+    need = ops.conv_wgrad_workspace_bytes(g, dt)
+    assert 0 < need <= ops.WORKSPACE_BYTES, f"{name}: expected a split reduction through the workspace"
+    dw = torch.zeros(rows * 9 * Cin + 64, dtype=torch.float32, device=dev())
+    db = torch.zeros(rows + 8, dtype=torch.float32, device=dev())
+    dw_ref, db_ref = dw.clone(), db.clone()
+    ops.conv_wgrad(x, dy, dw, g, dt, dbias=db, workspace=ws)
+    E.conv_wgrad(x, dy, dw_ref, g, dt, dbias=db_ref)
+    torch.cuda.synchronize()
+    close(dw, dw_ref, TOL_W[dt], name)
+    close(db, db_ref, TOL_W[dt], name + " bias")
+    assert dw[-64:].abs().max().item() == 0.0 and db[rows:].abs().max().item() == 0.0
+    if cin_real < Cin:
+        assert dw[: rows * 9 * Cin].view(rows, 9, Cin)[:, :, cin_real:].abs().max().item() == 0.0
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    ops.conv_wgrad(x, dy, dw2, g, dt, dbias=db2, workspace=ws)
+    assert torch.equal(dw, dw2), f"{name}: the workspace reduction must be deterministic"
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_attention_block_kernels_at_the_bench_batch(dt):
+    """model/nn.py:31-85 at B = 128, 8x8 tokens, 512 channels: LayerNorm over the channel axis, qkv / proj 1x1 convs and their input /
+    weight gradients (gather kernels, 8192 "pixels"), the matrix-core attention forward and backward."""
+    B, T, C = 128, 64, 512
+    npix = B * T
+    x = rnd((npix, C), dt, 1)
+    hl, hl_ref = torch.empty_like(x), torch.empty_like(x)
+    ops.ln_forward(x, None, hl, npix, T, C, 0, 1e-5, True, dt)
+    E.ln_forward(x, None, hl_ref, npix, T, C, 0, 1e-5, True, dt)
+    close(hl, hl_ref, TOL[dt], "LayerNorm(512) forward")
+    for rows, use_res in ((3 * C, False), (C, True)):
+        g = geom(npix, 1, 1, C, 1, 1, rows, rows, rows, K1)
+        assert ops.conv_dispatch(g, dt) == GATHER
+        w = rnd((rows, 1, C), dt, 2, scale=1.0 / math.sqrt(C))
+        bias = rnd((rows,), F32, 3)
+        res = rnd((npix, rows), dt, 4) if use_res else None
+        y = torch.full((npix, rows), 7.0, dtype=TD[dt], device=dev())
+        y_ref = y.clone()
+        ops.conv(hl_ref, w, bias, y, g, dt, res=res)
+        E.conv(hl_ref, w, bias, y_ref, g, dt, res=res)
+        close(y, y_ref, TOL[dt], f"1x1 512->{rows}")
+        dy = rnd((npix, rows), dt, 5)
+        dw = torch.zeros(rows * C, dtype=torch.float32, device=dev())
+        db = torch.zeros(rows, dtype=torch.float32, device=dev())
+        dw_ref, db_ref = dw.clone(), db.clone()
+        ops.conv_wgrad(hl_ref, dy, dw, g, dt, dbias=db, workspace=ops.new_workspace(dev()))
+        E.conv_wgrad(hl_ref, dy, dw_ref, g, dt, dbias=db_ref)
+        close(dw, dw_ref, TOL_W[dt], f"1x1 512->{rows} weight gradient")
+        close(db, db_ref, TOL_W[dt], f"1x1 512->{rows} bias gradient")
+        gd = geom(npix, 1, 1, rows, 1, 1, C, C, C, K1)  # input gradient: the same GEMM over dy with the transposed weights
+        wT = rnd((C, 1, rows), dt, 6, scale=1.0 / math.sqrt(rows))
+        dx, dx_ref = torch.empty((npix, C), dtype=TD[dt], device=dev()), torch.empty((npix, C), dtype=TD[dt], device=dev())
+        ops.conv(dy, wT, None, dx, gd, dt)
+        E.conv(dy, wT, None, dx_ref, gd, dt)
+        close(dx, dx_ref, TOL[dt], f"1x1 {rows}->512 input gradient")
+    qkv = rnd((npix, 3 * C), dt, 7, scale=1.5)
+    o, o_ref = torch.empty((npix, C), dtype=TD[dt], device=dev()), torch.empty((npix, C), dtype=TD[dt], device=dev())
+    lse, lse_ref = torch.empty(npix, device=dev()), torch.empty(npix, device=dev())
+    ops.attention_forward(qkv, o, lse, B, T, C, dt)
+    E.attention_forward(qkv, o_ref, lse_ref, B, T, C, dt)
+    close(o, o_ref, TOL[dt], "attention forward")
+    close(lse, lse_ref, 1e-4, "attention lse")
+    do = rnd((npix, C), dt, 8)
+    dq, dq_ref = torch.empty_like(qkv), torch.empty_like(qkv)
+    delta = torch.empty(npix, device=dev())
+    ops.attention_backward(qkv, o_ref, do, lse_ref, delta, dq, B, T, C, dt)
+    E.attention_backward(qkv, o_ref, do, lse_ref, delta, dq_ref, B, T, C, dt)
+    close(dq, dq_ref, TOL[dt], "attention backward")
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("HW,C", [(1024, 256), (256, 384), (64, 512), (4096, 128)])
+def test_layernorm_passes_at_the_bench_batch(HW, C, dt):
+    """The separate LayerNorm passes of the step (the 256 / 384 / 512-channel levels, where the conv epilogues do not hold a whole
+    channel row; 128 channels for the up-block's input) at B = 128 with per-sample modulation rows."""
+    B = 128
+    npix = B * HW
+    x = rnd((npix, C), dt, 1)
+    m = rnd((B, C + 64), F32, 2)
+    mm, ldm = m.view(-1)[32:], C + 64
+    y, y_ref = torch.empty_like(x), torch.empty_like(x)
+    ops.ln_forward(x, mm, y, npix, HW, C, ldm, 1e-5, True, dt)
+    E.ln_forward(x, mm, y_ref, npix, HW, C, ldm, 1e-5, True, dt)
+    close(y, y_ref, TOL[dt], "ln fwd")
+    dy, dres = rnd((npix, C), dt, 3), rnd((npix, C), dt, 4)
+    dx, dx_ref = torch.empty_like(x), torch.empty_like(x)
+    dm, dm_ref = torch.zeros_like(m), torch.zeros_like(m)
+    ops.ln_backward(dy, x, mm, dres, dx, dm.view(-1)[32:], npix, HW, C, ldm, 1e-5, True, dt)
+    E.ln_backward(dy, x, mm, dres, dx_ref, dm_ref.view(-1)[32:], npix, HW, C, ldm, 1e-5, True, dt)
+    close(dx, dx_ref, TOL[dt], "ln bwd dx")
+    close(dm, dm_ref, 1e-2, "ln bwd dm")
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+DEFAULT = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3,
+               padding_mode="zeros", attention_levels=[4])
+# (loss, per-tensor |g|_2, full gradient tensors) of the scale; observed values are appended to gpurun_out/bench_step_parity.txt
+STEP_TOL = {"bf16": (3e-4, 1e-2, 4e-2), "fp16": (3e-5, 2e-3, 8e-3)}
+
+
+def test_trainer_forward_backward_at_bench_size_vs_cpu_oracle():
+    """The timed path itself against the oracle: Trainer._forward_backward (what bench.py's step runs before the optimizer:
+    training_loop.py:376-378) on the default network at the bench's own B = 128, C = 65, 128x128, in bf16 and in fp16, with injected
+    (t, eps); the CPU oracle (oracle/unet.py, oracle/diffusion.py) computes loss and all 228 gradients of the same batch in 8 chunks
+    of 16 windows on the box's host cores (about a minute).  Loss, every gradient's L2 norm and every gradient tensor in full."""
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+    from oracle import diffusion as od
+    from oracle import unet as ou
+    B, C, H, CH = 128, 65, 128, 16
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(128)
+    x = torch.randn(B, C, H, H, generator=gen) * 0.5 + 0.5
+    t = torch.rand(B, generator=gen)
+    eps = torch.randn(B, C, H, H, generator=gen)
+    # ---- oracle, chunked: d/dtheta of sum_chunk((y - eps)^2) / N accumulates to the gradient of the batch mean
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # BASELINE.md section 3 sweep: more threads are slower on the 256-thread hosts
+    N = float(B * C * H * H)
+    names = list(sd)
+    g_ref = [torch.zeros_like(v) for v in sd.values()]
+    loss_ref = 0.0
+    for i in range(0, B, CH):
+        xt = od.perturb(x[i:i + CH], t[i:i + CH].view(-1, 1, 1, 1), eps[i:i + CH])
+        y = ou.score_unet_forward(sd, xt, t[i:i + CH], DEFAULT["hidden_blocks"], DEFAULT["attention_levels"])
+        part = ((y - eps[i:i + CH]) ** 2).sum() / N
+        for acc, gr in zip(g_ref, torch.autograd.grad(part, list(sd.values()))):
+            acc += gr
+        loss_ref += part.item()
+        del y, part, xt
+    torch.set_num_threads(nthreads)
+    # ---- the product path
+    net = net.cuda()
+    xd, td, epsd = x.cuda(), t.cuda(), eps.cuda()
+    report = []
+    for mode, (tl, tn, tg) in STEP_TOL.items():
+        tr = Trainer(net, precision=mode, ema_rates=())
+        tr.eng.flat_grad.zero_()
+        loss = tr._forward_backward(xd, td, epsd, sync=False)
+        torch.cuda.synchronize()
+        S = tr.loss_scale()
+        e_loss = abs(loss.item() - loss_ref) / loss_ref
+        named = dict(net.named_parameters())
+        e_norm, e_full = (0.0, ""), (0.0, "")
+        for n, gr in zip(names, g_ref):
+            got = named[n].grad.detach().double().cpu() / S
+            ref = gr.double()
+            e_norm = max(e_norm, (abs(got.norm().item() - ref.norm().item()) / ref.norm().item(), n))
+            e_full = max(e_full, ((got - ref).abs().max().item() / ref.abs().max().item(), n))
+        report.append(f"B={B} C={C} {mode}: loss {e_loss:.2e}  |g|_2 {e_norm[0]:.2e} ({e_norm[1]})  full tensors {e_full[0]:.2e} ({e_full[1]})")
+        assert e_loss <= tl, report[-1]
+        assert e_norm[0] <= tn, report[-1]
+        assert e_full[0] <= tg, report[-1]
+        del tr
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "bench_step_parity.txt"), "a") as f:
+        f.write("\n".join(report) + "\n")
