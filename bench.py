@@ -54,11 +54,33 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------------------------------- launcher
-def launch(a) -> int:
-    """`--gpus N` without a launcher's environment: one child process per GPU (this parent initialises no GPU: counting devices
-    does not), rendezvous on 127.0.0.1, rank 0's stdout is relayed, everything else goes to stderr."""
-    visible = torch.cuda.device_count()
-    if visible < a.gpus:
+def visible_gpus():
+    """GPUs this process tree may use, counted WITHOUT a HIP / HSA call (the parent must stay GPU-free: it only starts the ranks):
+    KFD topology nodes with SIMDs (/sys/class/kfd/kfd/topology/nodes/*/properties: CPU nodes have simd_count 0), narrowed by the
+    *_VISIBLE_DEVICES masks.  None when the topology is not readable (then --gpus is trusted and a rank without a device fails)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in sorted(os.listdir(root)):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        mask = os.environ.get(var)
+        if mask is not None:
+            n = min(n, len([m for m in mask.split(",") if m.strip() != ""]))
+    return n
+
+
+def launch(a, popen=subprocess.Popen, count=visible_gpus) -> int:
+    """`--gpus N` without a launcher's environment: one child process per GPU (what fabric.launch() does for the reference,
+    train.py:93-100), rendezvous on 127.0.0.1, rank 0's stdout is relayed, everything else goes to stderr.  This parent makes no HIP
+    call (devices are counted from the KFD topology in sysfs); the children are fresh interpreters."""
+    visible = count()
+    if visible is not None and visible < a.gpus:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but only {visible} GPU(s) are visible; refusing to report fewer ranks than asked for\n")
         return 2
     s = socket.socket()
@@ -69,8 +91,8 @@ def launch(a) -> int:
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                           stdout=subprocess.PIPE if r == 0 else sys.stderr))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode]
     deadline = time.time() + 120

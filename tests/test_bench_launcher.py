@@ -1,0 +1,103 @@
+"""bench.py's own rank launcher (`python bench.py --gpus N` without torch.distributed.run: what fabric.launch() does for the
+reference, train.py:93-100) on the CPU, with subprocess.Popen replaced by a recorder: per-child RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* wiring, rank 0's stdout relayed, a dead rank turns into a non-zero exit status, more ranks than visible GPUs are refused,
+and the parent never asks HIP for the device count."""
+import argparse
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+class FakeProc:
+    def __init__(self, argv, env, stdout, rc=0, out=b"", hang=False):
+        self.argv, self.env, self.stdout_arg, self.returncode_final, self.out, self.hang = argv, env, stdout, rc, out, hang
+        self.returncode = None
+        self.killed = False
+
+    def communicate(self):
+        self.returncode = self.returncode_final
+        return self.out, None
+
+    def wait(self, timeout=None):
+        if self.hang and not self.killed:
+            raise subprocess.TimeoutExpired(self.argv, timeout)
+        self.returncode = -9 if self.killed else self.returncode_final
+        return self.returncode
+
+    def kill(self):
+        self.killed = True
+
+
+def _launch(n, rcs=None, hang=None, count=lambda: 8, monkeypatch=None):
+    procs = []
+
+    def popen(argv, env=None, stdout=None):
+        r = len(procs)
+        p = FakeProc(argv, env, stdout, rc=(rcs or {}).get(r, 0), out=b'{"metric": "m", "n_gpus": %d}\n' % n if r == 0 else b"", hang=r == hang)
+        procs.append(p)
+        return p
+    a = argparse.Namespace(gpus=n)
+    return bench.launch(a, popen=popen, count=count), procs
+
+
+def test_launcher_wires_one_rank_per_gpu(capsys, monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc, procs = _launch(4)
+    assert rc == 0 and len(procs) == 4
+    ports = {p.env["MASTER_PORT"] for p in procs}
+    assert len(ports) == 1 and 1024 < int(next(iter(ports))) < 65536
+    for r, p in enumerate(procs):
+        assert p.argv[0] == sys.executable and p.argv[1] == os.path.abspath(bench.__file__) and p.argv[2:] == ["--gpus", "4", "--steps", "3"]
+        assert (p.env["RANK"], p.env["LOCAL_RANK"], p.env["WORLD_SIZE"], p.env["LOCAL_WORLD_SIZE"]) == (str(r), str(r), "4", "4")
+        assert p.env["MASTER_ADDR"] == "127.0.0.1" and p.env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert (p.stdout_arg == subprocess.PIPE) == (r == 0)  # only rank 0's stdout is captured: it carries the one JSON line
+    assert capsys.readouterr().out == '{"metric": "m", "n_gpus": 4}\n'
+    # a child under this environment goes straight to run_rank(): main() only launches when WORLD_SIZE is absent
+    assert "WORLD_SIZE" in procs[0].env
+
+
+def test_launcher_reports_a_dead_or_stuck_rank(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    rc, _ = _launch(2, rcs={1: 1})
+    assert rc == 1
+    rc, _ = _launch(2, rcs={0: -11})  # rank 0 killed by a signal
+    assert rc == 11
+    monkeypatch.setattr(bench.time, "time", iter([0.0] + [1000.0] * 10).__next__)  # the 120-s grace period is over at once
+    rc, procs = _launch(3, hang=2)
+    assert procs[2].killed and rc == 9
+
+
+def test_launcher_refuses_more_ranks_than_gpus_and_never_calls_hip(monkeypatch, capsys):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: pytest.fail("the launcher parent must not ask HIP for the device count"))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: pytest.fail("the launcher parent must not initialise the GPU"))
+    rc, procs = _launch(4, count=lambda: 2)
+    assert rc == 2 and procs == [] and "only 2 GPU(s) are visible" in capsys.readouterr().err
+    rc, procs = _launch(4, count=lambda: None)  # topology unreadable: --gpus is trusted, a rank without a device fails by itself
+    assert rc == 0 and len(procs) == 4
+
+
+def test_visible_gpus_reads_the_kfd_topology(tmp_path, monkeypatch):
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):  # two CPU nodes, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_listdir, real_open = os.listdir, open
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    monkeypatch.setattr(bench.os, "listdir", lambda p: real_listdir(str(nodes)) if p == root else real_listdir(p))
+    import builtins
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace(root, str(nodes)), *a, **k))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
