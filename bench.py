@@ -479,6 +479,8 @@ def run_rank(a):
         del trainer, feed, ds
         torch.cuda.empty_cache()
         out["deep_variant"] = deep_variant(dev)
+        torch.cuda.empty_cache()
+        out["sampler_configs3"] = sampler_configs3(dev, a.precision if a.precision != "fp32" else "bf16")
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
@@ -548,6 +550,63 @@ def deep_variant(dev, B=32):
         res["sampler_steps_per_s" + ("_hipgraph" if graph else "_eager")] = round(1 / d, 2)
         res["sampler_window_forwards_per_s" + ("_hipgraph" if graph else "_eager")] = round((L - 2 * k) / d, 1)
     return res
+
+
+def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections=(0, 2), steps=3, members=8, log=None):
+    """BASELINE configs[3] as the reference runs it (exp/downscaling.py:208-265 with exp/configs/000_on-model-eval/s16_t6.yml and
+    001_clim-downscaling/biased_climate_hadgem.yml): F = 4 variables, k = 6 (window 13 -> 52 channels), 128x128, window batches of
+    128, CONDITIONED on A = AvgPool2d(16) o x[::6] with the shipped likelihood_std / likelihood_gamma (exact_grad = False), for the
+    shipped trajectory lengths L = 49 / 121 / 8737 hours and corrections 0 (shipped) and 2 (src/thor/pipelines.py:52 code default
+    is non-zero).  Per leg: sampler steps/s, window-forwards/s and the members/hour a 256-step run would give; plus `members`
+    co-sampled members at L = 49 (their windows share the network batches).  Synthetic state and observation."""
+    import contextlib, io
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.score_fn import BatchedScoreFunction, PoolStrideOperator
+    F, k, H = 4, 6, 128
+    w = 2 * k + 1
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=F * w, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev).eval()
+    net.precision = precision
+    pipe = SDAPipeline()
+    A = PoolStrideOperator(16, 6)
+    std = torch.tensor([0.1692666615037876, 0.0425178630338289, 0.3268027589410125, 0.3268027589410125]).view(1, F, 1, 1)
+    gamma = 0.0007196856730011522
+    legs = []
+
+    def leg(L, nmem, c):
+        shape = (L, F, H, H) if nmem == 1 else (nmem, L, F, H, H)
+        g = torch.Generator(device=dev).manual_seed(L)
+        truth = torch.randn((L, F, H, H), device=dev, generator=g) * 0.5 + 0.5
+        with contextlib.redirect_stdout(io.StringIO()):
+            sf = BatchedScoreFunction(net, markov_order=k, batch_size=128, device=dev, noise_process=pipe)
+            sf.condition_on(A=A, y=A(truth), std=std, gamma=gamma, exact_grad=False)
+            assert sf._fused_guidance is not None
+            del truth
+            noise = torch.randn(shape, device=dev, generator=g)
+            pipe.sample(sf, noise, steps=1, corrections=c, tau=0.5, device=dev, show_progressbar=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x = pipe.sample(sf, noise, steps=steps, corrections=c, tau=0.5, device=dev, show_progressbar=False)
+            torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        assert bool(torch.isfinite(x).all())
+        nwin = (L - w + 1) * nmem
+        r = dict(L=L, members=nmem, corrections=c, windows_per_score_evaluation=nwin, sampler_steps_per_s=round(1 / d, 3),
+                 ms_per_sampler_step=round(1e3 * d, 2), window_forwards_per_s=round(nwin * (1 + c) / d, 1),
+                 members_per_hour_at_256_steps=round(nmem * 3600.0 / (256 * d), 2))
+        legs.append(r)
+        if log is not None:
+            log(r)
+
+    for L in lengths:
+        for c in corrections:
+            leg(L, 1, c)
+    if members > 1:
+        for c in corrections:
+            leg(49, members, c)
+    return dict(config="F=4, k=6, 52 ch x 128x128, %s, window batch 128, conditioned on AvgPool2d(16) o x[::6] (s16_t6.yml std / gamma, exact_grad=False), "
+                       "%d timed sampler steps per leg after 1 warm-up step" % (precision, steps), legs=legs)
 
 
 def main():

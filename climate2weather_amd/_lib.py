@@ -92,7 +92,7 @@ _lib = None
 
 def exported_symbols():
     """Names include/c2w_hip.h declares (used by the CPU test that the library exports all of them)."""
-    return list(_PROTOS) + ["c2w_target"]
+    return list(_PROTOS) + ["c2w_target", "c2w_sources_sha256"]
 
 
 def load() -> ctypes.CDLL:
@@ -103,17 +103,19 @@ def load() -> ctypes.CDLL:
         raise C2wError(f"{LIB_PATH} is missing: run `python -m climate2weather_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback for the product path.")
     if not os.environ.get("C2W_LIB") and os.environ.get("C2W_ALLOW_STALE_LIB", "") in ("", "0"):
-        from . import build as _build  # content hash of csrc/ + include/ against the stamp the build wrote next to the objects
+        from . import build as _build  # content hash of csrc/ + include/ against the digest linked into the library
         if os.path.isdir(_build.CSRC) and _build._stale():
-            raise C2wError(f"{LIB_PATH} was not built from the sources on disk (stamp {_build.STAMP} missing or different): run "
+            raise C2wError(f"{LIB_PATH} was not built from the sources on disk (the digest compiled into it, c2w_sources_sha256 = "
+                           f"{_build.embedded_digest()}, differs from sha256(csrc/, include/) = {_build.sources_digest()[:16]}...): run "
                            "`python -m climate2weather_amd.build`.  Refusing to run kernels that do not match the source tree.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = c_longlong if name.endswith("_bytes") else c_int
-    lib.c2w_target.restype = c_char_p
-    lib.c2w_target.argtypes = []
+    for name in ("c2w_target", "c2w_sources_sha256"):
+        getattr(lib, name).restype = c_char_p
+        getattr(lib, name).argtypes = []
     _lib = lib
     return lib
 

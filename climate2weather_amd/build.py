@@ -39,12 +39,24 @@ def file_digest(path: str) -> str:
     return h.hexdigest()
 
 
+def embedded_digest(lib_path: str = LIB):
+    """The source digest compiled INTO the library (c2w_sources_sha256), or None if the file is missing / predates the symbol.  The
+    library carries its own provenance: a .so copied next to the sources without the build directory still identifies itself."""
+    if not os.path.exists(lib_path):
+        return None
+    import ctypes
+    try:
+        fn = ctypes.CDLL(lib_path).c2w_sources_sha256
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    fn.argtypes = []
+    return fn().decode()
+
+
 def _stale() -> bool:
     """The library is reused only if it was built from exactly these sources (content hash, not mtimes: a copied tree has neither)."""
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
-        return True
-    with open(STAMP) as f:
-        return f.read().split()[:1] != [sources_digest()]
+    return embedded_digest() != sources_digest()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -72,12 +84,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {src}")
+    digest = sources_digest()
+    dsrc = os.path.join(HERE, "build", "sources_digest.cpp")
+    with open(dsrc, "w") as f:  # generated, outside csrc/: the digest of the sources is linked into the library built from them
+        f.write('extern "C" const char* c2w_sources_sha256(void) { return "%s"; }\n' % digest)
+    dobj = dsrc.replace(".cpp", ".o")
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O1", "-fPIC", "-c", dsrc, "-o", dobj])
+    objs.append(dobj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
-        f.write(sources_digest() + "\n")
+    with open(STAMP, "w") as f:  # informational only: the check reads the digest out of the library itself
+        f.write(digest + "\n")
     if verbose:
         print(f"compiled {len(objs)} translation units for gfx950 -> {LIB}: sources sha256 {sources_digest()[:16]}, library sha256 {file_digest(LIB)[:16]}",
               flush=True)

@@ -48,6 +48,7 @@ int c2w_conv_patch3(const C2wConvArgs& a, int dtype, hipStream_t st);
 
 // halo-patch weight-gradient kernel for the same convolutions (wgrad_patch.hip)
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a);
+bool c2w_wgrad_patch_pair(const C2wConvArgs& a);  // 8-pixel-wide images: two per K tile
 // ws / ws_bytes: the caller's scratch buffer for the split-K partial sums (NULL / too small: fp32 atomics)
 int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, int dtype, hipStream_t st);
 size_t c2w_wgrad_patch_ws_bytes(const C2wConvArgs& a, int dtype);

@@ -440,7 +440,7 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, voi
 extern "C" int c2w_conv_wgrad_dispatch(const C2wConvArgs* a, int dtype) {
     const int rc = wgrad_check(a, dtype);
     if (rc != 0) return rc;
-    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return a->Win == 8 ? C2W_KERNEL_PATCH_PAIR : C2W_KERNEL_PATCH_8X16;
+    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch_pair(*a) ? C2W_KERNEL_PATCH_PAIR : C2W_KERNEL_PATCH_8X16;
     return C2W_KERNEL_GATHER;
 }
 

@@ -503,7 +503,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
 
 }  // namespace
 
-static bool wgrad_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per K tile
+bool c2w_wgrad_patch_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per K tile
     static const bool off = getenv("C2W_CONV_PAIR") != nullptr && atoi(getenv("C2W_CONV_PAIR")) == 0;
     return !off && a.mode == C2W_CONV_S1 && a.Win == 8 && a.Hin == 8;
 }
@@ -511,11 +511,11 @@ static bool wgrad_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per 
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
     if (a.mode == C2W_CONV_UP)  // nearest-neighbour x2 upsampling folded into the patch load
         return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hout & 7) == 0 && (a.Wout & 15) == 0 && getenv("C2W_NO_UP_PATCH") == nullptr;
-    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && ((a.Win & 15) == 0 || wgrad_pair(a));
+    return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && ((a.Win & 15) == 0 || c2w_wgrad_patch_pair(a));
 }
 
 int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, int dtype, hipStream_t st) {
-    if (wgrad_pair(a)) {
+    if (c2w_wgrad_patch_pair(a)) {
         if (dtype == C2W_DTYPE_F32) return launch<float, true>(a, dw, db, ws, ws_bytes, st);
         if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, true>(a, dw, db, ws, ws_bytes, st);
         if (dtype == C2W_DTYPE_F16) return launch<f16_t, true>(a, dw, db, ws, ws_bytes, st);
@@ -528,7 +528,7 @@ int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_
 }
 
 size_t c2w_wgrad_patch_ws_bytes(const C2wConvArgs& a, int dtype) {
-    const bool pair = wgrad_pair(a);
+    const bool pair = c2w_wgrad_patch_pair(a);
     if (dtype == C2W_DTYPE_F32) return pair ? ws_need<4, true>(a) : ws_need<4, false>(a);
     return pair ? ws_need<2, true>(a) : ws_need<2, false>(a);
 }

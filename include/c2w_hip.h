@@ -245,6 +245,9 @@ int c2w_affine_channels(const float* x, float* y, const float* scale, const floa
 
 /* library identity: returns the gfx target string the kernels were compiled for ("gfx950") */
 const char* c2w_target(void);
+/* provenance: hex sha256 over the sources (csrc/, include/c2w_hip.h, compile flags) this library was built from; the Python loader
+ * refuses a library whose digest differs from the source tree next to it (climate2weather_amd/build.py) */
+const char* c2w_sources_sha256(void);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,83 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_
     dist.destroy_process_group()
 
 
+def run_chase(rank: int, world: int, port: int, golden_dir: str, out_dir: str, backend: str = "gloo"):
+    """Two optimizer steps with the update chasing the backward per finished bucket (Trainer.chase_optimizer / C2W_CHASE_OPT=1: the
+    all-reduce AND the fused AdamW + EMA of a bucket are issued while the rest of the backward still runs) and two with the update
+    behind the whole backward, from the same initial weights, several buckets: the weights must be the same."""
+    dev = _init(rank, world, port, backend)
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+
+    g = np.load(os.path.join(golden_dir, "tiny_net.npz"))
+    if world == 1:
+        os.environ["C2W_FORCE_DIST"] = "1"
+    x, t, eps = (torch.from_numpy(g[k]).to(dev) for k in ("x", "t", "eps"))
+    per = x.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    res = {}
+    for chase in (False, True):
+        torch.manual_seed(3)
+        net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
+                        attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev)
+        tr = Trainer(net, lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=0.05)
+        tr.chase_optimizer = chase
+        assert tr.sync_grads and len(tr.buckets) > 4
+        calls = []
+        orig = tr._update_range
+        tr._update_range = lambda s, e, lr, step, _o=orig: (calls.append((s, e)), _o(s, e, lr, step))[1]
+        for _ in range(2):
+            loss = tr.step(x[sl].contiguous(), t=t[sl].reshape(-1), eps=eps[sl].contiguous())
+        res[chase] = dict(loss=float(loss), sd={k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
+                          ema=tr.ema_flats[0].detach().cpu().clone(), update_calls=len(calls))
+    torch.save(res, os.path.join(out_dir, f"chase{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_full_size(rank: int, world: int, port: int, out_dir: str, steps: int = 3, batch: int = 16):
+    """The bench's own network (default configs/sda_unet.yml, C = 65, 128x128) in bf16 through a real RCCL communicator: every one of
+    the 25-MB buckets of the 288-MB gradient buffer is all-reduced from the gradient stream while wgrad_patch_kernel / conv_patch
+    launches of the same backward are still running.  Against the same steps without a process group (same seeds, same batches)."""
+    dev = _init(rank, world, port, "nccl")
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+    cfg = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3, padding_mode="zeros",
+               attention_levels=[4])
+    gen = torch.Generator().manual_seed(5 + rank)
+    xs = [(torch.randn(batch, 65, 128, 128, generator=gen) * 0.5 + 0.5).to(dev) for _ in range(steps)]
+    ts = [torch.rand(batch, generator=gen).to(dev) for _ in range(steps)]
+    res = {}
+    for mode in ("dist", "plain"):
+        if mode == "dist":
+            os.environ["C2W_FORCE_DIST"] = "1"
+        else:
+            os.environ.pop("C2W_FORCE_DIST", None)
+        torch.manual_seed(0)
+        net = ScoreUNet(channels=65, spatial=2, activation=torch.nn.SiLU, **cfg).to(dev)
+        tr = Trainer(net, lr=1e-4, precision="bf16", ema_rates=[0.9999], seed=11)
+        assert tr.sync_grads == (mode == "dist" or world > 1)
+        n_ar = [0]
+        orig = dist.all_reduce
+
+        def counting(*a, **k):
+            n_ar[0] += 1
+            return orig(*a, **k)
+        dist.all_reduce = counting
+        try:
+            losses = [float(tr.step(x, t=t)) for x, t in zip(xs, ts)]
+        finally:
+            dist.all_reduce = orig
+        torch.cuda.synchronize()
+        res[mode] = dict(losses=losses, flat=tr.eng.flat.detach().cpu().clone(), nb=len(tr.buckets), all_reduces=n_ar[0],
+                         on_side_stream=tr.eng.grad_stream() is not None)
+        del tr, net
+        torch.cuda.empty_cache()
+    torch.save(res, os.path.join(out_dir, f"full{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def run_module_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
     """The reference's own training-loop shape (training_loop.py:116,369-391): the module wrapped in torch DDP, autograd
     backward, torch.optim.AdamW over net.parameters() -- the drop-in seam with nothing replaced but the class name."""

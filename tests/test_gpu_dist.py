@@ -66,6 +66,48 @@ def test_training_step_over_rccl_two_ranks_equals_single_process(golden_dir, tmp
     _check_step(golden_dir, tmp_path, 2, bucket_mb)
 
 
+@pytest.mark.parametrize("world", [1, pytest.param(2, marks=two_gpus)])
+def test_optimizer_chasing_the_backward_over_rccl(golden_dir, tmp_path, world):
+    """Trainer.chase_optimizer (C2W_CHASE_OPT=1) through RCCL: all-reduce + fused AdamW + EMA per finished bucket on the gradient
+    stream while the backward runs, against the update behind the backward: same weights after two steps."""
+    import torch.multiprocessing as mp
+    from _ddp_worker import run_chase
+    mp.spawn(run_chase, args=(world, _free_port(), golden_dir, str(tmp_path), "nccl"), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"chase{r}.pt", weights_only=False) for r in range(world)]
+    for r in outs:
+        assert r[True]["update_calls"] > 2 * 4 and r[False]["update_calls"] == 2
+        for k, v in r[False]["sd"].items():
+            # same arithmetic per element; the gradients themselves carry fp32-atomics order noise (LayerNorm dm, loss sums)
+            assert (v - r[True]["sd"][k]).abs().max().item() <= 2e-6 + 1e-5 * v.abs().max().item(), k
+    for r in outs[1:]:
+        for k, v in outs[0][True]["sd"].items():
+            assert torch.equal(v, r[True]["sd"][k]), k
+
+
+@pytest.mark.parametrize("world", [1, pytest.param(2, marks=two_gpus)])
+def test_full_size_bf16_steps_through_an_rccl_communicator(tmp_path, world):
+    """The bench's network and precision through RCCL (one rank on every box, two where two GPUs are visible): 12 buckets of 25 MB
+    all-reduced from the gradient stream per step, next to the real wgrad_patch / conv_patch launches; the weights follow the same
+    steps taken without a process group."""
+    import torch.multiprocessing as mp
+    from _ddp_worker import run_full_size
+    mp.spawn(run_full_size, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"full{r}.pt", weights_only=False) for r in range(world)]
+    for o in outs:
+        d, p = o["dist"], o["plain"]
+        assert d["nb"] == 12 and d["all_reduces"] == 3 * 12 and d["on_side_stream"]
+        assert all(np.isfinite(d["losses"])) and all(np.isfinite(p["losses"]))
+    if world == 1:  # a one-rank sum is the identity: the communicator must not change the step
+        d, p = outs[0]["dist"], outs[0]["plain"]
+        assert p["all_reduces"] == 0
+        assert d["losses"] == pytest.approx(p["losses"], rel=2e-3)
+        # three AdamW steps of lr 1e-4 move a weight by <= 3e-4; bf16 gradients + atomics-order noise may flip g/(|g| + eps) where |g| ~ eps
+        assert (d["flat"] - p["flat"]).abs().max().item() <= 6.5e-4
+        assert (d["flat"] - p["flat"]).abs().mean().item() <= 2e-5
+    else:
+        assert torch.equal(outs[0]["dist"]["flat"], outs[1]["dist"]["flat"])  # ranks in lock step
+
+
 @two_gpus
 def test_time_sharded_sampler_over_rccl_two_ranks(golden_dir, tmp_path):
     import torch.multiprocessing as mp

@@ -681,3 +681,64 @@ def test_lazy_window_batches_train_like_gathered_ones(prec):
     assert ops.nchw_to_nhwc_noise(batch.materialize().contiguous(), 123456789, musig, b, 5, 6, 32 * 32, ld, dt)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and float(a.float().abs().sum()) > 0
+
+
+def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_reference():
+    """exp/configs/001_clim-downscaling/biased_climate_hadgem.yml: num_hours = 8737, batch_size = 128, conditioned (t_step 6, s_step 16,
+    the shipped likelihood_std / gamma, exact_grad = False) on the default network (F = 4, k = 6 -> 52 channels), bf16.  One score
+    evaluation = 8725 windows in 69 batches over a 2.3 GB trajectory.  Size-independent properties of src/thor/score.py:76-88,143-185:
+      * fold: frame i of eps (k <= i < L - k) is the CENTRE frame of window i - k's network output, frames 0..k-1 are the leading frames
+        of the first window, frames L-k..L-1 the trailing frames of the last -- checked against the module called directly on the first,
+        the last and a few middle window batches (same 128-window batches -> the same launches -> bit-equal);
+      * conditioning is frame-local: the conditioned evaluation == guidance applied to the unconditioned one (bit-equal), and frames
+        that are not observed (i % 6 != 0) keep the unconditioned score."""
+    L, Fv, k, H = 8737, 4, 6, 128
+    w = 2 * k + 1
+    nwin = L - w + 1
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=Fv * w, spatial=2, activation=torch.nn.SiLU, **DEFAULT).to(dev).eval()
+    net.precision = "bf16"
+    pipe = SDAPipeline()
+    g = torch.Generator(device=dev).manual_seed(8737)
+    x = torch.randn((L, Fv, H, H), device=dev, generator=g)
+    t = torch.tensor(0.7)
+    sf = BatchedScoreFunction(net, markov_order=k, batch_size=128, device=dev, noise_process=pipe)
+    with torch.no_grad():
+        eps_u = sf(x, t).clone()
+        assert eps_u.shape == x.shape and bool(torch.isfinite(eps_u).all())
+        # fold against direct module calls on whole batches of the evaluation (first, two middle ones, the ragged last: 8725 = 68 * 128 + 21)
+        for b0 in (0, 128 * 17, 128 * 40, 128 * 68):
+            nb = min(128, nwin - b0)
+            wins = torch.stack([x[i:i + w].reshape(w * Fv, H, H) for i in range(b0, b0 + nb)])
+            y = net(wins, t.to(dev)).view(nb, w, Fv, H, H)
+            assert torch.equal(eps_u[b0 + k: b0 + k + nb], y[:, k]), f"centre frames of windows {b0}..{b0 + nb - 1}"
+            if b0 == 0:
+                assert torch.equal(eps_u[:k], y[0, :k]), "leading frames come from the first window"
+            if b0 + nb == nwin:
+                assert torch.equal(eps_u[L - k:], y[-1, k + 1:]), "trailing frames come from the last window"
+        # conditioning
+        A = PoolStrideOperator(16, 6)
+        std = torch.tensor([0.1692666615037876, 0.0425178630338289, 0.3268027589410125, 0.3268027589410125]).view(1, Fv, 1, 1)
+        gamma = 0.0007196856730011522
+        yobs = A(torch.randn((L, Fv, H, H), device=dev, generator=g) * 0.5 + 0.5)
+        assert yobs.shape == ((L + 5) // 6, Fv, 8, 8)
+        sf.condition_on(A=A, y=yobs, std=std, gamma=gamma, exact_grad=False)
+        assert sf._fused_guidance is not None
+        eps_c = sf(x, t)
+        ref = eps_u.clone()
+        mu, sigma = pipe._mu_sigma_f(float(t))
+        ops.guidance(x, ref, yobs, std.reshape(Fv).to(dev), yobs.shape[0], Fv, H, H, 16, 6, mu, sigma, gamma)
+        assert torch.equal(eps_c, ref)
+        observed = torch.zeros(L, dtype=torch.bool, device=dev)
+        observed[::6] = True
+        assert torch.equal(eps_c[~observed], eps_u[~observed])
+        assert not torch.equal(eps_c[observed], eps_u[observed])
+        # the guidance term itself against the reference's formula on a few observed frames (fp32 torch ops, src/thor/score.py:48-57)
+        for i in (0, 6 * 700, 8736):
+            x0 = (x[i] - sigma * eps_u[i]) / mu
+            err = yobs[i // 6] - F.avg_pool2d(x0, 16)
+            var = std.to(dev)[0] ** 2 + gamma * (sigma / mu) ** 2
+            J = F.interpolate((err / var)[None], scale_factor=16, mode="nearest")[0] / 256.0 / mu
+            want = eps_u[i] - sigma * J
+            assert (eps_c[i] - want).abs().max().item() <= 1e-4 * want.abs().max().item()

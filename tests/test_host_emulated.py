@@ -192,6 +192,24 @@ def test_ddp_two_ranks_gloo_equals_single_process(golden_dir, tmp_path, bucket_m
     assert r0["draws"]["seed"] != r1["draws"]["seed"] and not torch.equal(r0["draws"]["t"], r1["draws"]["t"])
 
 
+def test_optimizer_chasing_the_backward_equals_the_update_behind_it_two_ranks_gloo(golden_dir, tmp_path):
+    """C2W_CHASE_OPT / Trainer.chase_optimizer with several buckets on two ranks: all-reduce + fused AdamW + EMA per finished bucket,
+    issued from inside the backward, against the whole-buffer update behind it -- same weights and EMA after two steps, on both
+    ranks; the chasing run really updated bucket by bucket."""
+    import torch.multiprocessing as mp
+    from _ddp_worker import run_chase
+    mp.spawn(run_chase, args=(2, _free_port(), golden_dir, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"chase{r}.pt", weights_only=False) for r in (0, 1))
+    for r in (r0, r1):
+        assert r[True]["update_calls"] > 2 * 4 and r[False]["update_calls"] == 2
+        for k, v in r[False]["sd"].items():
+            assert torch.equal(v, r[True]["sd"][k]), k
+        assert torch.equal(r[False]["ema"], r[True]["ema"])
+        assert r[False]["loss"] == r[True]["loss"]
+    for k, v in r0[True]["sd"].items():
+        assert torch.equal(v, r1[True]["sd"][k]), k  # ranks in lock step
+
+
 def test_score_function_and_sampler_match_golden(emu, golden_dir):
     s = _golden(golden_dir, "sampler.npz")
     net = _tiny().eval()
