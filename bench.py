@@ -417,8 +417,8 @@ def run_rank(a):
     # ---- by_kernel (outside the headline region): every implicit-GEMM launch of `kernel_steps` more steps, streams serialised
     if extras and a.kernel_steps > 0:
         timer.events.clear()
-        prev = os.environ.get("C2W_WGRAD_STREAM")
-        os.environ["C2W_WGRAD_STREAM"] = "0"  # read per launch by engine.grad_stream(): weight gradients on the caller's stream
+        prev = trainer.eng.use_grad_stream
+        trainer.eng.use_grad_stream = False  # weight gradients on the caller's stream: every kernel alone on the chip
         one_step()
         torch.cuda.synchronize()
         timer.mode = "all"
@@ -428,16 +428,13 @@ def run_rank(a):
         torch.cuda.synchronize()
         ser_ms = 1e3 * (time.perf_counter() - ts0) / a.kernel_steps
         timer.mode = "off"
-        if prev is None:
-            os.environ.pop("C2W_WGRAD_STREAM", None)
-        else:
-            os.environ["C2W_WGRAD_STREAM"] = prev
+        trainer.eng.use_grad_stream = prev
         if out is not None:
             fam = timer.summarise(steps=a.kernel_steps)
             gemm_ms = sum(v["ms_per_step"] for v in fam.values())
             out["by_kernel"] = dict(
                 note="every implicit-GEMM launch (ops.conv / ops.conv_wgrad) of %d extra steps, HIP events per launch, backward streams serialised "
-                     "(C2W_WGRAD_STREAM=0) so each kernel runs alone; FLOP are algorithmic (real channel counts); weight-gradient times include the "
+                     "(engine.use_grad_stream off) so each kernel runs alone; FLOP are algorithmic (real channel counts); weight-gradient times include the "
                      "split-K reduction launch; sorted by time per step" % a.kernel_steps,
                 serialised_step_ms=round(ser_ms, 2), implicit_gemm_ms_per_step=round(gemm_ms, 2), everything_else_ms_per_step=round(ser_ms - gemm_ms, 2),
                 kernels=[dict(kernel=k, **v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])])

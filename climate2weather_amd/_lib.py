@@ -92,7 +92,7 @@ _lib = None
 
 def exported_symbols():
     """Names include/c2w_hip.h declares (used by the CPU test that the library exports all of them)."""
-    return list(_PROTOS) + ["c2w_target", "c2w_sources_sha256"]
+    return list(_PROTOS) + ["c2w_target", "c2w_sources_sha256", "c2w_knobs_reload"]
 
 
 def load() -> ctypes.CDLL:
@@ -113,6 +113,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = c_longlong if name.endswith("_bytes") else c_int
+    lib.c2w_knobs_reload.restype = None
+    lib.c2w_knobs_reload.argtypes = []
     for name in ("c2w_target", "c2w_sources_sha256"):
         getattr(lib, name).restype = c_char_p
         getattr(lib, name).argtypes = []

@@ -13,6 +13,7 @@
 // The fp32 / general-T kernels in attention.hip stay the reference implementation and the fallback.
 #include <cstdlib>
 #include "common.h"
+#include "knobs.h"
 #include "c2w_hip.h"
 
 namespace {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16
 static bool is16(int dtype) { return dtype == C2W_DTYPE_BF16 || dtype == C2W_DTYPE_F16; }
 
 bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype) {
-    return is16(dtype) && Tn == T64 && C % 32 == 0 && C <= 512 && B > 0 && getenv("C2W_ATTN_VALU") == nullptr;
+    return is16(dtype) && Tn == T64 && C % 32 == 0 && C <= 512 && B > 0 && !c2w_knobs().attn_valu;
 }
 
 namespace {
@@ -343,7 +344,7 @@ int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* l
 
 // forward only: T a multiple of 64 beyond 64 (the backward of those shapes stays on the fp32 VALU kernels)
 bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype) {
-    return is16(dtype) && Tn > T64 && Tn % T64 == 0 && Tn <= 4096 && C % 32 == 0 && C <= 512 && B > 0 && getenv("C2W_ATTN_VALU") == nullptr;
+    return is16(dtype) && Tn > T64 && Tn % T64 == 0 && Tn <= 4096 && C % 32 == 0 && C <= 512 && B > 0 && !c2w_knobs().attn_valu;
 }
 
 int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, hipStream_t st) {

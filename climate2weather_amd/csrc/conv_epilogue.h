@@ -8,17 +8,9 @@
 #pragma once
 #include "conv_geom.h"
 
-#ifndef C2W_EPI_NT
-#define C2W_EPI_NT 1  // the epilogues' 16-B output stores carry the non-temporal hint (written once, read by a later kernel, never by
-                      // this one): 1-2 % on isolated launches of every flavour, 0.2 % on the step (profiles/r02_ab_conv_epilogues.txt)
-#endif
-__device__ __forceinline__ void epi_st(char* ptr, const u32x4_t& v) {
-#if C2W_EPI_NT
-    __builtin_nontemporal_store(v, (u32x4_t*)ptr);
-#else
-    *(u32x4_t*)ptr = v;
-#endif
-}
+// the epilogues' 16-B output stores carry the non-temporal hint (written once, read by a later kernel, never by this one): 1-2 % on
+// isolated launches of every flavour, 0.2 % on the step (profiles/r02_ab_conv_epilogues.txt)
+__device__ __forceinline__ void epi_st(char* ptr, const u32x4_t& v) { __builtin_nontemporal_store(v, (u32x4_t*)ptr); }
 
 
 // bias of the 16 output channels this lane's accumulator rows cover (wave tile 64 co: 4 m-tiles x rows 4*lg..4*lg+3)
@@ -148,22 +140,6 @@ struct EpiStore {
             const int R = r0 + RS * i, trow = R >> 4, col = R & 15, img = col >> 3;
             const long long pix = pixA + (long long)img * HW + trow * 8 + (col & 7);
             off[i] = (c < p.Cout && img < nimg) ? (pix * p.ldy + c) * ESZ : -1;
-        }
-        issue_prefetch(p);
-    }
-
-    // The same for a pass of conv_patch_t4_kernel: LDS row R = 32 g + col holds the pixel 4 g image rows below pix0's row, column
-    // col of a 32-pixel-wide tile (row j of each of the four waves).  R = r0 + 16 i  ->  g = i >> 1, col = 16 (i & 1) + r0.
-    __device__ __forceinline__ void prefetch_rows32(const C2wConvArgs& p, int tid, int co0, long long pix0, int W) {
-        static_assert(NTHR / SEGS == 16 && NROWS == 128, "16-bit tiles, 256 threads, 128 rows per pass");
-        const int r0 = tid / SEGS, cs = tid - r0 * SEGS;
-        const int c = co0 + cs * PER16;
-        const long long pitch = (long long)p.ldy * ESZ;
-        const long long off0 = c < p.Cout ? ((pix0 + r0) * p.ldy + c) * ESZ : -1;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const long long d = ((long long)(i >> 1) * 4 * W + 16 * (i & 1)) * pitch;
-            off[i] = off0 >= 0 ? off0 + d : -1;
         }
         issue_prefetch(p);
     }

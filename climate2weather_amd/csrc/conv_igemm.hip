@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "conv_epilogue.h"
+#include "knobs.h"
 
 namespace {
 
@@ -326,8 +327,7 @@ int launch_mode(const C2wConvArgs& a, int naive, hipStream_t st) {
     }
     const int nN = (a.Cout + BN - 1) / BN;
     // 256-pixel tiles unless they would leave CUs idle (fewer workgroups than CUs): then 128-pixel tiles, twice the workgroups
-    static const int force_nw = getenv("C2W_GATHER_NW") ? atoi(getenv("C2W_GATHER_NW")) : 0;
-    const bool small = force_nw ? force_nw == 2 : ((npix + 255) / 256) * nN < 256;
+    const bool small = ((npix + 255) / 256) * nN < 256;
     return small ? launch_tile<T, MODE, 2>(a, npix, nN, st) : launch_tile<T, MODE, 4>(a, npix, nN, st);
 }
 
@@ -345,9 +345,31 @@ int launch_dtype(const C2wConvArgs& a, int naive, hipStream_t st) {
 
 }  // namespace
 
+// ---- run-time knobs (knobs.h): read once, re-read on request
+namespace {
+C2wKnobs read_knobs() {
+    auto off0 = [](const char* n) { const char* v = getenv(n); return v != nullptr && atoi(v) == 0; };  // "NAME=0" switches a default-on path off
+    C2wKnobs k;
+    k.force_gather = getenv("C2W_FORCE_GATHER") != nullptr;
+    k.conv_t3 = getenv("C2W_CONV_T3") ? atoi(getenv("C2W_CONV_T3")) : -1;
+    k.conv_pair = !off0("C2W_CONV_PAIR");
+    k.conv_ts2_patch = !off0("C2W_CONV_TS2_PATCH");
+    k.up_patch = getenv("C2W_NO_UP_PATCH") == nullptr;
+    k.pool2 = getenv("C2W_NO_POOL2") == nullptr;
+    k.ln_fusion = getenv("C2W_NO_LN_FUSION") == nullptr;
+    k.lnf = getenv("C2W_NO_LNF") == nullptr;
+    k.wgrad_atomics = getenv("C2W_WGRAD_ATOMICS") != nullptr;
+    k.attn_valu = getenv("C2W_ATTN_VALU") != nullptr;
+    return k;
+}
+C2wKnobs g_knobs = read_knobs();
+}  // namespace
+const C2wKnobs& c2w_knobs() { return g_knobs; }
+extern "C" void c2w_knobs_reload(void) { g_knobs = read_knobs(); }
+
 extern "C" int c2w_conv_patch_supported(const C2wConvArgs* a, int dtype) {
     (void)dtype;
-    return a != nullptr && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr ? 1 : 0;
+    return a != nullptr && c2w_conv_patch_eligible(*a) && !c2w_knobs().force_gather ? 1 : 0;
 }
 
 extern "C" int c2w_conv_pool2_supported(const C2wConvArgs* a, int dtype) {
@@ -355,27 +377,24 @@ extern "C" int c2w_conv_pool2_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || a->mode != C2W_CONV_S1 || a->res != nullptr || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE ||
         a->ln_x != nullptr || a->lnf_y != nullptr)
         return 0;
-    return c2w_conv_patch_eligible(*a) && !c2w_conv_pair_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_POOL2") == nullptr ? 1 : 0;
+    return c2w_conv_patch_eligible(*a) && !c2w_conv_pair_eligible(*a) && !c2w_knobs().force_gather && c2w_knobs().pool2 ? 1 : 0;
 }
 
 extern "C" int c2w_conv_lnfwd_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE || a->ln_x != nullptr) return 0;
-    return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr &&
-                   getenv("C2W_NO_LNF") == nullptr
-               ? 1
-               : 0;
+    return c2w_conv_patch_eligible(*a) && !c2w_knobs().force_gather && c2w_knobs().ln_fusion && c2w_knobs().lnf ? 1 : 0;
 }
 
 extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE) return 0;
-    return c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr && getenv("C2W_NO_LN_FUSION") == nullptr ? 1 : 0;
+    return c2w_conv_patch_eligible(*a) && !c2w_knobs().force_gather && c2w_knobs().ln_fusion ? 1 : 0;
 }
 
 extern "C" int c2w_conv_dispatch(const C2wConvArgs* a, int dtype) {
     if (a == nullptr) return C2W_ERR_BAD_ARG;
-    const bool gather = getenv("C2W_FORCE_GATHER") != nullptr;
+    const bool gather = c2w_knobs().force_gather;
     if (!gather && c2w_conv_patch_eligible(*a)) return c2w_conv_patch3_wanted(*a, dtype) ? C2W_KERNEL_PATCH_16X16 : C2W_KERNEL_PATCH_8X16;
     if (!gather && c2w_conv_pair_eligible(*a)) return C2W_KERNEL_PATCH_PAIR;
     if (!gather && c2w_conv_ts2_patch_eligible(*a)) return C2W_KERNEL_PATCH_TS2;
@@ -396,9 +415,10 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if ((a->flags & C2W_CONV_POOL2) != 0 && (naive != 0 || !c2w_conv_pool2_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
-    if (naive == 0 && c2w_conv_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_s1(*a, dtype, st);
-    if (naive == 0 && c2w_conv_pair_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_pair(*a, dtype, st);
-    if (naive == 0 && c2w_conv_ts2_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_conv_patch_ts2(*a, dtype, st);
+    const bool patch = naive == 0 && !c2w_knobs().force_gather;
+    if (patch && c2w_conv_patch_eligible(*a)) return c2w_conv_patch_s1(*a, dtype, st);
+    if (patch && c2w_conv_pair_eligible(*a)) return c2w_conv_patch_pair(*a, dtype, st);
+    if (patch && c2w_conv_ts2_patch_eligible(*a)) return c2w_conv_patch_ts2(*a, dtype, st);
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, naive, st);

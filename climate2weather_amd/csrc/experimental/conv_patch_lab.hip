@@ -1,30 +1,31 @@
 // Halo-patch implicit GEMM for the 3x3 stride-1 convolutions (the 60 res-block convs and their input gradients:
-// 98.8 of the 116 GFLOP forward, model/nn.py:155,157) on gfx950 -- the 8x16-pixel-tile kernels: fp32 mode, 16-bit launches below
-// 1024 workgroups of the 16x16-tile kernel (conv_patch3.hip), 8-pixel-wide images (two per tile) and the stride-2 input gradient
-// per output-parity class.
+// 98.8 of the 116 GFLOP forward, model/nn.py:155,157) on gfx950.
 //
-// Why a halo patch: PMC on the gather kernel (profiles/r01_pmc_conv_gather_b32.md) shows ~290 non-MFMA instructions per 32 MFMAs
-// per wave -- per-tap gather address arithmetic and scalar loop overhead -- so the wave's in-order issue stream, not the matrix
-// pipe / LDS / HBM, set the time.  Here
-//   * a workgroup owns an 8x16 output tile of one image and stages the (8+2)x(16+2) input halo patch ONCE per K-chunk
+// Why a second kernel: PMC on the gather kernel (profiles/r01_pmc_conv_gather_b32.md) shows ~290 non-MFMA
+// instructions per 32 MFMAs per wave -- per-tap gather address arithmetic and scalar loop overhead -- so the wave's
+// in-order issue stream, not the matrix pipe / LDS / HBM, set the time.  Here
+//   * a block owns a 16x16 output tile of one image and stages the (16+2)x(16+2) input halo patch ONCE per K-chunk
 //     (128 B of channels per pixel); all 9 taps read it from LDS -> each input pixel is fetched once, not 9 times;
 //   * the 9 taps are unrolled: the patch row pitch is 24 pixels (a multiple of 8), so the XOR swizzle of a fragment
 //     read depends only on (lane, kw) and every LDS address is  register + immediate  -- no per-stage VALU;
-//   * per stage (one tap of one chunk) a wave issues its weight pieces by LDS-DMA one tap ahead, counted vmcnt, one raw s_barrier;
+//   * per stage (one tap of one chunk) a wave issues 2 weight pieces + at most 1 patch piece of LDS-DMA
+//     (patch of the NEXT chunk trickles in during taps 0..6), counted vmcnt, one raw s_barrier;
 //   * weights ring: 3 slots of [128 co][128 B]; slot = tap % 3 is a compile-time constant.
-// MFMA tiling: 128 px x 128 co per workgroup, 4 waves x (4x4) 16x16 tiles, A = weights, B = pixels.
-// (The 16x16-tile, one-workgroup-per-CU form of this kernel -- 156 KB of LDS -- measured 5 % behind two half-tile workgroups per CU
-// and was removed in round 3; the cycle-stamp / ablation builds live in csrc/experimental/conv_patch_lab.hip.)
+// Same MFMA tiling as conv_igemm.hip: 256 px x 128 co per block, 8 waves x (4x4) 16x16 tiles, A = weights, B = pixels.
 #include <cstdlib>
 
 #include "conv_epilogue.h"
-#include "knobs.h"
 
 namespace {
 
+constexpr int NTHREADS = 512;
 constexpr int PW = 24;                    // patch row pitch in pixels (18 used)
 constexpr int PROW = PW * 128;            // bytes per patch row
+constexpr int NPIECE = 18 * 3;            // 1 KiB LDS-DMA pieces (8 pixels each) per patch
+constexpr int PBYTES = NPIECE * 1024;     // 55,296
 constexpr int WBYTES = 128 * 128;         // one tap's weight tile: 128 co x 128 B
+constexpr int WBASE = 2 * PBYTES;         // weight ring behind the two patch slots
+constexpr int LDS_MAIN = WBASE + 3 * WBYTES;  // 159,744 B of the CU's 163,840
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -42,6 +43,204 @@ template <> struct Mma<float> {
 };
 
 template <int N> struct IC { static constexpr int value = N; };
+
+#ifndef C2W_EXP
+#define C2W_EXP 0  // diagnostic timing builds only: 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA in the loop, 8 no barrier,
+#endif             // 16 cycle stamps (s_memtime) to the buffer registered with c2w_debug_set (tools/stamp_conv_patch.py)
+#if C2W_EXP & 16
+__device__ unsigned long long* c2w_dbg = nullptr;
+#define C2W_STAMP(var) var = __builtin_amdgcn_s_memtime()
+#else
+#define C2W_STAMP(var) (void)0
+#endif
+template <typename T>
+__device__ __forceinline__ void mma_x(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    if constexpr (C2W_EXP & 1) {
+        asm volatile("" ::"v"(a), "v"(b));
+    } else {
+        Mma<T>::run(a, b, c);
+    }
+}
+__device__ __forceinline__ u32x4_t lds_x(const char* p, const u32x4_t& keep) {
+    if constexpr (C2W_EXP & 2) {
+        return keep;
+    } else {
+        return *(const u32x4_t*)p;
+    }
+}
+
+__device__ __forceinline__ void wait_vm(int n) {  // wave-uniform n in {0,2,3}
+    if (n == 3) {
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else if (n == 2) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_patch_s1_kernel(const C2wConvArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int CK = 128 / ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int nN = (p.Cout + 127) / 128;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hin, W = p.Win;
+    const int tw = W >> 4, tpi = (H >> 4) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 4, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    // ---- patch pieces of this wave: round r -> piece r*8 + wid (pieces past the end repeat the last one)
+    uint32_t pvo[7];
+    int pdst[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        int pc = r * 8 + wid;
+        pc = pc < NPIECE ? pc : NPIECE - 1;
+        const int pr = pc / 3, pg = pc - pr * 3;
+        const int px = pg * 8 + (lane >> 3);
+        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+        const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+        pvo[r] = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+        pdst[r] = pc * 1024;
+    }
+    uint32_t wvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+    auto issue_w = [&](int chunk, int tap, int wslot) {
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rw, smem + WBASE + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
+    };
+
+    // ---- fragment read offsets: register part (the rest is an immediate)
+    uint32_t offA[2][4], preB[2][3][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = wm * 64 + m * 16 + li;
+            offA[ks][m] = (uint32_t)(WBASE + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int px = li + kw;
+                preB[ks][kw][n] = (uint32_t)(((wn * 4 + n) * PW + px) * 128 + (((ks * 4 + lg) ^ (px & 7)) << 4));
+            }
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * 9;
+
+    float bv[4][4];  // bias: fetched now, used in the epilogue (its latency hides under the main loop)
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+
+    // prologue: patch of chunk 0, weights of stages 0 and 1
+#pragma unroll
+    for (int r = 0; r < 7; ++r) glds16(rx, smem + pdst[r], pvo[r], 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    int np = 2;  // LDS-DMA pieces this wave issued in the previous stage (still allowed in flight)
+    u32x4_t da[4] = {}, db[4] = {};  // second-half fragments of the previous stage (deferred MFMAs)
+
+    auto stage = [&](auto PARc, auto TAPc, int c) {
+        constexpr int PAR = decltype(PARc)::value, TAP = decltype(TAPc)::value;
+        constexpr int KH = TAP / 3, KW = TAP % 3, WS = TAP % 3;
+        const int s = c * 9 + TAP;
+        wait_vm(np);
+        if constexpr (!(C2W_EXP & 8)) __builtin_amdgcn_s_barrier();
+        np = 0;
+        if (!(C2W_EXP & 4) && s + 2 < NS) {
+            constexpr int T2 = (TAP + 2) % 9;
+            issue_w(TAP + 2 >= 9 ? c + 1 : c, T2, (TAP + 2) % 3);
+            np = 2;
+        }
+        if (!(C2W_EXP & 4) && TAP < 7 && c + 1 < nchunk) {
+            glds16(rx, smem + (PAR ^ 1) * PBYTES + pdst[TAP < 7 ? TAP : 0], pvo[TAP < 7 ? TAP : 0], (uint32_t)(c + 1) * 128u);
+            np += 1;
+        }
+        // software pipeline across the barrier: the second K-half of every stage is multiplied AFTER the next stage's
+        // barrier, from registers, while that stage's first fragments are still on their way from LDS.
+        u32x4_t a0[4], b0[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = lds_x(smem + offA[0][m] + WS * WBYTES, da[m]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b0[n] = lds_x(smem + preB[0][KW][n] + KH * PROW + PAR * PBYTES, db[n]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_x<T>(da[m], db[n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = lds_x(smem + offA[1][m] + WS * WBYTES, a0[m]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) db[n] = lds_x(smem + preB[1][KW][n] + KH * PROW + PAR * PBYTES, b0[n]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma_x<T>(a0[m], b0[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before any wave may refill their slot
+    };
+    auto chunk9 = [&](auto PARc, int c) {
+        stage(PARc, IC<0>{}, c); stage(PARc, IC<1>{}, c); stage(PARc, IC<2>{}, c);
+        stage(PARc, IC<3>{}, c); stage(PARc, IC<4>{}, c); stage(PARc, IC<5>{}, c);
+        stage(PARc, IC<6>{}, c); stage(PARc, IC<7>{}, c); stage(PARc, IC<8>{}, c);
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk9(IC<0>{}, c);
+        if (c + 1 < nchunk) chunk9(IC<1>{}, c + 1);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) mma_x<T>(da[m], db[n], acc[m][n]);
+
+    // ---- epilogue (conv_epilogue.h): bias/activation in registers -> LDS [pixel][channel] -> 16-B NHWC stores
+    constexpr int OS = 128 * ESZ + 16;
+    EpiStore<T, 256, NTHREADS> est;
+    est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    __syncthreads();
+    char* const O = smem;
+    epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
+    __syncthreads();
+    est.finish(p, O, OS, tid);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Two-workgroups-per-CU variant.  Cycle stamps (profiles/r01_stamps_conv_patch.md) show a 256-pixel tile spending 40-48 %
@@ -160,6 +359,8 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     const int nchunk = p.Cin / CK;
     const int NS = nchunk * 9;
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    C2W_STAMP(st0);
     issue_patch(0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
@@ -174,6 +375,7 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         const int s = c * 9 + TAP;
         wait_vm4(np);
         __builtin_amdgcn_s_barrier();
+        if (s == 0) C2W_STAMP(st1);
         if (TAP == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
             issue_patch(c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,18 +422,24 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
 
     constexpr int OS = 128 * ESZ + 16;
+    C2W_STAMP(st2);
+    unsigned long long sa = 0, sb = 0, sc = 0;
     EpiStore<T, 128, H_NTHR> est;
     const bool pool2 = !PAIR && (p.flags & C2W_CONV_POOL2) != 0;
     if constexpr (PAIR) est.prefetch_pair8(p, tid, co0, ((long long)b * H + oh0) * W, H * W, nimg);
     else if (!pool2) est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    C2W_STAMP(sa);
     __syncthreads();
+    C2W_STAMP(sb);
     char* const O = smem;
     float* const red = (float*)(smem + 128 * OS);  // 128 floats behind O: column sums of the fused LN backward
     if constexpr (ESZ == 2) {
         if (p.ln_x != nullptr && tid < 128) red[tid] = 0.f;
     }
     epi_acc_to_lds<T>(O, OS, acc, bv, p.act, wm * 64, wn * 64, li, lg);
+    C2W_STAMP(sc);
     __syncthreads();
+    C2W_STAMP(st3);
     if (pool2) {
         est.finish_pool2(p, O, OS, tid, co0, ((long long)b * (H >> 1) + (oh0 >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
     } else if constexpr (ESZ == 2 && !PAIR) {
@@ -241,6 +449,13 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     } else {
         est.finish(p, O, OS, tid);
     }
+    C2W_STAMP(st4);
+#if C2W_EXP & 16
+    if (tid == 0 && c2w_dbg != nullptr) {
+        unsigned long long* d = c2w_dbg + (size_t)L * 8;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = sa; d[4] = sb; d[5] = sc; d[6] = st3; d[7] = st4;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -456,17 +671,30 @@ int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
 }
 
 template <typename T>
-int launch(const C2wConvArgs& a, hipStream_t st) {  // two 8x16-tile workgroups per CU
+int launch(const C2wConvArgs& a, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
-    static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
-    static bool attr_h = false;
-    if (!attr_h) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        attr_h = true;
+    constexpr int lds_epi = 256 * (128 * ESZ + 16);
+    constexpr int lds = LDS_MAIN > lds_epi ? LDS_MAIN : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_s1_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
     }
     const int nN = (a.Cout + 127) / 128;
-    const int nMh = a.B * (a.Hout >> 3) * (a.Wout >> 4);
-    conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, H_LDS, st>>>(a);
+    if (getenv("C2W_CONV_FULL") == nullptr || a.ln_x != nullptr || a.lnf_y != nullptr || (a.Hin & 15) != 0 || a.mode != C2W_CONV_S1) {  // two half-tile workgroups per CU
+        static_assert(128 * (128 * ESZ + 16) <= H_LDS, "half-tile output rows fit");
+        static bool attr_h = false;
+        if (!attr_h) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            attr_h = true;
+        }
+        const int nMh = a.B * (a.Hout >> 3) * (a.Wout >> 4);
+        const int lds_h = getenv("C2W_HALF_ONE_PER_CU") ? 100 * 1024 : H_LDS;  // diagnostic: forbid co-residency
+        conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, lds_h, st>>>(a);
+        return (int)hipGetLastError();
+    }
+    const int nM = a.B * (a.Hin >> 4) * (a.Win >> 4);
+    conv_patch_s1_kernel<T><<<nM * nN, NTHREADS, lds, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -489,7 +717,8 @@ int launch_pair(const C2wConvArgs& a, hipStream_t st) {
 
 // input gradient of the stride-2 convs per output-parity class on the halo patch (conv_patch_ts2_kernel)
 bool c2w_conv_ts2_patch_eligible(const C2wConvArgs& a) {
-    return c2w_knobs().conv_ts2_patch && a.mode == C2W_CONV_TS2 && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hin & 7) == 0 && (a.Win & 15) == 0 &&
+    static const bool off = getenv("C2W_CONV_TS2_PATCH") != nullptr && atoi(getenv("C2W_CONV_TS2_PATCH")) == 0;
+    return !off && a.mode == C2W_CONV_TS2 && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hin & 7) == 0 && (a.Win & 15) == 0 &&
            a.ln_x == nullptr && a.lnf_y == nullptr && a.y2 == nullptr && a.act == C2W_ACT_NONE &&
            (long long)a.B * (a.Hin >> 3) * (a.Win >> 4) * ((a.Cout + 127) / 128) * 4 < (1ll << 31);
 }
@@ -503,7 +732,8 @@ int c2w_conv_patch_ts2(const C2wConvArgs& a, int dtype, hipStream_t st) {
 
 // 8-pixel-wide images: two of them per 8x16 tile (conv_patch_half_kernel<T, PAIR>); no fused LayerNorm epilogues in that mode
 bool c2w_conv_pair_eligible(const C2wConvArgs& a) {
-    return c2w_knobs().conv_pair && a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && a.Win == 8 && (a.Hin & 7) == 0 && a.ln_x == nullptr &&
+    static const bool off = getenv("C2W_CONV_PAIR") != nullptr && atoi(getenv("C2W_CONV_PAIR")) == 0;
+    return !off && a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && a.Win == 8 && (a.Hin & 7) == 0 && a.ln_x == nullptr &&
            a.lnf_y == nullptr && (long long)((a.B + 1) >> 1) * (a.Hin >> 3) * ((a.Cout + 127) / 128) < (1ll << 31);
 }
 
@@ -516,7 +746,7 @@ int c2w_conv_patch_pair(const C2wConvArgs& a, int dtype, hipStream_t st) {
 
 bool c2w_conv_patch_eligible(const C2wConvArgs& a) {  // OUTPUT grids that 8 x 16-pixel tiles cover exactly; stride 1, or x2 upsampling folded in
     const bool geom = (a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout) ||
-                      (a.mode == C2W_CONV_UP && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && c2w_knobs().up_patch);
+                      (a.mode == C2W_CONV_UP && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && getenv("C2W_NO_UP_PATCH") == nullptr);
     return geom && (a.Hout & 7) == 0 && (a.Wout & 15) == 0 &&
            (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
 }
@@ -529,3 +759,6 @@ int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st) {
     return C2W_ERR_BAD_ARG;
 }
 
+#if C2W_EXP & 16
+extern "C" int c2w_debug_set(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(c2w_dbg), &ptr, sizeof(void*)); }
+#endif

@@ -20,9 +20,12 @@
 #include <utility>
 #include "conv_geom.h"
 
-#include "knobs.h"
-// (schedule variants measured and rejected -- burst LDS-DMA issue, fragments one tap ahead, carried kh = 2 fragments -- and the ablation
-// builds live in csrc/experimental/wgrad_patch_lab.hip; results in profiles/r02_experiments.md section 1)
+#ifndef C2W_WPV
+#define C2W_WPV 0  // bit 0: patch fragments of the kh = 2 taps carried to the next K step (see the main loop): spills (252 + 12 VGPRs), off
+#endif
+#ifndef C2W_EXP
+#define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 LDS-DMA after the first tile
+#endif             // reads out of range (issued, nothing fetched), 8 not issued at all, 32 no epilogue, 64 every tile's loads read the split's first two tiles (L2 hits)
 
 
 namespace {
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     };
     auto srcA = [&](int t, int sa) {  // dY tile of K tile t -> dY slot sa
         int b, oh0, ow0;
+        if constexpr ((C2W_EXP & 64) != 0) t = t0 + ((t - t0) & 1);  // every load hits one of two tiles: L2-resident sources
         tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;  // a missing partner image reads as zeros (out of the descriptor's range)
         TileSrc s;
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     };
     auto srcP = [&](int t, int sp) {  // input halo patch of K tile t -> patch slot sp
         int b, oh0, ow0;
+        if constexpr ((C2W_EXP & 64) != 0) t = t0 + ((t - t0) & 1);
         tile_origin(t, b, oh0, ow0);
         const uint32_t nimg = PAIR && b + 1 < p.B ? 2u : 1u;
         TileSrc s;
@@ -260,9 +265,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the 4 youngest = the dY pieces of tile t + 1 (real or out of range)
         __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading tile t - 1's slots
         // next patch -> the patch slot of tile t - 1; the dY tile after next -> the dY slot of tile t - 1 = (sa + 2) mod 3
-        const bool hasP = t + 1 < t1, hasA = t + 2 < t1;
+        const bool hasP = (C2W_EXP & 4) == 0 && t + 1 < t1, hasA = (C2W_EXP & 4) == 0 && t + 2 < t1;
         const TileSrc nP = srcP(hasP ? t + 1 : t, sp ^ 1), nA = srcA(hasA ? t + 2 : t, sa == 0 ? 2 : sa - 1);
-        if constexpr (!BF) {  // fp32 path: burst behind the barrier
+        if constexpr (!BF || (C2W_WPV & 2) != 0) {  // burst behind the barrier (fp32 path; diagnostic A/B for the 16-bit path)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pieceP(nP, r, hasP);
 #pragma unroll
@@ -280,12 +285,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
             const uint32_t sA = (uint32_t)(uintptr_t)SA, sP = (uint32_t)(uintptr_t)SP;
             auto rd = [&](tr_frag& f, uint32_t base, uint32_t o0, uint32_t o1, auto IMMc) {
                 constexpr int IMM = decltype(IMMc)::value;
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(base + o0), "n"(IMM));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(base + o1), "n"(IMM));
+                if constexpr ((C2W_EXP & 2) != 0) {
+                    f.lo = (tr_half){(int)o0, (int)base};
+                    f.hi = (tr_half){(int)o1, IMM};
+                } else {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(base + o0), "n"(IMM));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(base + o1), "n"(IMM));
+                }
             };
             static_for<4>([&](auto KSc) {
                 constexpr int ks = decltype(KSc)::value;
-                {
+                if constexpr ((C2W_WPV & 2) == 0 && (C2W_EXP & 8) == 0) {
                     // The next tiles' LDS-DMA, four pieces at a time at K-step boundaries (fragment registers are dead there), and
                     // never on both waves of a SIMD at once (waves w and w + 4 share one): a piece holds the issuing wave's
                     // instruction stream for 60-185 cycles; while one wave of the pair is held its partner has the matrix pipe to
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                         for (int i = 0; i < 4; ++i) pieceA(nA, i, hasA);
                     }
                 }
-                constexpr int PF = 2;  // patch fragments are read PF taps ahead of their MFMAs
+                constexpr int PF = (C2W_WPV & 4) != 0 ? 1 : 2;  // patch fragments are read PF taps ahead of their MFMAs
                 tr_frag a[MTW], bq[PF + 1];
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) rd(a[m], sA, offA[m][0], offA[m][1], IC<ks * 32 * 256>{});
@@ -312,13 +322,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                     constexpr int tp = decltype(TPc)::value;
                     if constexpr (tp + PF < 9) rd(bq[(tp + PF) % (PF + 1)], sP, offB[tp + PF][0], offB[tp + PF][1], IC<ks * 2 * PPITCH * 128>{});
                     constexpr int AHEAD = (tp + PF < 9 ? PF : 8 - tp) * 2;  // reads younger than tap tp's: they may stay in flight
-                    if constexpr (AHEAD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else if constexpr (AHEAD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr ((C2W_EXP & 2) == 0) {
+                        if constexpr (AHEAD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        else if constexpr (AHEAD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     const bf16x8_t bfr = bq[tp % (PF + 1)].vec();
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) acc[tp][m] = mfma16s<T>(a[m].vec(), bfr, acc[tp][m]);
+                    for (int m = 0; m < MTW; ++m) {
+                        if constexpr ((C2W_EXP & 1) == 0) {
+                            acc[tp][m] = mfma16s<T>(a[m].vec(), bfr, acc[tp][m]);
+                        } else {
+                            asm volatile("" ::"v"(a[m].vec()), "v"(bfr));
+                        }
+                    }
                     if (tp == 8 && do_bias) {
                         const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
 #pragma unroll
@@ -348,6 +366,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 
     // ---- epilogue: per tap, tile -> LDS [co][ci] fp32 -> atomics as whole (co, tap) rows of CIB floats
     if (t0 >= t1) return;
+    if constexpr ((C2W_EXP & 32) != 0) {
+        f32x4_t tsum = acc[0][0];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) tsum += acc[tp][m];
+        if (tsum[0] + tsum[1] + tsum[2] + tsum[3] == 12345.678f) p.dw[tid] = tsum[0];
+        return;
+    }
     if (do_bias && li == 0) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
@@ -464,7 +491,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
         attr_set = true;
     }
     const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
-    p.ws = (ws != nullptr && need <= ws_bytes && nsplit > 1 && !c2w_knobs().wgrad_atomics) ? ws : nullptr;
+    p.ws = (ws != nullptr && need <= ws_bytes && nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? ws : nullptr;
     wgrad_patch_kernel<T, PAIR><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
@@ -477,12 +504,13 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
 }  // namespace
 
 bool c2w_wgrad_patch_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per K tile
-    return c2w_knobs().conv_pair && a.mode == C2W_CONV_S1 && a.Win == 8 && a.Hin == 8;
+    static const bool off = getenv("C2W_CONV_PAIR") != nullptr && atoi(getenv("C2W_CONV_PAIR")) == 0;
+    return !off && a.mode == C2W_CONV_S1 && a.Win == 8 && a.Hin == 8;
 }
 
 bool c2w_wgrad_patch_eligible(const C2wConvArgs& a) {
     if (a.mode == C2W_CONV_UP)  // nearest-neighbour x2 upsampling folded into the patch load
-        return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hout & 7) == 0 && (a.Wout & 15) == 0 && c2w_knobs().up_patch;
+        return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.Hout & 7) == 0 && (a.Wout & 15) == 0 && getenv("C2W_NO_UP_PATCH") == nullptr;
     return a.mode == C2W_CONV_S1 && a.Hin == a.Hout && a.Win == a.Wout && (a.Hin & 7) == 0 && ((a.Win & 15) == 0 || c2w_wgrad_patch_pair(a));
 }
 

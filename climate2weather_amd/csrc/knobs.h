@@ -1,0 +1,20 @@
+// Run-time knobs of libc2w_hip.so -- ALL of them (DESIGN.md section 10 lists them with their purpose).  They override the dispatcher
+// for tests and A/B measurements; none changes a result beyond the kernels' own rounding.  The environment is read ONCE, at the
+// first launch; c2w_knobs_reload() (exported) re-reads it -- a test that flips a knob inside one process calls it afterwards.
+#pragma once
+
+struct C2wKnobs {
+    bool force_gather;    // C2W_FORCE_GATHER=1   every conv / weight gradient on the general gather kernels (no halo-patch kernels)
+    int conv_t3;          // C2W_CONV_T3          -1 (default): 16x16-tile conv kernel from 1024 workgroups; 0: never; 16: wherever the image is tiled
+    bool conv_pair;       // C2W_CONV_PAIR=0      8-pixel-wide images NOT paired on the halo-patch kernels (gather kernels instead)
+    bool conv_ts2_patch;  // C2W_CONV_TS2_PATCH=0 stride-2 input gradient NOT on the parity-class halo-patch kernel
+    bool up_patch;        // C2W_NO_UP_PATCH=1    up-convs NOT on the halo-patch kernels (upsampling folded into the gather kernel instead)
+    bool pool2;           // C2W_NO_POOL2=1       c2w_conv_pool2_supported answers 0 (callers run conv + c2w_sumpool2)
+    bool ln_fusion;       // C2W_NO_LN_FUSION=1   no LayerNorm forward / backward in conv epilogues (callers run the separate passes)
+    bool lnf;             // C2W_NO_LNF=1         no LayerNorm FORWARD emission only
+    bool wgrad_atomics;   // C2W_WGRAD_ATOMICS=1  split-K partial sums by fp32 atomics even when a workspace is handed over
+    bool attn_valu;       // C2W_ATTN_VALU=1      attention on the fp32 VALU kernels instead of the matrix-core ones
+};
+
+const C2wKnobs& c2w_knobs();
+extern "C" void c2w_knobs_reload(void);

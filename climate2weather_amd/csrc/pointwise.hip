@@ -769,8 +769,6 @@ extern "C" int c2w_ln_backward(const void* dy, const void* x, const float* m, co
     long long want = (npix / 2048 + 15) / 16 * 16;
     if (want < 16) want = 16;
     if (want > 512) want = 512;
-    static const int ppb_env = getenv("C2W_LN_PPB") ? atoi(getenv("C2W_LN_PPB")) : 0;  // diagnostic override
-    if (ppb_env > 0) want = ppb_env;
     const int ppb = HW < want ? HW : (int)want;
     dim3 grid((HW + ppb - 1) / ppb, (unsigned)(npix / HW));
     const int nv = (C + 16 * (dtype == C2W_DTYPE_F32 ? 4 : 8) - 1) / (16 * (dtype == C2W_DTYPE_F32 ? 4 : 8));

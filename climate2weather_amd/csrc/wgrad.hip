@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "conv_geom.h"
+#include "knobs.h"
 
 namespace {
 
@@ -347,7 +348,7 @@ static void split_plan(const C2wConvArgs& a, int& tilesM, int& tilesN, int& nspl
     tilesN = (NT * (a.Cin / CIB) + 3) / 4;
     tilesM = (a.Cout + COT - 1) / COT;
     const int tilesMN = tilesM * tilesN;
-    static const int target = getenv("C2W_WGRAD_TARGET") ? atoi(getenv("C2W_WGRAD_TARGET")) : 432;
+    constexpr int target = 432;  // workgroups a launch aims for (measured best of 256 / 432 / 512 / 768 at the bench sizes)
     nsplit = (target + tilesMN - 1) / tilesMN;
     if (nsplit > nkt) nsplit = nkt;
     if (nsplit < 1) nsplit = 1;
@@ -385,7 +386,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
         attr_set = true;
     }
     const size_t need = (size_t)p.nsplit * tilesMN * COT * 4 * CIB * sizeof(float);
-    p.ws = (ws != nullptr && need <= ws_bytes && p.nsplit > 1 && getenv("C2W_WGRAD_ATOMICS") == nullptr) ? ws : nullptr;
+    p.ws = (ws != nullptr && need <= ws_bytes && p.nsplit > 1 && !c2w_knobs().wgrad_atomics) ? ws : nullptr;
     wgrad_kernel<T, MODE><<<tilesMN * p.nsplit, NTHREADS, lds, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per4 = (size_t)tilesMN * COT * 4 * CIB / 4;
@@ -431,7 +432,7 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, voi
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const size_t wsb = workspace == nullptr ? 0 : (size_t)workspace_bytes;
-    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch(*a, dw, dbias, ws, wsb, dtype, st);
+    if (c2w_wgrad_patch_eligible(*a) && !c2w_knobs().force_gather) return c2w_wgrad_patch(*a, dw, dbias, ws, wsb, dtype, st);
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, dw, dbias, ws, wsb, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, dw, dbias, ws, wsb, st);
     return launch_dtype<f16_t>(*a, dw, dbias, ws, wsb, st);
@@ -440,7 +441,7 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, voi
 extern "C" int c2w_conv_wgrad_dispatch(const C2wConvArgs* a, int dtype) {
     const int rc = wgrad_check(a, dtype);
     if (rc != 0) return rc;
-    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return c2w_wgrad_patch_pair(*a) ? C2W_KERNEL_PATCH_PAIR : C2W_KERNEL_PATCH_8X16;
+    if (c2w_wgrad_patch_eligible(*a) && !c2w_knobs().force_gather) return c2w_wgrad_patch_pair(*a) ? C2W_KERNEL_PATCH_PAIR : C2W_KERNEL_PATCH_8X16;
     return C2W_KERNEL_GATHER;
 }
 
@@ -448,7 +449,7 @@ extern "C" int c2w_conv_wgrad_dispatch(const C2wConvArgs* a, int dtype) {
 extern "C" long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* a, int dtype) {
     const int rc = wgrad_check(a, dtype);
     if (rc != 0) return rc;
-    if (c2w_wgrad_patch_eligible(*a) && getenv("C2W_FORCE_GATHER") == nullptr) return (long long)c2w_wgrad_patch_ws_bytes(*a, dtype);
+    if (c2w_wgrad_patch_eligible(*a) && !c2w_knobs().force_gather) return (long long)c2w_wgrad_patch_ws_bytes(*a, dtype);
     const int esz = dtype == C2W_DTYPE_F32 ? 4 : 2;
     if (a->mode == C2W_CONV_1X1) return (long long)(esz == 4 ? ws_need<4, 1>(*a) : ws_need<2, 1>(*a));
     return (long long)(esz == 4 ? ws_need<4, 9>(*a) : ws_need<2, 9>(*a));

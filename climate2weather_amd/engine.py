@@ -194,6 +194,9 @@ class Engine:
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
         self._wg_stream = None  # second HIP stream for the weight-gradient launches (see _wg)
+        # C2W_WGRAD_STREAM=0 (read once, here; or set the attribute): weight gradients on the caller's stream, every kernel alone on the
+        # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
+        self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
         self.attach(net)
 
@@ -337,12 +340,12 @@ class Engine:
 
     # ------------------------------------------------------------------ weight gradients on a second stream
     def grad_stream(self):
-        """The stream every write into ``flat_grad`` is enqueued on, or None (CPU tensors / C2W_WGRAD_STREAM=0: the current
+        """The stream every write into ``flat_grad`` is enqueued on, or None (CPU tensors / ``use_grad_stream`` off: the current
         stream).  A layer's weight gradient and its input gradient both depend only on the layer's output gradient; on one
         stream they run back to back and the chip idles through every kernel's last round of workgroups, the 27-us split-K
         reduction launches and the launch gaps.  On two streams the hardware dispatcher fills those holes with the other
         stream's workgroups (the LDS footprints forbid real co-residency: 127 KB + 2 x 70.7 KB > 160 KB)."""
-        if self.flat is None or not self.flat.is_cuda or os.environ.get("C2W_WGRAD_STREAM") == "0":
+        if self.flat is None or not self.flat.is_cuda or not self.use_grad_stream:
             return None
         if self._wg_stream is None or self._wg_stream.device != self.flat.device:
             self._wg_stream = torch.cuda.Stream(device=self.flat.device)
@@ -557,11 +560,7 @@ class Engine:
             d1 = torch.empty((npix, Cc), dtype=T, device=dev) if train else None
             mulmode = MUL_PLAIN
             act_inf, act_train = (ACT_RELU, ACT_RELU_PAIR) if lay.activation == "relu" else (ACT_SILU, ACT_SILU_PAIR)
-            if train and os.environ.get("C2W_KEEP_PREACT") and lay.activation == "silu":  # diagnostic A/B: keep a and silu(a), evaluate silu'(a) in the backward pass
-                a1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=ACT_NONE, y2=d1)
-                h1, d1, mulmode = d1, a1, MUL_DSILU
-            else:
-                h1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=act_train if train else act_inf, y2=d1)
+            h1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=act_train if train else act_inf, y2=d1)
             if want_ln is not None:
                 out, g2, r2, hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin, want_ln=want_ln)
             else:

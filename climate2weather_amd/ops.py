@@ -57,6 +57,11 @@ def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
+def knobs_reload() -> None:
+    """Re-read the library's run-time knobs (C2W_* dispatch overrides) from the environment: it reads them once, at load."""
+    _lib.load().c2w_knobs_reload()
+
+
 def conv_patch_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)

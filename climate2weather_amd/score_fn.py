@@ -145,6 +145,9 @@ class _WindowScore(AbstractScoreFunction):
             except StopIteration:  # pragma: no cover
                 device = torch.device("cuda")
         self.device = torch.device(device)
+        # window batches of one score evaluation alternate between this many HIP streams (1: the caller's stream only);
+        # C2W_SCORE_STREAMS (read once, here) or the attribute
+        self.num_streams = int(os.environ.get("C2W_SCORE_STREAMS", type(self).num_streams))
 
     # reference-compatible helpers (src/thor/score.py:68-88)
     def unfold(self, x):
@@ -225,7 +228,7 @@ class _WindowScore(AbstractScoreFunction):
     num_streams = 4  # window batches of one score evaluation alternate between this many HIP streams (1: the caller's stream only)
 
     def _side_streams(self, nbatches: int):
-        n = min(int(os.environ.get("C2W_SCORE_STREAMS", self.num_streams)), nbatches)  # env: diagnostic A/B
+        n = min(int(self.num_streams), nbatches)
         if n < 2:
             return []
         pool = self.__dict__.setdefault("_streams", [])

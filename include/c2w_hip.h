@@ -244,6 +244,11 @@ int c2w_affine_channels(const float* x, float* y, const float* scale, const floa
                         void* stream);
 
 /* library identity: returns the gfx target string the kernels were compiled for ("gfx950") */
+/* Run-time knobs (dispatch overrides for tests and A/B measurements: C2W_FORCE_GATHER, C2W_CONV_T3, C2W_CONV_PAIR, C2W_CONV_TS2_PATCH,
+ * C2W_NO_UP_PATCH, C2W_NO_POOL2, C2W_NO_LN_FUSION, C2W_NO_LNF, C2W_WGRAD_ATOMICS, C2W_ATTN_VALU; csrc/knobs.h) are
+ * read from the environment once, when the library is loaded; this re-reads them. */
+void c2w_knobs_reload(void);
+
 const char* c2w_target(void);
 /* provenance: hex sha256 over the sources (csrc/, include/c2w_hip.h, compile flags) this library was built from; the Python loader
  * refuses a library whose digest differs from the source tree next to it (climate2weather_amd/build.py) */

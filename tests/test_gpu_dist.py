@@ -77,8 +77,10 @@ def test_optimizer_chasing_the_backward_over_rccl(golden_dir, tmp_path, world):
     for r in outs:
         assert r[True]["update_calls"] > 2 * 4 and r[False]["update_calls"] == 2
         for k, v in r[False]["sd"].items():
-            # same arithmetic per element; the gradients themselves carry fp32-atomics order noise (LayerNorm dm, loss sums)
-            assert (v - r[True]["sd"][k]).abs().max().item() <= 2e-6 + 1e-5 * v.abs().max().item(), k
+            # same arithmetic per element; the gradients themselves carry fp32-atomics order noise (LayerNorm dm, loss sums), which
+            # Adam's g / (|g| + eps) amplifies where |g| ~ eps: at most the two steps' full stride there, nothing on average
+            d = (v - r[True]["sd"][k]).abs()
+            assert d.max().item() <= 2 * 2e-3 and d.mean().item() <= 2e-6, (k, d.max().item(), d.mean().item())
     for r in outs[1:]:
         for k, v in outs[0][True]["sd"].items():
             assert torch.equal(v, r[True]["sd"][k]), k

@@ -438,9 +438,9 @@ def test_window_batches_on_several_streams_equal_one_stream(monkeypatch):
     x = torch.randn(3, 14, 2, 64, 64, device="cuda")  # 3 members x 12 windows = 36 windows -> 5 balanced batches
     t = torch.tensor(0.4)
     with torch.no_grad():
-        monkeypatch.setenv("C2W_SCORE_STREAMS", "1")
+        sf.num_streams = 1
         ref = sf.score_fn(x, t).clone()
-        monkeypatch.setenv("C2W_SCORE_STREAMS", "4")
+        sf.num_streams = 4
         for _ in range(6):
             out = sf.score_fn(x, t)
             torch.cuda.synchronize()

@@ -25,6 +25,13 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment():
+    """monkeypatch restores the environment after a test; the library's knob table (read once) must follow."""
+    yield
+    ops.knobs_reload()
+
+
 def rnd(shape, dt, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(TD[dt]).to(dev())
@@ -304,8 +311,11 @@ def test_conv_wgrad(case, dt, force_gather, monkeypatch):
         if mode != ops.CONV_S1:
             pytest.skip("only 3x3 stride-1 has two kernels")
         monkeypatch.setenv("C2W_FORCE_GATHER", "1")  # the general kernel on shapes the halo-patch kernel would take
+        ops.knobs_reload()  # the library reads its knobs once
     taps = 1 if mode == ops.CONV_1X1 else 9
     Hout, Wout = _out_hw(mode, Hin, Win)
+    if force_gather is True:
+        assert ops.conv_wgrad_dispatch(geom(B, Hin, Win, Cin, Hout, Wout, wrows, ldy, wrows, mode), dt) == _lib.KERNEL_GATHER
     Cw = wrows  # gradient rows = real output channels
     g = geom(B, Hin, Win, Cin, Hout, Wout, Cw, ldy, wrows, mode)
     x = rnd((B * Hin * Win, Cin), dt, 1)
