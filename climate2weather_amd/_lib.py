@@ -30,7 +30,7 @@ class ConvArgs(Structure):
         ("Hout", c_int32), ("Wout", c_int32), ("Cout", c_int32), ("ldy", c_int32),
         ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),
         ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
-        ("ln_eps", c_float), ("flags", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p),
+        ("ln_eps", c_float), ("flags", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p), ("kvalid", c_int32),
     ]
 
 

@@ -9,12 +9,14 @@
 //     four waves per SIMD; half the weight bytes streamed per output pixel, halo overhead 1.27 instead of 1.41;
 //   * the patch row pitch is 20 pixels (18 x 20 x 128 B = 46,080 B; pieces run through the flattened pixel index, 45 LDS-DMA pieces
 //     of 1 KiB), staged ONCE per 64-channel K chunk, all nine taps read it at immediate LDS offsets;
-//   * a stage is one tap x HALF a K chunk (32 channels): the weight ring is 3 x 8 KiB ([128 co][64 B] rows, XOR-swizzled on the
+//   * a stage is one tap x HALF a K chunk (32 channels); the loop body is the nine taps of one half, so K is walked in 32-channel
+//     steps and a caller's promise that trailing channels are zero (kvalid: the padded edge convs) ends it early; the weight ring is 3 x 8 KiB ([128 co][64 B] rows, XOR-swizzled on the
 //     source address so that every ds_read_b128 lane group covers all 64 banks), filled two stages ahead by LDS-DMA with counted
-//     vmcnt waits; 70.7 KB of LDS => two workgroups per CU, one in its epilogue while the other multiplies; one barrier per stage;
+//     vmcnt waits; 71.7 KB of LDS => two workgroups per CU, one in its epilogue while the other multiplies; one barrier per stage;
 //   * stages run kernel-column-major (half, kw, kh): the three taps of a column read the same pixel columns one row apart, so the
 //     pixel fragments stay in registers across kh -- 22 fragment reads per three stages instead of 36;
-//   * the bias is loaded after the loop (16 VGPRs the loop does not have);
+//   * the bias reaches LDS by one LDS-DMA piece at kernel start and is read after the loop (16 VGPRs the loop does not have, and no
+//     dependent global load at the head of the epilogue);
 //   * one instantiation per epilogue family (LayerNorm emission / LayerNorm backward / elementwise / 2x2-pooled): in the smaller
 //     kernels the residual / multiplier rows of BOTH 8-row blocks are requested before the first block is finished.
 // MFMA shape and the epilogue (conv_epilogue.h) are those of conv_patch_half_kernel; A = weights, B = pixels.
@@ -54,7 +56,8 @@ template <int TR, int NW = 4> struct T3Cfg {
     static constexpr int NPASS = TR / 8;                       // epilogue passes of 128 tile pixels
     static constexpr int LDS_LOOP = PBYTES + 3 * T3_WBYTES;  // 50,176 / 70,656 with three slots
     static constexpr int LDS_EPI = TR * 16 * T3_OS + 512;      // output tile + LayerNorm column sums
-    static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+    static constexpr int LDS_BIAS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;  // the tile's 128 bias values: one LDS-DMA piece (1 KiB) behind everything else
+    static constexpr int LDS = LDS_BIAS + 1024;
     static constexpr int WAVES_PER_SIMD = NW == 8 ? 4 : (TR == 8 ? 3 : 2);
     static_assert(NB >= 1 && 8 % NW == 0, "wave tiling");
 };
@@ -176,31 +179,64 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[j][m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int nchunk = p.Cin / 64;
-    const int NS = nchunk * 18;
+    // K extent in 32-channel halves of the 64-channel chunks: all of Cin, or the caller's promise that channels >= kvalid are zero in
+    // x or in w (C2wConvArgs.kvalid: the padded edge convs at C = 65 visit 3 halves instead of 4)
+    const int kv = p.kvalid > 0 && p.kvalid < p.Cin ? p.kvalid : p.Cin;
+    const int nhalf = (kv + 31) >> 5;
+    const int NS = nhalf * 9;
 
     float bv[4][4];
+    if (wid == 0) {  // the bias of the tile's 128 output channels -> LDS, by the wave's OLDEST load (every counted wait below covers it): the
+                     // epilogue reads it from there instead of starting with a dependent global load (isolated launches 0-2.8 % faster)
+        const bool hb = p.bias != nullptr && co0 < p.wrows;  // no bias / rows past wrows read as zero (out of the descriptor's range)
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(hb ? (const void*)(p.bias + co0) : (const void*)p.w, hb ? (uint32_t)(p.wrows - co0) * 4u : 0u);
+        glds16(rb, smem + CF::LDS_BIAS, lane < 32 ? (uint32_t)lane * 16u : C2W_OOB, 0u);
+    }
     issue_patch(0);
-    issue_w(0, 0, 0, 0);  // stage 0 = (tap 0, half 0) in both stage orders
+    issue_w(0, 0, 0, 0);  // stage 0 = (tap 0, half 0)
     issue_w(0, 3, 0, 1);  // stage 1 = (kh 1, kw 0) = tap 3, half 0
 
-    // stage s = chunk c x 18 + IDX, IDX = half * 9 + kw * 3 + kh (kernel-column-major); its weights live in ring slot s % 3 = IDX % 3
-    // (18 % 3 == 0).  The three taps of one kernel column read the SAME pixel columns (li + kw) at rows n + kh, so the pixel fragments
-    // stay in registers across kh: 4 rows at kh = 0, one new row each at kh = 1, 2 -- 22 ds_read_b128 per three stages instead of 36
-    // (LDS bytes read per MFMA 0.23 KB instead of 0.375 KB).
+    // L2 warm-up of the epilogue's operand rows.  The residual / multiplier / LayerNorm-input rows of the tile can only be REQUESTED once
+    // the accumulators have left the registers, i.e. 3-5 us into the epilogue, and that wait is what a fused launch pays per operand
+    // (ablation: 45 us per 537 MB operand stream at 128->128 @128^2, profiles/r03_experiments.md).  In the tile's last stage -- behind
+    // its vmcnt(0), so the counted waits of the loop are not disturbed -- every thread touches one 128-B line of each operand's tile
+    // (512 lines = 64 KB) with a 4-byte LDS-DMA load into a scratch slot nobody reads: the lines are on their way from HBM into L2
+    // while the last MFMAs, the gather barrier and the staging run.
+    auto touch_operands = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));  // derived here, not held through the loop
+        const int pix = t >> 1;
+        const bool in_row = co0 + (t & 1) * 64 < p.Cout;  // a partial last channel tile has fewer lines per pixel
+        const uint32_t voff = in_row ? (uint32_t)(((pix >> 4) * W + (pix & 15)) * p.ldy) * ESZ + (uint32_t)(t & 1) * 128u : C2W_OOB;
+        const size_t tile0 = ((((size_t)b * H + oh0) * W + ow0) * p.ldy + co0) * ESZ;
+        char* const scratch = smem + CF::LDS_BIAS + 512;  // 256 B behind the bias values (garbage, never read)
+        const void* const ops_[2] = {p.res, p.ln_x != nullptr ? p.ln_x : p.mul};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (ops_[k] != nullptr) {  // kernel arguments: uniform
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)ops_[k] + tile0, 0x7ffffff0u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (lds_void_t*)scratch, 4, (int)voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // stage s = hc x 9 + IDX: hc = 2 x chunk + half (the 32-channel half of a 64-channel K chunk), IDX = kw * 3 + kh (kernel-column-
+    // major); its weights live in ring slot s % 3 = IDX % 3 (9 % 3 == 0).  The three taps of one kernel column read the SAME pixel
+    // columns (li + kw) at rows n + kh, so the pixel fragments stay in registers across kh: 4 rows at kh = 0, one new row each at
+    // kh = 1, 2 -- 22 ds_read_b128 per three stages instead of 36 (LDS bytes read per MFMA 0.23 KB instead of 0.375 KB).
     u32x4_t bq[4 * NB + 2];
-    auto stage = [&](auto IDXc, int c) {
+    auto stage = [&](auto IDXc, int hc) {
         constexpr int IDX = decltype(IDXc)::value;
-        constexpr int HALF = IDX / 9;
-        constexpr int KW = (IDX % 9) / 3;
+        constexpr int KW = IDX / 3;
         constexpr int KH = IDX % 3;
-        constexpr int WS = IDX % 3;  // ring slot of stage s = s % 3 (18 % 3 == 0: a compile-time slot)
-        const int s = c * 18 + IDX;
+        constexpr int WS = IDX % 3;  // ring slot of stage s = s % 3: a compile-time slot
+        const int s = hc * 9 + IDX;
+        const int half = hc & 1, c = hc >> 1;
         auto issue_ahead = [&]() {  // weights of stage s + 2
-            constexpr int I2 = (IDX + 2) % 18;
-            constexpr int H2 = I2 / 9;
-            constexpr int T2 = (I2 % 3) * 3 + (I2 % 9) / 3;
-            issue_w(IDX + 2 < 18 ? c : c + 1, T2, H2, I2 % 3);
+            constexpr int I2 = (IDX + 2) % 9;
+            constexpr int T2 = (I2 % 3) * 3 + I2 / 3;
+            const int h2 = IDX + 2 < 9 ? hc : hc + 1;
+            issue_w(h2 >> 1, T2, h2 & 1, I2 % 3);
         };
         u32x4_t a[4];
         auto mfmas = [&](auto KHc, auto hook) {
@@ -214,11 +250,11 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
                 }
             }
         };
-        // everything but the next stage's (stages') weight pieces has landed
+        // everything but the next stage's weight piece has landed
         t3_wait<CF::WPIECES>(s + 1 < NS);
         __builtin_amdgcn_s_barrier();
         bool ahead = s + 2 < NS;
-        if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+        if (IDX == 0 && half == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
             issue_patch(c);
             if (ahead) issue_ahead();
             ahead = false;
@@ -230,31 +266,30 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
                 ahead = false;
             }
         }
+        if constexpr (IDX == 8 && EPI != 0) {
+            if (s + 1 == NS) touch_operands();  // the tile's last stage: nothing of the loop is in flight any more (vmcnt(0) above)
+        }
         const uint32_t offA = offA_at() + (uint32_t)(WS * T3_WBYTES);
-        const uint32_t offB_kw = offB_at(KW) ^ (uint32_t)(HALF * 64);
-        auto rowp = [&](int kw, int half, int row) {
-            const uint32_t o = kw == KW && half == HALF ? offB_kw : (offB_at(kw) ^ (uint32_t)(half * 64));
-            return (const u32x4_t*)(smem + o + row * T3_PW * 128);
-        };
+        const uint32_t offB_kw = offB_at(KW) ^ (uint32_t)(half * 64);
+        auto rowp = [&](int row) { return (const u32x4_t*)(smem + offB_kw + row * T3_PW * 128); };
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = *(const u32x4_t*)(smem + offA + m * 1024);
         {
             if constexpr (KH == 0) {
 #pragma unroll
-                for (int n = 0; n < 4 * NB; ++n) bq[n] = *rowp(KW, HALF, n);
+                for (int n = 0; n < 4 * NB; ++n) bq[n] = *rowp(n);
             } else {
-                bq[4 * NB - 1 + KH] = *rowp(KW, HALF, 4 * NB - 1 + KH);
+                bq[4 * NB - 1 + KH] = *rowp(4 * NB - 1 + KH);
             }
         }
         mfmas(IC3<KH>{}, [&](int n) {
         });
     };
-    // (the chunk loops are spelled out: wrapped in a generic lambda the same code allocates 8 registers more and spills)
+    // (the loop body is spelled out: wrapped in a generic lambda the same code allocates 8 registers more and spills)
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
-        stage(IC3<0>{}, c); stage(IC3<1>{}, c); stage(IC3<2>{}, c); stage(IC3<3>{}, c); stage(IC3<4>{}, c); stage(IC3<5>{}, c);
-        stage(IC3<6>{}, c); stage(IC3<7>{}, c); stage(IC3<8>{}, c); stage(IC3<9>{}, c); stage(IC3<10>{}, c); stage(IC3<11>{}, c);
-        stage(IC3<12>{}, c); stage(IC3<13>{}, c); stage(IC3<14>{}, c); stage(IC3<15>{}, c); stage(IC3<16>{}, c); stage(IC3<17>{}, c);
+    for (int hc = 0; hc < nhalf; ++hc) {
+        stage(IC3<0>{}, hc); stage(IC3<1>{}, hc); stage(IC3<2>{}, hc); stage(IC3<3>{}, hc); stage(IC3<4>{}, hc);
+        stage(IC3<5>{}, hc); stage(IC3<6>{}, hc); stage(IC3<7>{}, hc); stage(IC3<8>{}, hc);
     }
 
     // epilogue: the residual / multiplier rows are fetched AFTER the accumulators have left the registers (the half-tile
@@ -264,7 +299,11 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, li_e = lane_e & 15, lg_e = lane_e >> 4;
-    epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bv);  // after the loop: 16 VGPRs the loop does not have
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // after the loop: 16 VGPRs the loop does not have
+        const f32x4_t t = *(const f32x4_t*)(smem + CF::LDS_BIAS + (wm * 64 + m * 16 + lg_e * 4) * 4);
+        bv[m][0] = t[0]; bv[m][1] = t[1]; bv[m][2] = t[2]; bv[m][3] = t[3];
+    }
     __syncthreads();
     char* const O = smem;
     float* const red = (float*)(smem + TR * 16 * T3_OS);
@@ -274,31 +313,22 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // both 8-row blocks' residual / multiplier rows are requested before the first block is finished: the second block's HBM latency
     // runs behind the first block's arithmetic and stores (the accumulators have left the registers, so both sets fit)
     if constexpr (CF::NPASS == 2 && EPI != 0) {  // the per-family instantiations; in the all-in-one kernel (EPI = 0) this spills 54 registers
-        const bool pool2 = EPI == 0 && (p.flags & C2W_CONV_POOL2) != 0;
         EpiStore<T, 128, T3_NTHR> est0, est1;
-        if (p.ln_x != nullptr && tid_e < 128) red[tid_e] = 0.f;
-        if (!pool2) {
-            est0.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0) * W + ow0, W);
-            est1.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8) * W + ow0, W);
-        }
+        if (EPI == 3 && tid_e < 128) red[tid_e] = 0.f;
+        est0.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0) * W + ow0, W);
+        est1.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8) * W + ow0, W);
         __syncthreads();
+        typename EpiStore<T, 128, T3_NTHR>::LnColSums dmsum;  // LayerNorm backward: modulation-gradient column sums, carried over both blocks
+        if constexpr (EPI == 3) dmsum.clear();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             auto& est = h == 0 ? est0 : est1;
             const char* const Oh = O + h * 128 * T3_OS;
             if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
-            else if constexpr (EPI == 3) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
-            else if constexpr (EPI == 4) est.finish(p, Oh, T3_OS, tid_e);
-            else if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
-            else if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
-            else if (p.lnf_y != nullptr) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+            else if constexpr (EPI == 3) est.finish_ln_rows(p, Oh, T3_OS, tid_e, b, dmsum);
             else est.finish(p, Oh, T3_OS, tid_e);
-            if (h == 0 && (EPI == 3 || (EPI == 0 && p.ln_x != nullptr))) {  // the LayerNorm column sums are re-zeroed for the second block only after everyone read them
-                __syncthreads();
-                if (tid_e < 128) red[tid_e] = 0.f;
-                __syncthreads();
-            }
         }
+        if constexpr (EPI == 3) est0.finish_ln_dm(p, tid_e, b, red, dmsum);  // one reduction per tile (was: per block, with two more barriers between)
     } else {
 #pragma unroll
         for (int h = 0; h < CF::NPASS; ++h) {

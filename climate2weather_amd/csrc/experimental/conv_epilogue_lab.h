@@ -7,6 +7,12 @@
 // all of a group's global loads issued before the first use.
 #pragma once
 #include "conv_geom.h"
+// LAB COPY of conv_epilogue.h (included by experimental/conv_patch3_lab.hip only) with ablation bits for timing builds -- results are
+// WRONG with any bit set:  -DC2W_EPI_ABL=  1 LayerNorm-emission / pair flavours: second output not stored   2 residual / multiplier rows
+// not loaded   4 LayerNorm-emission: no LayerNorm arithmetic (the stored row is written twice)   8 first output not stored
+#ifndef C2W_EPI_ABL
+#define C2W_EPI_ABL 0
+#endif
 
 // the epilogues' 16-B output stores carry the non-temporal hint (written once, read by a later kernel, never by this one): 1-2 % on
 // isolated launches of every flavour, 0.2 % on the step (profiles/r02_ab_conv_epilogues.txt)
@@ -145,6 +151,11 @@ struct EpiStore {
     }
 
     __device__ __forceinline__ void issue_prefetch(const C2wConvArgs& p) {
+        if constexpr ((C2W_EPI_ABL & 2) != 0) {
+#pragma unroll
+            for (int i = 0; i < (EARLY ? NIT : 1); ++i) rr[i] = mm[i] = (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            return;
+        }
         if constexpr (EARLY) {
             if (p.res != nullptr) {
 #pragma unroll
@@ -163,25 +174,9 @@ struct EpiStore {
     //   y = res + ( g - mean(g) - xh * sum(g*xh)/den ) / s ;   ln_dm[img][c] += column sums of the LN part
     // Same arithmetic, in the same order, as ln_bwd_kernel (pointwise.hip): 16 lanes share a pixel row.
     // `red`: 128 floats of LDS outside O, zeroed by the caller before the barrier that precedes this call.
-    typedef __attribute__((ext_vector_type(2))) float ln_f2;  // pairs -> v_pk_{add,mul,fma}_f32: half the VALU issue slots
-    struct LnColSums {  // per-thread column sums of the LayerNorm part: the thread's 8 channels over the rows it has finished
-        ln_f2 am[4];
-        __device__ __forceinline__ void clear() {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) am[k] = (ln_f2){0.f, 0.f};
-        }
-    };
-    // one call = one pass of NROWS tile rows and the modulation-gradient reduction behind it (tiles of one pass)
     __device__ __forceinline__ void finish_ln(const C2wConvArgs& p, const char* O, int OS, int tid, int img, float* red) {
-        LnColSums cs;
-        cs.clear();
-        finish_ln_rows(p, O, OS, tid, img, cs);
-        finish_ln_dm(p, tid, img, red, cs);
-    }
-    // the rows of one pass; the column sums are carried in `acc` (a tile of several passes reduces them once: finish_ln_dm)
-    __device__ __forceinline__ void finish_ln_rows(const C2wConvArgs& p, const char* O, int OS, int tid, int img, LnColSums& acc) {
         static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN backward: 16-bit tiles only");
-        typedef ln_f2 f2;
+        typedef __attribute__((ext_vector_type(2))) float f2;  // pairs -> v_pk_{add,mul,fma}_f32: half the VALU issue slots
         const int cs = tid & (SEGS - 1);
         f2 m2[4];
         if (p.ln_m != nullptr) {
@@ -193,7 +188,9 @@ struct EpiStore {
             for (int k = 0; k < 4; ++k) m2[k] = (f2){0.f, 0.f};
         }
         const float inv_den = 1.0f / (float)(128 - (p.ln_unbiased ? 1 : 0));
-        f2 (&am)[4] = acc.am;
+        f2 am[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) am[k] = (f2){0.f, 0.f};
         auto unpack2 = [](const u32x4_t& v, f2* f) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -247,24 +244,19 @@ struct EpiStore {
             for (int k = 0; k < 4; ++k) out[k] = pack2<T>(o[k][0], o[k][1]);
             if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
         }
-    }
-    // column sums -> ln_dm[img]: across the four pixel rows of a wave in registers (lanes l, l+16, l+32, l+48 hold the same channels),
-    // across the waves through 128 floats of LDS (`red`, zeroed by the caller before the barrier that precedes the first pass), then
-    // one global atomic per channel.  Every thread of the workgroup must call it (barrier inside).
-    __device__ __forceinline__ void finish_ln_dm(const C2wConvArgs& p, int tid, int img, float* red, const LnColSums& acc) {
-        if (p.ln_dm == nullptr) return;  // kernel argument: uniform
-        const int cs = tid & (SEGS - 1);
+        if (p.ln_dm != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float v = acc.am[k][h];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if ((tid & 63) < 16) atomicAdd(&red[cs * PER16 + 2 * k + h], v);
-            }
-        __syncthreads();
-        if (tid < 128) atomicAdd(p.ln_dm + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + tid, red[tid]);
+                for (int h = 0; h < 2; ++h) {  // rows of this wave that share the channel: lanes l, l+16, l+32, l+48
+                    float v = am[k][h];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if ((tid & 63) < 16) atomicAdd(&red[cs * PER16 + 2 * k + h], v);
+                }
+            __syncthreads();
+            if (tid < 128) atomicAdd(p.ln_dm + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + tid, red[tid]);
+        }
     }
 
     // ---- fused LayerNorm FORWARD of the consumer (bf16 tile with whole 128-channel rows of one image `img`):
@@ -307,7 +299,13 @@ struct EpiStore {
                     out[k] = pack2<T>(u[k][0], u[k][1]);
                 }
             }
-            if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
+            if constexpr ((C2W_EPI_ABL & 8) == 0) {
+                if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
+            }
+            if constexpr ((C2W_EPI_ABL & 4) != 0) {
+                if (off[i] >= 0) epi_st((char*)p.lnf_y + off[i], out);
+                continue;
+            }
             unpack2(out, u);  // the values as stored (bf16), like the separate LN pass would read them
             f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
@@ -326,7 +324,11 @@ struct EpiStore {
             u32x4_t ln;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ln[k] = pack2<T>(u[k][0] * rs, u[k][1] * rs);
-            if (off[i] >= 0) epi_st((char*)p.lnf_y + off[i], ln);
+            if constexpr ((C2W_EPI_ABL & 1) == 0) {
+                if (off[i] >= 0) epi_st((char*)p.lnf_y + off[i], ln);
+            } else {
+                asm volatile("" ::"v"(ln));
+            }
         }
     }
 
@@ -428,8 +430,10 @@ struct EpiStore {
                         d_[e] = sg + h_[e] * (1.0f - sg);
                     }
                     if (o >= 0) {
-                        epi_st((char*)p.y + o, pack16<T>(h_));
-                        epi_st((char*)p.y2 + o, pack16<T>(d_));
+                        if constexpr ((C2W_EPI_ABL & 8) == 0) epi_st((char*)p.y + o, pack16<T>(h_));
+                        else asm volatile("" ::"v"(pack16<T>(h_)));
+                        if constexpr ((C2W_EPI_ABL & 1) == 0) epi_st((char*)p.y2 + o, pack16<T>(d_));
+                        else asm volatile("" ::"v"(pack16<T>(d_)));
                     }
                 } else if (p.act == C2W_ACT_RELU_PAIR && p.y2 != nullptr) {  // y = max(a, 0), y2 = (a > 0)
                     float a_[PER16], h_[PER16], d_[PER16];
@@ -444,7 +448,8 @@ struct EpiStore {
                         epi_st((char*)p.y2 + o, pack16<T>(d_));
                     }
                 } else if (o >= 0) {
-                    epi_st((char*)p.y + o, v[i]);
+                    if constexpr ((C2W_EPI_ABL & 8) == 0) epi_st((char*)p.y + o, v[i]);
+                    else asm volatile("" ::"v"(v[i]));
                     if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
                         float f2[PER16];
                         unpack16<T>(v[i], f2);

@@ -28,7 +28,7 @@
 // counted vmcnt waits (seen as wrong weight rows at chunk boundaries with 40 spilled registers).
 #include <cstdlib>
 
-#include "conv_epilogue.h"
+#include "conv_epilogue_lab.h"
 
 #ifndef C2W_T3V
 #define C2W_T3V 10  // stage order / LDS-DMA placement / bias placement of conv_patch_t3_kernel (bits: see `stage` below); 10 = measured best
@@ -57,6 +57,10 @@
 #endif
 #ifndef C2W_T3_STAGGER
 #define C2W_T3_STAGGER 0  // x 8128 cycles: start delay of the second workgroup of every CU (see the kernel entry)
+#endif
+#ifndef C2W_T3_BIASLDS
+#define C2W_T3_BIASLDS 0  // 1: the tile's 128 bias values are fetched by one LDS-DMA piece at kernel start (wave 0) into 1 KiB behind the loop's LDS
+                          // and read from there after the loop -- no dependent global load at the head of the epilogue
 #endif
 #ifndef C2W_EXP
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA, 8 no stage barrier
@@ -87,7 +91,8 @@ template <int TR, int NW = 4> struct T3Cfg {
     static constexpr int NPASS = TR / 8;                       // epilogue passes of 128 tile pixels
     static constexpr int LDS_LOOP = PBYTES + C2W_T3_RING * T3_WBYTES;  // 50,176 / 70,656 with three slots
     static constexpr int LDS_EPI = TR * 16 * T3_OS + 512;      // output tile + LayerNorm column sums
-    static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+    static constexpr int LDS_BIAS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;  // offset of the bias kilobyte (C2W_T3_BIASLDS)
+    static constexpr int LDS = LDS_BIAS + ((C2W_T3_BIASLDS) ? 1024 : 0);
     static constexpr int WAVES_PER_SIMD = NW == 8 ? 4 : (TR == 8 ? 3 : 2);
     static_assert(NB >= 1 && 8 % NW == 0, "wave tiling");
 };
@@ -374,6 +379,13 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
 
     float bv[4][4];
     if constexpr (TR == 16 && (C2W_T3V & 8) == 0) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);  // latency hidden by the loop; 16 VGPRs
+    if constexpr ((C2W_T3_BIASLDS) != 0) {
+        if (wid == 0) {  // oldest load of this wave: every counted wait below covers it
+            const bool hb = p.bias != nullptr && co0 < p.wrows;
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(hb ? (const void*)(p.bias + co0) : (const void*)p.w, hb ? (uint32_t)(p.wrows - co0) * 4u : 0u);
+            glds16(rb, smem + CF::LDS_BIAS, lane < 32 ? (uint32_t)lane * 16u : C2W_OOB, 0u);
+        }
+    }
     issue_patch(0);
     issue_w(0, 0, 0, 0);  // stage 0 = (tap 0, half 0) in both stage orders
     if constexpr ((C2W_T3V & 2) != 0) issue_w(0, 3, 0, 1);  // kw-major: stage 1 = (kh 1, kw 0) = tap 3, half 0
@@ -578,7 +590,13 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, li_e = lane_e & 15, lg_e = lane_e >> 4;
-    if constexpr (TR == 8 || (C2W_T3V & 8) != 0) epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bv);
+    if constexpr ((C2W_T3_BIASLDS) != 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4_t t = *(const f32x4_t*)(smem + CF::LDS_BIAS + (wm * 64 + m * 16 + lg_e * 4) * 4);
+            bv[m][0] = t[0]; bv[m][1] = t[1]; bv[m][2] = t[2]; bv[m][3] = t[3];
+        }
+    } else if constexpr (TR == 8 || (C2W_T3V & 8) != 0) epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bv);
     __syncthreads();
     T3_STAMP(4);
     char* const O = smem;

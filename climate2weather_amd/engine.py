@@ -530,7 +530,10 @@ class Engine:
             if want_ln is not None and act == ACT_NONE and y2 is None and ops.conv_lnfwd_supported(g, dt):
                 hn = torch.empty_like(y)
                 lnf = dict(y=hn, m=want_ln[1], ldm=ldm if want_ln[1] is not None else 0, eps=LN_EPS, unbiased=self.ln_unbiased)
-            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2, lnf=lnf)
+            # padded operand (network input at C = 65: rows of 128 channels): channels >= rec.cin are zero in x and in w -- a promise the
+            # 16x16-tile kernel turns into fewer K steps
+            ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2, lnf=lnf,
+                     kvalid=rec.cin if rec.kstride != rec.cin else 0)
             if want_ln is not None:
                 return y, g, rec, hn
             return y, g, rec
@@ -542,7 +545,10 @@ class Engine:
             if ln is not None and not ops.conv_lnbwd_supported(g, dt):
                 return None
             dx = torch.empty((B * Ho * Wo, ld_out), dtype=T, device=dev)
-            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=mulmode, ln=ln)
+            # output conv at C = 65: gy rows are padded to dg_ld = 128 channels, the padding is zero (mse_loss_grad) and so are the
+            # operand's columns there
+            ops.conv(gy, self._wT(rec, dt), None, dx, g, dt, res=res, mul=mul, mulmode=mulmode, ln=ln,
+                     kvalid=rec.rows if rec.dg_ld != rec.rows else 0)
             return dx
 
         def res_block(b: BlockSpec, xin, Hc, Wc, h0=None, want_ln=None):

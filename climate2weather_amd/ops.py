@@ -45,7 +45,7 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
 
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
-         ln=None, lnf=None, pool2: bool = False):
+         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
     dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.
@@ -54,6 +54,7 @@ def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=
     a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf)
     if pool2:  # y: [B][Hout/2][Wout/2][ldy] <- 2x2 sums of the result (only where conv_pool2_supported says so)
         a.flags = _lib.CONV_POOL2
+    a.kvalid = int(kvalid)  # promise: input channels >= kvalid are all zero in x or in w (0: no promise)
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 

@@ -79,6 +79,11 @@ typedef struct C2wConvArgs {
      * produced the block input, without a separate pass over it. */
     void* lnf_y;        /* [B*Hout*Wout][ldy] or NULL */
     const float* lnf_m; /* [B][ln_ldm] fp32 modulation rows of the CONSUMER block, or NULL (plain LayerNorm) */
+    /* Optional promise about channel padding: 0, or the number of leading input channels that can be non-zero -- channels kvalid..Cin-1
+     * of x (or of w) are ALL ZERO (the network-input conv at C = 65 reads rows padded to 128 channels, model/nn.py:193; the input
+     * gradient of the output conv reads a gradient whose padding channels are zero, :194).  Kernels may skip the multiplications
+     * the promise makes void (conv_patch_t3_kernel: whole 32-channel half chunks); results are unchanged. */
+    int32_t kvalid;
 } C2wConvArgs;
 
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly

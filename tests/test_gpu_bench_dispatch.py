@@ -78,6 +78,9 @@ FWD_CASES = [
     # edge convs (model/nn.py:193-194) at C = 65: K padded 65 -> 128 with zero channels; 65 real output rows in a 128-wide buffer
     ("network input 65(128)->128 @128^2", T3, S1, 16, 128, 128, 128, 128, 65, ["bias+lnf", "bias"]),
     ("network output 128->65(128) @128^2", T3, S1, 16, 128, 128, 128, 65, 128, ["bias"]),
+    ("network output's input gradient 65(128)->128 @128^2", T3, S1, 16, 128, 128, 128, 128, 65, ["plain"]),
+    ("K of 3 chunks, the last one half void: 160(192)->128 @64^2", T3, S1, 64, 64, 192, 128, 128, 160, ["bias+res"]),
+    ("K promise that leaves whole chunks out: 40(192)->128 @64^2", T3, S1, 64, 64, 192, 128, 128, 40, ["bias"]),
     # stride-2 family (model/nn.py:169-174): forward on the gather kernel, input gradient per output-parity class (+ skip gradient)
     ("down 128->128 128^2->64^2", GATHER, S2, 16, 128, 128, 128, 128, 128, ["bias"]),
     ("down 256->384 32^2->16^2", GATHER, S2, 128, 32, 256, 384, 384, 256, ["bias"]),
@@ -142,6 +145,16 @@ def _run_conv_case(case, dt, ep):
         close(dm, dm_ref, 1e-2, f"{name} [{ep}] modulation gradient")
     if wrows < Cout:
         assert y[:, wrows:].abs().max().item() == 0.0, f"{name}: padded output rows must stay zero"
+    if cin_real < Cin:  # C2wConvArgs.kvalid: the promise that the padding channels are zero lets the kernel skip K steps -- same bits
+        y_k = torch.full_like(y, 5.0)
+        kw_k = dict(kw)
+        if want_lnf:
+            hn_k = torch.full_like(y, 5.0)
+            kw_k = dict(lnf=dict(kw["lnf"], y=hn_k))
+        ops.conv(x, w, bias, y_k, g, dt, res=res, kvalid=cin_real, **kw_k)
+        assert torch.equal(y_k, y), f"{name} [{ep}]: kvalid = {cin_real} changed the result"
+        if want_lnf:
+            assert torch.equal(hn_k, hn)
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])

@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../climate2weather_amd"
 name=$1; shift
 mkdir -p build/alt/$name
 for f in conv_patch3 conv_patch wgrad_patch; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../include -Icsrc "$@" -c csrc/experimental/${f}_lab.hip -o build/alt/$name/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../include -Icsrc -Icsrc/experimental "$@" -c csrc/experimental/${f}_lab.hip -o build/alt/$name/$f.o &
 done
 wait
 objs=""
