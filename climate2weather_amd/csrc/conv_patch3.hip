@@ -196,30 +196,6 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     issue_w(0, 0, 0, 0);  // stage 0 = (tap 0, half 0)
     issue_w(0, 3, 0, 1);  // stage 1 = (kh 1, kw 0) = tap 3, half 0
 
-    // L2 warm-up of the epilogue's operand rows.  The residual / multiplier / LayerNorm-input rows of the tile can only be REQUESTED once
-    // the accumulators have left the registers, i.e. 3-5 us into the epilogue, and that wait is what a fused launch pays per operand
-    // (ablation: 45 us per 537 MB operand stream at 128->128 @128^2, profiles/r03_experiments.md).  In the tile's last stage -- behind
-    // its vmcnt(0), so the counted waits of the loop are not disturbed -- every thread touches one 128-B line of each operand's tile
-    // (512 lines = 64 KB) with a 4-byte LDS-DMA load into a scratch slot nobody reads: the lines are on their way from HBM into L2
-    // while the last MFMAs, the gather barrier and the staging run.
-    auto touch_operands = [&]() {
-        int t = tid;
-        asm volatile("" : "+v"(t));  // derived here, not held through the loop
-        const int pix = t >> 1;
-        const bool in_row = co0 + (t & 1) * 64 < p.Cout;  // a partial last channel tile has fewer lines per pixel
-        const uint32_t voff = in_row ? (uint32_t)(((pix >> 4) * W + (pix & 15)) * p.ldy) * ESZ + (uint32_t)(t & 1) * 128u : C2W_OOB;
-        const size_t tile0 = ((((size_t)b * H + oh0) * W + ow0) * p.ldy + co0) * ESZ;
-        char* const scratch = smem + CF::LDS_BIAS + 512;  // 256 B behind the bias values (garbage, never read)
-        const void* const ops_[2] = {p.res, p.ln_x != nullptr ? p.ln_x : p.mul};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (ops_[k] != nullptr) {  // kernel arguments: uniform
-                const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)ops_[k] + tile0, 0x7ffffff0u);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (lds_void_t*)scratch, 4, (int)voff, 0, 0, 0);
-            }
-        }
-    };
-
     // stage s = hc x 9 + IDX: hc = 2 x chunk + half (the 32-channel half of a 64-channel K chunk), IDX = kw * 3 + kh (kernel-column-
     // major); its weights live in ring slot s % 3 = IDX % 3 (9 % 3 == 0).  The three taps of one kernel column read the SAME pixel
     // columns (li + kw) at rows n + kh, so the pixel fragments stay in registers across kh: 4 rows at kh = 0, one new row each at
@@ -265,9 +241,6 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
                 issue_ahead();
                 ahead = false;
             }
-        }
-        if constexpr (IDX == 8 && EPI != 0) {
-            if (s + 1 == NS) touch_operands();  // the tile's last stage: nothing of the loop is in flight any more (vmcnt(0) above)
         }
         const uint32_t offA = offA_at() + (uint32_t)(WS * T3_WBYTES);
         const uint32_t offB_kw = offB_at(KW) ^ (uint32_t)(half * 64);
