@@ -207,6 +207,30 @@ class LaunchTimer:
         return out
 
 
+def pmc_traffic(a):
+    """roofline.traffic: HBM bytes per forward launch of the dominant layers, from the PMC passes over this same training step
+    (tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate runs, FETCH_SIZE
+    doubled for gfx950; summary committed as profiles/r03_pmc_step.json).  PMC counters cannot be read from inside this process, so the
+    figure is the committed profile's, valid for the default workload only -- null otherwise."""
+    path = os.path.join(REPO, "profiles", "r03_pmc_step.json")
+    if not (a.size == 128 and a.batch == 128 and a.precision == "bf16" and a.vars == 5 and os.path.exists(path)):
+        return dict(traffic=None, from_profile=None)
+    try:
+        prof = json.load(open(path))
+        fd = prof["forward_dominant_launches"]
+        k = {(e["kernel"], e["workgroups"]): e for e in prof["kernels"]}
+        lnf = k.get(("conv_patch_t3_kernel<16, unsigned short, 8, 2>", 8192), {})
+    except (OSError, KeyError, ValueError):
+        return dict(traffic=None, from_profile=None)
+    return dict(traffic=fd["hbm_bytes"],
+                from_profile=dict(note="PMC passes over this training step on another box (tools/pmc_step.sh; rocprofv3 --kernel-trace --pmc, one counter group per run; "
+                                       "FETCH_SIZE x 2 for gfx950 + WRITE_SIZE): mean over the forward launches of 8192 workgroups with the epilogues the step runs "
+                                       "(SiLU pair: 537 MB in + 2 x 537 MB out algorithmic; residual + LayerNorm emission: 2 x 537 MB in + 2 x 537 MB out)",
+                                  source="profiles/r03_pmc_step.json", traffic_bytes_per_launch=fd["hbm_bytes"], hbm_read_bytes=fd["hbm_read_bytes"],
+                                  hbm_write_bytes=fd["hbm_write_bytes"], launches_profiled=fd["launches"],
+                                  mfma_busy_layernorm_emission_flavour=lnf.get("mfma_busy"), clock_ghz_under_load=lnf.get("clock_ghz")))
+
+
 # ----------------------------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_model() -> str:
     try:
@@ -371,11 +395,7 @@ def run_rank(a):
                         achieved=kf["tflops"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=kf["frac"],
                         launches_timed=int(round(kf["launches_per_step"] * a.steps)), avg_launch_ms=kf["avg_ms"],
                         flops_per_launch=kf["gflop_per_launch"] * 1e9,
-                        traffic=None,
-                        from_profile=dict(note="NOT measured in this run: PMC passes of the same kernel and shape (bias-only epilogue) on another box (rocprofv3 --pmc, "
-                                               "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); algorithmic bytes are 537 MB in + 537 MB out per launch",
-                                          source="profiles/r02_pmc_conv_patch3.md", traffic_bytes_per_launch=1.057e9, mfma_busy=0.62,
-                                          clock_ghz_under_load=1.75) if (a.size == 128 and a.batch == 128 and a.precision == "bf16") else None,
+                        **pmc_traffic(a),
                         all_launches=dict(note="forward + input-gradient launches of the same layers; the latter overlap the weight-gradient stream",
                                           launches_timed=int(round(all_n * a.steps)), avg_launch_ms=round(all_ms / all_n, 4) if all_n else None,
                                           achieved=round(all_tf, 1), frac=round(all_tf / MFMA_PEAK_TFLOPS, 4)))
