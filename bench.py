@@ -228,7 +228,12 @@ def pmc_traffic(a):
                                        "(SiLU pair: 537 MB in + 2 x 537 MB out algorithmic; residual + LayerNorm emission: 2 x 537 MB in + 2 x 537 MB out)",
                                   source="profiles/r03_pmc_step.json", traffic_bytes_per_launch=fd["hbm_bytes"], hbm_read_bytes=fd["hbm_read_bytes"],
                                   hbm_write_bytes=fd["hbm_write_bytes"], launches_profiled=fd["launches"],
-                                  mfma_busy_layernorm_emission_flavour=lnf.get("mfma_busy"), clock_ghz_under_load=lnf.get("clock_ghz")))
+                                  mfma_busy_layernorm_emission_flavour=lnf.get("mfma_busy"), clock_ghz_under_load=lnf.get("clock_ghz"),
+                                  mfma_busy_by_kernel_in_step={f"{e['kernel']} x{e['workgroups']} workgroups": dict(
+                                      mfma_busy=e.get("mfma_busy"), clock_ghz=e.get("clock_ghz"), launches=e.get("launches_mfma"))
+                                      for e in prof["kernels"] if e.get("mfma_busy") is not None and e.get("launches_mfma", 0) >= 10},
+                                  mfma_busy_note="SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the share of the cycles of the clock the chip "
+                                                 "HOLDS in which the matrix pipe is busy -- rocprof's MFMA utilisation; `frac` above is FLOP/s against the 2.4 GHz spec peak"))
 
 
 # ----------------------------------------------------------------------------------------------------------------- CPU baseline
