@@ -11,8 +11,8 @@ g = dict(B=B, Hin=H, Win=H, Cin=C, Hout=H, Wout=H, Cout=C, ldy=C, wrows=C, mode=
 x = torch.randn(B*H*H, C, device=dev).to(T); w = (torch.randn(C, 9, C, device=dev)/math.sqrt(9*C)).to(T)
 bias = torch.randn(C, device=dev); y = torch.empty(B*H*H, C, device=dev, dtype=T)
 res = torch.randn(B*H*H, C, device=dev).to(T)
-ntile = B*(H//16)**2 * (1 if os.environ.get('C2W_CONV_FULL') else 2)
-NS = 8 if not os.environ.get('C2W_CONV_FULL') else 5
+ntile = B*(H//16)**2 * 2  # 8x16-pixel tiles (lab build of conv_patch_lab.hip with -DC2W_EXP=16)
+NS = 8
 dbg = torch.zeros(ntile*NS, dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.c2w_debug_set.argtypes = [ctypes.c_void_p]
