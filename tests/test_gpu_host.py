@@ -333,6 +333,56 @@ def test_graph_replayed_score_function_equals_eager(golden_dir):
     assert (outs[1].cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_graph_replayed_score_function_sees_weights_written_through_the_parameters(prec):
+    """Round-2 advisor finding: replay never re-enters Engine.forward(), so the graph cache has to look at the Parameters' version
+    counters itself.  Capture in a 16-bit mode (the captured launches read the 16-bit weight SHADOW), then change the weights the way
+    callers do -- load_state_dict, an in-place optimizer-style update, an EMA copy_ -- and evaluate again with graphs on: each time
+    the result must equal a fresh eager evaluation of the new weights (stale captures would return the old weights' score)."""
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(11)
+    cfg = dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg).to(dev).eval()
+    net.precision = prec
+    pipe = SDAPipeline()
+    x = torch.randn(9, 2, 32, 32, device=dev)
+    t = torch.tensor(0.6)
+
+    def both():
+        outs = []
+        for graphs in (True, False):
+            sf_ = sf if graphs else BatchedScoreFunction(net, markov_order=1, batch_size=4, device=dev, noise_process=pipe)
+            with torch.no_grad():
+                outs.append(sf_(x, t).clone())
+        return outs
+
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=dev, noise_process=pipe)
+    sf.use_graphs = True
+    g0, e0 = both()
+    assert torch.equal(g0, e0) and len(sf._graphs) == 1
+    # 1. load_state_dict
+    sd = {k: v + 0.05 * torch.randn_like(v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    g1, e1 = both()
+    assert torch.equal(g1, e1) and not torch.equal(g1, g0)
+    # 2. in-place update through the Parameter objects (what torch.optim does)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    g2, e2 = both()
+    assert torch.equal(g2, e2) and not torch.equal(g2, g1)
+    # 3. copy_ into the parameters (EMA -> net)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(p * 0.9)
+    g3, e3 = both()
+    assert torch.equal(g3, e3) and not torch.equal(g3, g2)
+    # unchanged weights: the captures are reused
+    first = next(iter(sf._graphs.values()))["graphs"]
+    g4, _ = both()
+    assert next(iter(sf._graphs.values()))["graphs"] is first and torch.equal(g4, g3)
+
+
 def test_bf16_and_fp16_training_track_fp32_training():
     """60 optimizer steps on a small network and a fixed synthetic batch stream: the bf16 throughput mode and the fp16 mode (the
     reference's own "16-mixed", under the device-resident dynamic loss scale) must learn like the fp32 parity mode (same data,
