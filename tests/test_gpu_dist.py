@@ -142,3 +142,23 @@ def test_bench_launcher_spawns_one_rank_per_gpu(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == n and rec["config"]["parallelism"] == f"dp{n}" and rec["config"]["global_batch"] == 8 * n
     assert rec["world_size_rccl"] == n and rec["value"] > 0
+
+
+def test_bench_launcher_counts_gpus_without_hip_and_refuses_more_ranks_than_gpus():
+    """bench.visible_gpus() reads the KFD topology of THIS box (no HIP call); asking for one rank more than there are GPUs is
+    refused (rc 2) before any child starts -- or, where the topology is unreadable, fails in the rank that finds no device."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    seen = bench.visible_gpus()
+    assert seen is None or seen == NGPU, (seen, NGPU)
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(NGPU + 1), "--steps", "1", "--warmup", "0", "--batch", "4",
+                          "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    if seen is not None:
+        assert out.returncode == 2 and f"only {NGPU} GPU(s) are visible" in out.stderr
+
