@@ -54,11 +54,13 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------------------------------- launcher
-def visible_gpus():
-    """GPUs this process tree may use, counted WITHOUT a HIP / HSA call (the parent must stay GPU-free: it only starts the ranks):
-    KFD topology nodes with SIMDs (/sys/class/kfd/kfd/topology/nodes/*/properties: CPU nodes have simd_count 0), narrowed by the
-    *_VISIBLE_DEVICES masks.  None when the topology is not readable (then --gpus is trusted and a rank without a device fails)."""
+def visible_gpus(run=subprocess.run):
+    """GPUs this process tree may use, counted WITHOUT a HIP / HSA call in THIS process (the parent must stay GPU-free: it only
+    starts the ranks).  First the KFD topology in sysfs (nodes with SIMDs; CPU nodes have simd_count 0), narrowed by the
+    *_VISIBLE_DEVICES masks; where that is not readable (containers) a throw-away child process asks the runtime.  None if neither
+    answers (then --gpus is trusted and a rank without a device fails)."""
     root = "/sys/class/kfd/kfd/topology/nodes"
+    n = None
     try:
         n = 0
         for node in sorted(os.listdir(root)):
@@ -67,18 +69,26 @@ def visible_gpus():
             if int(props.get("simd_count", "0")) > 0:
                 n += 1
     except (OSError, ValueError):
+        n = None
+    if n is not None:
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            mask = os.environ.get(var)
+            if mask is not None:
+                n = min(n, len([m for m in mask.split(",") if m.strip() != ""]))
+        return n
+    try:  # a child may initialise whatever it likes; this process does not
+        r = run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
         return None
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        mask = os.environ.get(var)
-        if mask is not None:
-            n = min(n, len([m for m in mask.split(",") if m.strip() != ""]))
-    return n
 
 
-def launch(a, popen=subprocess.Popen, count=visible_gpus) -> int:
+def launch(a, popen=subprocess.Popen, count=visible_gpus, grace=15.0) -> int:
     """`--gpus N` without a launcher's environment: one child process per GPU (what fabric.launch() does for the reference,
     train.py:93-100), rendezvous on 127.0.0.1, rank 0's stdout is relayed, everything else goes to stderr.  This parent makes no HIP
-    call (devices are counted from the KFD topology in sysfs); the children are fresh interpreters."""
+    call; the children are fresh interpreters.  A rank that dies takes the job down: the survivors (stuck in the rendezvous or in a
+    collective) are killed `grace` seconds later and the exit status is the failure's."""
+    import threading
     visible = count()
     if visible is not None and visible < a.gpus:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but only {visible} GPU(s) are visible; refusing to report fewer ranks than asked for\n")
@@ -93,16 +103,24 @@ def launch(a, popen=subprocess.Popen, count=visible_gpus) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                            stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:  # rank 0 is gone: a rank still alive two minutes later is stuck in a collective
-            p.kill()
-            rcs.append(p.wait())
-    sys.stdout.write(out0.decode())
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].communicate()[0]), daemon=True)  # drains rank 0's pipe while we watch
+    reader.start()
+    deadline = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if deadline is None and any(rc not in (None, 0) for rc in rcs):
+            deadline = time.time() + grace
+        if deadline is not None and time.time() >= deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            deadline = float("inf")
+        time.sleep(0.05)
+    reader.join(timeout=30)
+    sys.stdout.write((out0[0] if out0 and out0[0] else b"").decode())
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 

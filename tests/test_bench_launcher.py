@@ -15,35 +15,45 @@ import bench  # noqa: E402
 
 
 class FakeProc:
-    def __init__(self, argv, env, stdout, rc=0, out=b"", hang=False):
-        self.argv, self.env, self.stdout_arg, self.returncode_final, self.out, self.hang = argv, env, stdout, rc, out, hang
+    """What launch() uses of subprocess.Popen: poll / communicate / kill / returncode.  `life`: polls until it exits by itself
+    (None: never -- a rank stuck in a collective)."""
+
+    def __init__(self, argv, env, stdout, rc=0, out=b"", life=1):
+        self.argv, self.env, self.stdout_arg, self.rc_final, self.out, self.life = argv, env, stdout, rc, out, life
         self.returncode = None
         self.killed = False
+        self.polls = 0
+
+    def poll(self):
+        if self.returncode is None:
+            self.polls += 1
+            if self.killed:
+                self.returncode = -9
+            elif self.life is not None and self.polls > self.life:
+                self.returncode = self.rc_final
+        return self.returncode
 
     def communicate(self):
-        self.returncode = self.returncode_final
+        import time as _t
+        while self.returncode is None:
+            _t.sleep(0.01)
         return self.out, None
-
-    def wait(self, timeout=None):
-        if self.hang and not self.killed:
-            raise subprocess.TimeoutExpired(self.argv, timeout)
-        self.returncode = -9 if self.killed else self.returncode_final
-        return self.returncode
 
     def kill(self):
         self.killed = True
 
 
-def _launch(n, rcs=None, hang=None, count=lambda: 8, monkeypatch=None):
+def _launch(n, rcs=None, hang=None, count=lambda: 8, grace=0.2):
     procs = []
 
     def popen(argv, env=None, stdout=None):
         r = len(procs)
-        p = FakeProc(argv, env, stdout, rc=(rcs or {}).get(r, 0), out=b'{"metric": "m", "n_gpus": %d}\n' % n if r == 0 else b"", hang=r == hang)
+        p = FakeProc(argv, env, stdout, rc=(rcs or {}).get(r, 0), out=b'{"metric": "m", "n_gpus": %d}\n' % n if r == 0 else b"",
+                     life=None if r == hang else 2 + r)
         procs.append(p)
         return p
     a = argparse.Namespace(gpus=n)
-    return bench.launch(a, popen=popen, count=count), procs
+    return bench.launch(a, popen=popen, count=count, grace=grace), procs
 
 
 def test_launcher_wires_one_rank_per_gpu(capsys, monkeypatch):
@@ -63,15 +73,17 @@ def test_launcher_wires_one_rank_per_gpu(capsys, monkeypatch):
     assert "WORLD_SIZE" in procs[0].env
 
 
-def test_launcher_reports_a_dead_or_stuck_rank(monkeypatch):
+def test_launcher_reports_a_dead_rank_and_kills_the_ranks_it_leaves_stuck(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
     rc, _ = _launch(2, rcs={1: 1})
     assert rc == 1
     rc, _ = _launch(2, rcs={0: -11})  # rank 0 killed by a signal
     assert rc == 11
-    monkeypatch.setattr(bench.time, "time", iter([0.0] + [1000.0] * 10).__next__)  # the 120-s grace period is over at once
-    rc, procs = _launch(3, hang=2)
-    assert procs[2].killed and rc == 9
+    # rank 1 dies at once (no device), rank 0 and rank 2 wait for it in the rendezvous forever: killed after the grace period
+    rc, procs = _launch(3, rcs={1: 3}, hang=0, grace=0.2)
+    assert procs[0].killed and not procs[1].killed and rc == 9
+    rc, procs = _launch(2, hang=1, rcs={0: 5}, grace=0.2)
+    assert procs[1].killed and rc == 9
 
 
 def test_launcher_refuses_more_ranks_than_gpus_and_never_calls_hip(monkeypatch, capsys):
@@ -101,3 +113,23 @@ def test_visible_gpus_reads_the_kfd_topology(tmp_path, monkeypatch):
     assert bench.visible_gpus() == 3
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
     assert bench.visible_gpus() == 2
+
+
+def test_visible_gpus_asks_a_child_process_where_sysfs_is_not_readable(monkeypatch):
+    """Containers without /sys/class/kfd: a throw-away child counts the devices (it may initialise the runtime; the parent does not)."""
+    real_listdir = os.listdir
+    root = "/sys/class/kfd/kfd/topology/nodes"
+
+    def listdir(p):
+        if p == root:
+            raise FileNotFoundError(p)
+        return real_listdir(p)
+    monkeypatch.setattr(bench.os, "listdir", listdir)
+    calls = []
+
+    def run(argv, **kw):
+        calls.append(argv)
+        return subprocess.CompletedProcess(argv, 0, stdout="some banner\n4\n", stderr="")
+    assert bench.visible_gpus(run=run) == 4
+    assert calls and calls[0][0] == sys.executable and "device_count" in calls[0][2]
+    assert bench.visible_gpus(run=lambda argv, **kw: subprocess.CompletedProcess(argv, 1, stdout="", stderr="boom")) is None
