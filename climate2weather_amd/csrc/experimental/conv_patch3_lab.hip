@@ -58,6 +58,10 @@
 #ifndef C2W_T3_STAGGER
 #define C2W_T3_STAGGER 0  // x 8128 cycles: start delay of the second workgroup of every CU (see the kernel entry)
 #endif
+#ifndef C2W_T3_EPIPRIO
+#define C2W_T3_EPIPRIO 0  // s_setprio N from the end of the MFMA loop on: the epilogue's VALU work competes with the CU's other workgroup's MFMAs for
+                          // the SIMD's issue slots (stamps: 3 us to stage 64 accumulators); a higher priority shortens the epilogue
+#endif
 #ifndef C2W_T3_BIASLDS
 #define C2W_T3_BIASLDS 0  // 1: the tile's 128 bias values are fetched by one LDS-DMA piece at kernel start (wave 0) into 1 KiB behind the loop's LDS
                           // and read from there after the loop -- no dependent global load at the head of the epilogue
@@ -583,6 +587,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         t3_epi_direct<T, 0, NB>(p, acc, tile_off, wn * 4 * NB, W, co0, co_l, lane_d & 15);
         return;
     }
+    if constexpr ((C2W_T3_EPIPRIO) != 0) __builtin_amdgcn_s_setprio(C2W_T3_EPIPRIO);
     // epilogue: the residual / multiplier rows are fetched AFTER the accumulators have left the registers (the half-tile
     // kernel prefetches them next to live accumulators; that does not fit here) -- the co-resident workgroups cover the
     // exposed latency.  Output rows go through LDS in blocks of 128 (= 8 tile rows), one EpiStore pass each.
