@@ -26,12 +26,17 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(uint16_t, b);
 }
+// Two fp32 -> one dword of two 16-bit values, ONE instruction each (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: RNE, NaN stays NaN, fp16
+// overflow -> inf).  Written as a 2-vector conversion: converted one at a time and or-ed together, hipcc emitted a v_cvt_pk per VALUE
+// plus a shift and an or per pair -- 16 instructions per 8 outputs instead of 4, in every epilogue (round 3, `hipcc -S`).
+typedef __attribute__((ext_vector_type(2))) float c2w_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 c2w_bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((c2w_f32x2_t){lo, hi}, c2w_bf16x2_t));
 }
 
-__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {  // RNE each (v_cvt_f16_f32), overflow -> inf
-    return __builtin_bit_cast(uint32_t, (f16x2_t){(_Float16)lo, (_Float16)hi});
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((c2w_f32x2_t){lo, hi}, f16x2_t));
 }
 // two 16-bit storage values in one dword <-> fp32
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
