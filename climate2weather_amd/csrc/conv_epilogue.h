@@ -80,6 +80,16 @@ struct EpiStore {
     static constexpr bool EARLY = NIT <= 8;  // bf16: 8 segments per thread fit in registers next to the accumulators
     long long off[NIT];
     u32x4_t rr[EARLY ? NIT : 1], mm[EARLY ? NIT : 1];
+    // tiles that lie inside one image (prefetch_tile16*): only the channel bound can mask a thread, so all of its segments share ONE
+    // validity -- a bool tested once instead of a 64-bit compare + exec-mask branch in front of every store (`hipcc -S`, round 3)
+    bool same_valid = false, valid0 = false;
+    __device__ __forceinline__ bool ok(int i) const { return same_valid ? valid0 : off[i] >= 0; }
+    // LDS address of the thread's i-th segment: row = tid / SEGS + i * (NTHR / SEGS) -- unsigned, so that the i-dependent part is an
+    // immediate offset of the ds_read (the signed seg / SEGS cost eight VALU operations per segment)
+    static __device__ __forceinline__ const char* lds_seg(const char* O, int OS, int tid, int i) {
+        const unsigned r0 = (unsigned)tid / SEGS, cs = (unsigned)tid % SEGS;
+        return O + (r0 + (unsigned)i * (NTHR / SEGS)) * (unsigned)OS + cs * 16u;
+    }
 
     template <typename PixFn>
     __device__ __forceinline__ void prefetch(const C2wConvArgs& p, int tid, int co0, PixFn pix) {
@@ -109,6 +119,8 @@ struct EpiStore {
             const long long d = (long long)((RS * i) >> 4) * W * pitch + (long long)((RS * i) & 15) * pitch;
             off[i] = off0 >= 0 ? off0 + d : -1;
         }
+        same_valid = true;
+        valid0 = off0 >= 0;
         issue_prefetch(p);
     }
 
@@ -126,6 +138,8 @@ struct EpiStore {
             const long long d = (long long)((RS * i) >> 4) * 2 * Wo * pitch + (long long)((RS * i) & 15) * 2 * pitch;
             off[i] = off0 >= 0 ? off0 + d : -1;
         }
+        same_valid = true;
+        valid0 = off0 >= 0;
         issue_prefetch(p);
     }
 
@@ -148,12 +162,12 @@ struct EpiStore {
         if constexpr (EARLY) {
             if (p.res != nullptr) {
 #pragma unroll
-                for (int i = 0; i < NIT; ++i) rr[i] = *(const u32x4_t*)((const char*)p.res + (off[i] >= 0 ? off[i] : 0));
+                for (int i = 0; i < NIT; ++i) rr[i] = *(const u32x4_t*)((const char*)p.res + (ok(i) ? off[i] : 0));
             }
             const void* const mulp = p.ln_x != nullptr ? p.ln_x : p.mul;  // LN mode: the multiplier slot carries the LN input rows
             if (mulp != nullptr) {
 #pragma unroll
-                for (int i = 0; i < NIT; ++i) mm[i] = *(const u32x4_t*)((const char*)mulp + (off[i] >= 0 ? off[i] : 0));
+                for (int i = 0; i < NIT; ++i) mm[i] = *(const u32x4_t*)((const char*)mulp + (ok(i) ? off[i] : 0));
             }
         }
     }
@@ -204,10 +218,8 @@ struct EpiStore {
         };
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int seg = tid + i * NTHR;
-            const int row = seg / SEGS;
             f2 g[4], u[4];
-            unpack2(*(const u32x4_t*)(O + row * OS + cs * 16), g);
+            unpack2(*(const u32x4_t*)lds_seg(O, OS, tid, i), g);
             unpack2(mm[i], u);
             f2 s2 = (f2){0.f, 0.f}, sg2 = (f2){0.f, 0.f};
 #pragma unroll
@@ -245,7 +257,7 @@ struct EpiStore {
             u32x4_t out;
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[k] = pack2<T>(o[k][0], o[k][1]);
-            if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
+            if (ok(i)) epi_st((char*)p.y + off[i], out);
         }
     }
     // column sums -> ln_dm[img]: across the four pixel rows of a wave in registers (lanes l, l+16, l+32, l+48 hold the same channels),
@@ -293,9 +305,7 @@ struct EpiStore {
         };
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int seg = tid + i * NTHR;
-            const int row = seg / SEGS;
-            u32x4_t out = *(const u32x4_t*)(O + row * OS + cs * 16);
+            u32x4_t out = *(const u32x4_t*)lds_seg(O, OS, tid, i);
             f2 u[4];
             if (p.res != nullptr) {
                 f2 r[4];
@@ -307,7 +317,7 @@ struct EpiStore {
                     out[k] = pack2<T>(u[k][0], u[k][1]);
                 }
             }
-            if (off[i] >= 0) epi_st((char*)p.y + off[i], out);
+            if (ok(i)) epi_st((char*)p.y + off[i], out);
             unpack2(out, u);  // the values as stored (bf16), like the separate LN pass would read them
             f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
@@ -326,7 +336,7 @@ struct EpiStore {
             u32x4_t ln;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ln[k] = pack2<T>(u[k][0] * rs, u[k][1] * rs);
-            if (off[i] >= 0) epi_st((char*)p.lnf_y + off[i], ln);
+            if (ok(i)) epi_st((char*)p.lnf_y + off[i], ln);
         }
     }
 
@@ -374,28 +384,26 @@ struct EpiStore {
 
     __device__ __forceinline__ void finish(const C2wConvArgs& p, const char* O, int OS, int tid) {
         constexpr int GRP = NIT < 8 ? NIT : 8;
+        if (same_valid && !valid0) return;  // a thread past the channel bound stores nothing (no cross-lane operation in this flavour)
 #pragma unroll
         for (int g0 = 0; g0 < NIT; g0 += GRP) {
             u32x4_t v[GRP], r2[GRP], m2[GRP];
 #pragma unroll
-            for (int i = 0; i < GRP; ++i) {
-                const int seg = tid + (g0 + i) * NTHR;
-                const int row = seg / SEGS, cs = seg - row * SEGS;
-                v[i] = *(const u32x4_t*)(O + row * OS + cs * 16);
-            }
+            for (int i = 0; i < GRP; ++i) v[i] = *(const u32x4_t*)lds_seg(O, OS, tid, g0 + i);
             if constexpr (!EARLY) {
                 if (p.res != nullptr) {
 #pragma unroll
-                    for (int i = 0; i < GRP; ++i) r2[i] = *(const u32x4_t*)((const char*)p.res + (off[g0 + i] >= 0 ? off[g0 + i] : 0));
+                    for (int i = 0; i < GRP; ++i) r2[i] = *(const u32x4_t*)((const char*)p.res + (ok(g0 + i) ? off[g0 + i] : 0));
                 }
                 if (p.mul != nullptr) {
 #pragma unroll
-                    for (int i = 0; i < GRP; ++i) m2[i] = *(const u32x4_t*)((const char*)p.mul + (off[g0 + i] >= 0 ? off[g0 + i] : 0));
+                    for (int i = 0; i < GRP; ++i) m2[i] = *(const u32x4_t*)((const char*)p.mul + (ok(g0 + i) ? off[g0 + i] : 0));
                 }
             }
 #pragma unroll
             for (int i = 0; i < GRP; ++i) {
                 const long long o = off[g0 + i];
+                const bool st = ok(g0 + i);
                 if (p.mul != nullptr || p.res != nullptr) {
                     float f[PER16];
                     unpack16<T>(v[i], f);
@@ -427,7 +435,7 @@ struct EpiStore {
                         h_[e] = a_[e] * sg;
                         d_[e] = sg + h_[e] * (1.0f - sg);
                     }
-                    if (o >= 0) {
+                    if (st) {
                         epi_st((char*)p.y + o, pack16<T>(h_));
                         epi_st((char*)p.y2 + o, pack16<T>(d_));
                     }
@@ -439,11 +447,11 @@ struct EpiStore {
                         h_[e] = fmaxf(a_[e], 0.f);
                         d_[e] = a_[e] > 0.f ? 1.f : 0.f;
                     }
-                    if (o >= 0) {
+                    if (st) {
                         epi_st((char*)p.y + o, pack16<T>(h_));
                         epi_st((char*)p.y2 + o, pack16<T>(d_));
                     }
-                } else if (o >= 0) {
+                } else if (st) {
                     epi_st((char*)p.y + o, v[i]);
                     if (p.y2 != nullptr) {  // second output: silu of the stored value (training keeps pre-activation and activation)
                         float f2[PER16];
