@@ -779,7 +779,9 @@ def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_
         ref = eps_u.clone()
         mu, sigma = pipe._mu_sigma_f(float(t))
         ops.guidance(x, ref, yobs, std.reshape(Fv).to(dev), yobs.shape[0], Fv, H, H, 16, 6, mu, sigma, gamma)
-        assert torch.equal(eps_c, ref)
+        ne = eps_c != ref
+        assert not bool(ne.any()), (f"{int(ne.sum())} elements differ in frames {ne.flatten(1).any(1).nonzero().flatten().tolist()[:12]}; "
+                                    f"max |d| {(eps_c - ref).abs().nan_to_num(1e30).max().item():.3e}; non-finite {int((~torch.isfinite(eps_c)).sum())}")
         observed = torch.zeros(L, dtype=torch.bool, device=dev)
         observed[::6] = True
         assert torch.equal(eps_c[~observed], eps_u[~observed])
