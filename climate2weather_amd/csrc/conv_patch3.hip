@@ -228,6 +228,15 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         };
         // everything but the next stage's weight piece has landed
         t3_wait<CF::WPIECES>(s + 1 < NS);
+        // ... and every LDS read this wave has issued is in its registers.  The slot read in stage s - 1 is refilled right behind this
+        // barrier (issue_ahead below, by whichever wave gets there first), the patch buffer behind the barrier of a chunk start: a
+        // fragment read still queued in the LDS when its wave arrives here can be overtaken by that refill.  hipcc places the reads'
+        // own lgkmcnt waits at their first use, and it sinks MFMAs below the barrier -- with the packed 16-bit conversions of round 3
+        // it left stage 5's last weight fragment (a[3], first used after the barrier) outstanding across the barrier of stage 6, and
+        // about one forward in 200 under four concurrent streams computed (tap 7, m = 3) with tap 8's weights for one wave
+        // (profiles/r03_experiments.md "weight ring race"; tests/test_kernel_resources.py checks every barrier of every LDS-DMA
+        // kernel in the ISA).  Measured cost of the explicit wait: none (step 48.45 ms either way).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         bool ahead = s + 2 < NS;
         if (IDX == 0 && half == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now

@@ -70,6 +70,11 @@
 #define C2W_EXP 0  // diagnostic timing builds only (results are wrong): 1 no MFMA, 2 no LDS fragment reads, 4 no weight LDS-DMA, 8 no stage barrier
 #endif             // in the loop, 32 no epilogue (accumulators reduced to one store per lane)
 
+#if (C2W_T3_BIASLDS) == 2
+__device__ unsigned int c2w_bias_dbg[16];  // [0] mismatching lanes, [1] lanes that read exactly 0 where the bias is not 0, [2..] a sample
+extern "C" int c2w_bias_dbg_read(unsigned int* host16) { return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(c2w_bias_dbg), 64); }
+extern "C" int c2w_bias_dbg_clear() { unsigned int z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(c2w_bias_dbg), z, 64); }
+#endif
 namespace {
 
 #ifndef C2W_T3_NW
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         // everything but the next stage's (stages') weight pieces has landed
         if constexpr (RING == 3) t3_wait<CF::WPIECES>(s + 1 < NS);
         else t3_wait_n<CF::WPIECES>(NS - 1 - s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no fragment read crosses the barrier the ring is refilled behind (see the product kernel)
         if constexpr ((C2W_EXP & 8) == 0) __builtin_amdgcn_s_barrier();
         bool ahead = s + DIST < NS;
         if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
@@ -601,6 +607,27 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
             const f32x4_t t = *(const f32x4_t*)(smem + CF::LDS_BIAS + (wm * 64 + m * 16 + lg_e * 4) * 4);
             bv[m][0] = t[0]; bv[m][1] = t[1]; bv[m][2] = t[2]; bv[m][3] = t[3];
         }
+#if (C2W_T3_BIASLDS) == 2
+        {   // detector: the same values by the global path; count what the LDS copy got wrong, then use the global ones
+            float bg[4][4];
+            epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bg);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (__float_as_uint(bg[m][r]) != __float_as_uint(bv[m][r])) {
+                        atomicAdd(&c2w_bias_dbg[0], 1u);
+                        if (bv[m][r] == 0.f) atomicAdd(&c2w_bias_dbg[1], 1u);
+                        c2w_bias_dbg[2] = __float_as_uint(bv[m][r]);
+                        c2w_bias_dbg[3] = __float_as_uint(bg[m][r]);
+                        c2w_bias_dbg[4] = blockIdx.x;
+                        c2w_bias_dbg[5] = (unsigned)tid_e;
+                        c2w_bias_dbg[6] = gridDim.x;
+                    }
+                    bv[m][r] = bg[m][r];
+                }
+        }
+#endif
     } else if constexpr (TR == 8 || (C2W_T3V & 8) != 0) epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bv);
     __syncthreads();
     T3_STAMP(4);

@@ -198,6 +198,7 @@ class Engine:
         # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
+        self.debug_trace: Optional[list] = None  # diagnostics: a list collects (name, output tensor[, operands of a conv]) of every conv / attention launch of a forward
         self.attach(net)
 
     # ------------------------------------------------------------------ parameter storage
@@ -534,6 +535,10 @@ class Engine:
             # 16x16-tile kernel turns into fewer K steps
             ops.conv(xin, self._w(rec, dt), self._b(rec), y, g, dt, act=act, res=res, y2=y2, lnf=lnf,
                      kvalid=rec.cin if rec.kstride != rec.cin else 0)
+            if self.debug_trace is not None:
+                self.debug_trace.append((name, y, dict(x=xin, w=self._w(rec, dt), g=g, act=act, res=res)))
+                if hn is not None:
+                    self.debug_trace.append((name + " [LayerNorm emitted]", hn))
             if want_ln is not None:
                 return y, g, rec, hn
             return y, g, rec
@@ -604,6 +609,8 @@ class Engine:
             o = torch.empty((npix, Cc), dtype=T, device=dev)
             lse = torch.empty((npix,), dtype=torch.float32, device=dev) if train else None
             ops.attention_forward(qkv, o, lse, B, Tn, Cc, dt)
+            if self.debug_trace is not None:
+                self.debug_trace += [(p + " qkv", qkv), (p + " attention", o)]
             out = torch.empty((npix, Cc), dtype=T, device=dev)
             gp = self._geom(npix, 1, 1, Cc, 1, 1, Cc, Cc, Cc, CONV_1X1)
             ops.conv(o, self._w(rp, dt), self._b(rp), out, gp, dt, res=xin)

@@ -6,6 +6,7 @@ import os
 import re
 import shutil
 import subprocess
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 import pytest
@@ -13,15 +14,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "climate2weather_amd", "csrc")
 FILES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch3.hip", "wgrad.hip", "wgrad_patch.hip"]
+_CACHE = {}
+
+
+def _compile(src):
+    """(resource-usage remarks, device assembly) of one translation unit, compiled once per session."""
+    if src not in _CACHE:
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        with tempfile.TemporaryDirectory() as tmp:
+            asm = os.path.join(tmp, src + ".s")
+            out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                                  "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", asm, "-Rpass-analysis=kernel-resource-usage"],
+                                 capture_output=True, text=True, timeout=900)
+            assert out.returncode == 0, out.stderr[-2000:]
+            _CACHE[src] = (out.stderr, open(asm).read())
+    return _CACHE[src]
 
 
 def _remarks(src):
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                          "--cuda-device-only", "-c", os.path.join(CSRC, src), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
-                         capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    return out.stderr
+    return _compile(src)[0]
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
@@ -37,3 +48,57 @@ def test_counted_vmcnt_kernels_do_not_spill():
             seen += 1
             assert scratch == 0 and spill == 0, f"{src}: {name} uses scratch ({scratch} B/lane, {spill} spilled VGPRs)"
     assert seen >= 10  # every template instantiation was looked at
+
+
+def lds_reads_outstanding_at_barriers(asm: str):
+    """[(kernel, line, [reads])] for every s_barrier of every kernel that issues LDS-DMA at which LDS reads are still outstanding
+    (the wave's LDS queue is followed in layout order: ds_* and s_load push, `s_waitcnt lgkmcnt(N)` retires all but the N youngest)."""
+    lines = asm.splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w*:", l)] + [len(lines)]
+    found, kernels, barriers = [], 0, 0
+    for k in range(len(starts) - 1):
+        name = lines[starts[k]].split(":")[0]
+        body = [l.split(";")[0].strip() for l in lines[starts[k]:starts[k + 1]]]
+        if not any(re.match(r"(buffer_load|global_load_lds).*\blds\b|global_load_lds", l) for l in body):
+            continue
+        kernels += 1
+        q = []
+        for i, l in enumerate(body):
+            if re.match(r"ds_(read|load)", l):
+                q.append(l)
+            elif l.startswith(("ds_", "s_load", "s_buffer_load")):
+                q.append("")  # counts on lgkmcnt, not a read of staged data
+            elif l.startswith("s_waitcnt"):
+                m = re.search(r"lgkmcnt\((\d+)\)", l)
+                if m:
+                    q = q[len(q) - int(m.group(1)):] if int(m.group(1)) else []
+            elif l.startswith("s_barrier"):
+                barriers += 1
+                if any(q):
+                    found.append((name, i, [x for x in q if x]))
+    return found, kernels, barriers
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_no_lds_read_is_outstanding_at_a_barrier_of_an_lds_dma_kernel():
+    """The LDS-DMA rings refill a slot right behind the barrier that follows its last read.  A fragment read that is still queued when
+    its wave arrives at that barrier can be overtaken by the refill: round 3 saw conv_patch_t3 compute one wave's (tap 7, m = 3) with
+    tap 8's weights about once in 200 forwards under four streams, because hipcc had left that ds_read_b128 outstanding across the
+    barrier (first use sunk below it).  Where the waits go is the compiler's choice and changes with unrelated edits, so the shipped ISA
+    is checked: in every kernel that issues LDS-DMA, every s_barrier is reached with no LDS read outstanding."""
+    with ThreadPoolExecutor(max_workers=len(FILES)) as ex:
+        asms = [a for _, a in ex.map(_compile, FILES)]
+    kernels = barriers = 0
+    for src, asm in zip(FILES, asms):
+        found, k, b = lds_reads_outstanding_at_barriers(asm)
+        kernels += k
+        barriers += b
+        assert not found, f"{src}: LDS reads outstanding at a barrier: " + "; ".join(f"{n[-48:]} line {i}: {r}" for n, i, r in found[:4])
+    assert kernels >= 40 and barriers >= 300  # every LDS-DMA kernel instantiation was looked at
+
+
+def test_the_barrier_checker_sees_an_outstanding_read():
+    asm = "\n".join(["_Zk:", " buffer_load_dwordx4 v1, s[0:3], 0 offen lds", " ds_read_b128 v[2:5], v9", " ds_read_b128 v[6:9], v9 offset:16",
+                     " s_waitcnt lgkmcnt(1)", " s_barrier", " s_waitcnt lgkmcnt(0)", " s_barrier", "_Zplain:", " ds_read_b32 v1, v2", " s_barrier"])
+    found, kernels, barriers = lds_reads_outstanding_at_barriers(asm)
+    assert kernels == 1 and barriers == 2 and len(found) == 1 and found[0][2] == ["ds_read_b128 v[6:9], v9 offset:16"]
