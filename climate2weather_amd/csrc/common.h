@@ -30,9 +30,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 // overflow -> inf).  Written as a 2-vector conversion: converted one at a time and or-ed together, hipcc emitted a v_cvt_pk per VALUE
 // plus a shift and an or per pair -- 16 instructions per 8 outputs instead of 4, in every epilogue (round 3, `hipcc -S`).
 typedef __attribute__((ext_vector_type(2))) float c2w_f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 c2w_bf16x2_t;
+// The bf16 form is issued from a volatile asm statement: same instruction, but hipcc then keeps the conversions where the epilogues
+// wrote them (between the activation arithmetic of neighbouring values) instead of clustering them in front of the LDS writes.  Same-box
+// A/B on the fixed kernel, three rounds: SiLU epilogues of the dominant conv 547 -> 525 and 591 -> 572 us, step 48.48 -> 48.12 ms
+// (profiles/r03_experiments.md section 5); with an s_nop behind it, or as a non-volatile asm, 0.1-0.2 ms of that are lost again.
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector((c2w_f32x2_t){lo, hi}, c2w_bf16x2_t));
+    uint32_t d;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+    return d;
 }
 
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
