@@ -212,6 +212,9 @@ __global__ __launch_bounds__(GCfg<NW>::NTHREADS, 2) void conv_igemm_kernel(const
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // no fragment read may still be queued in the LDS when its wave arrives here: the slot it reads is refilled right behind the
+        // barrier (conv_patch3.hip tells how that went wrong once; today's schedule has nothing outstanding here, the wait pins it)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage s landed for every wave; every wave is done reading slot (s+2)%3 (= stage s-1)
         if (s + 2 < NS) issue(s + 2, slot >= 1 ? slot - 1 : NSLOT - 1);
         const char* const Pb = Pbuf + slot * PBYTES;
