@@ -49,7 +49,7 @@ def explain_stages(info, y2, r2, rows, cols, B):
 ROUNDS, NS = int(os.environ.get("ROUNDS", "40")), int(os.environ.get("NSTREAMS", "4"))
 torch.manual_seed(0)
 net = ScoreUNet(channels=52, spatial=2, activation=torch.nn.SiLU, **CFG).to(dev).eval()
-net.precision = "bf16"
+net.precision = os.environ.get("PRECISION", "bf16")
 eng = net._get_engine()
 x = torch.randn(128, 52, 128, 128, device=dev)
 t = torch.tensor(0.7, device=dev)
