@@ -1,6 +1,8 @@
 // Matrix-core version of the bottleneck attention (model/nn.py:62-85) for the shape the default network runs:
-// bf16, T = 64 tokens (8x8 pixels), one head of width C (a multiple of 32, <= 512).  One workgroup (4 waves) per image;
-// wave w owns the 16-row strip w of every 64-row matrix.  All five products are v_mfma_f32_16x16x32_bf16:
+// bf16, T = 64 tokens (8x8 pixels), one head of width C (a multiple of 32, <= 512).  One workgroup of EIGHT waves per image (B = 128
+// images fill half the chip's CUs, so the waves of an image are what there is to spread the work over): wave w works on the 16-row
+// strip w & 3 of every 64-row matrix; the two waves of a strip split the K range of S (forward), take S and dP (backward), and each
+// take half of the column tiles of every output strip.  All five products are v_mfma_f32_16x16x32_bf16:
 //
 //   forward :  S = q k^T (K-dim C: both operands are K-contiguous in HBM -> fragments by 16-B global loads, no LDS),
 //              P = softmax(S * s^2) in fp32 (s = C^-1/4 on q and on k, model/nn.py:76-83), rounded to bf16 like the
@@ -55,33 +57,51 @@ __device__ __forceinline__ float row16_max(float v) {
 // rows [0,64) x C bf16 of a [.][ld] matrix -> LDS [64][pitch]
 __device__ __forceinline__ void stage_rows(char* dst, int pitch, const bf16_t* src, int ld, int C) {
     const int nch = C >> 3;
-    for (int i = threadIdx.x; i < T64 * nch; i += 256) {
+    for (int i = threadIdx.x; i < T64 * nch; i += blockDim.x) {
         const int r = i / nch, c = i - r * nch;
         *(u32x4_t*)(dst + r * pitch + c * 16) = *(const u32x4_t*)(src + (size_t)r * ld + c * 8);
     }
 }
 
-// acc[n] (+)= A-strip(16 rows of `a`, starting at row w*16) . B^T, both K-contiguous in HBM: the 16 x 64 strip of a b^T
+// acc[n] (+)= A-strip(16 rows of `a`, starting at row w*16) . B^T over the K steps [ks0, ks1) of 32, both K-contiguous in HBM (row pitches
+// lda / ldb): the 16 x 64 strip of a b^T
 template <typename T>
-__device__ __forceinline__ void strip_abt(f32x4_t (&acc)[4], const bf16_t* a, const bf16_t* b, int ld, int C, int w, int li, int lg) {
-    const bf16_t* ar = a + (size_t)(16 * w + li) * ld + 8 * lg;
-    const bf16_t* br = b + (size_t)li * ld + 8 * lg;
+__device__ __forceinline__ void strip_abt(f32x4_t (&acc)[4], const bf16_t* a, int lda, const bf16_t* b, int ldb, int ks0, int ks1, int w, int li,
+                                          int lg) {
+    const bf16_t* ar = a + (size_t)(16 * w + li) * lda + 8 * lg;
+    const bf16_t* br = b + (size_t)li * ldb + 8 * lg;
 #pragma unroll 4
-    for (int ks = 0; ks < C / 32; ++ks) {
+    for (int ks = ks0; ks < ks1; ++ks) {
         const bf16x8_t av = *(const bf16x8_t*)(ar + 32 * ks);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ld + 32 * ks);
+            const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ldb + 32 * ks);
             acc[n] = mfma16s<T>(av, bv, acc[n]);
         }
     }
 }
 
-// out strip (16 rows starting at 16 w) = A . M, K-dim 64:  A fragments a[ks] given, M[64][C] in LDS (pitch), all C/16 column tiles
+// a wave's 16 x 64 fp32 accumulator strip <-> its 4 KiB of the exchange area X (element [4 lg + r][16 n + li])
+__device__ __forceinline__ void strip_to_lds(char* X, int w, const f32x4_t (&acc)[4], int li, int lg) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(float*)(X + w * 4096 + ((4 * lg + r) * 64 + 16 * n + li) * 4) = acc[n][r];
+}
+__device__ __forceinline__ void strip_from_lds(const char* X, int w, f32x4_t (&acc)[4], int li, int lg) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] = *(const float*)(X + w * 4096 + ((4 * lg + r) * 64 + 16 * n + li) * 4);
+}
+
+// out strip (16 rows starting at 16 w) = A . M, K-dim 64:  A fragments a[ks] given, M[64][C] in LDS (pitch), column tiles [ct0, ct1)
 template <typename T>
-__device__ __forceinline__ void strip_times_lds(bf16_t* out, int ldo, const bf16x8_t (&a)[2], const char* M, int pitch, int C, int w, int li,
-                                                int lg) {
-    for (int ct = 0; ct < C / 16; ++ct) {
+__device__ __forceinline__ void strip_times_lds(bf16_t* out, int ldo, const bf16x8_t (&a)[2], const char* M, int pitch, int ct0, int ct1, int w,
+                                                int li, int lg) {
+    // (computed transposed -- M's fragment as the row operand, one 8-byte store per lane instead of four 2-byte ones -- it measured
+    // SLOWER: backward 38.3 -> 42.2 us, forward 18.3 -> 19.3; and such stores must convert with pack_acc2, see common.h)
+    for (int ct = ct0; ct < ct1; ++ct) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) acc = mfma16s<T>(a[ks], tr_frag(M, pitch, 32 * ks, 16 * ct, li, lg), acc);
@@ -90,52 +110,63 @@ __device__ __forceinline__ void strip_times_lds(bf16_t* out, int ldo, const bf16
     }
 }
 
+constexpr int NTA = 512;  // threads of the T = 64 kernels
+
 template <typename T>  // T = bf16_t or f16_t: the operand format tag (pointers carry raw 16-bit patterns)
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+__global__ __launch_bounds__(NTA) void attn_mfma_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                             int C, float scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VP = C * 2 + 16;
     char* const Vl = smem;
     char* const Pl = smem + T64 * VP;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
+    char* const X = Pl + T64 * PP;  // 4 x 4 KiB: the upper-K partial sums of S on their way to the strip's other wave
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, half = w8 >> 2, li = lane & 15, lg = lane >> 4;
     const int ld = 3 * C;
     const bf16_t* base = qkv + (size_t)blockIdx.x * T64 * ld;
     stage_rows(Vl, VP, base + 2 * C, ld, C);
 
     f32x4_t s[4] = {};
-    strip_abt<T>(s, base, base + C, ld, C, w, li, lg);
-    // accumulator element s[n][r] = S[16 w + 4 lg + r][16 n + li]
+    const int nks = C / 32, ksm = nks / 2;
+    strip_abt<T>(s, base, ld, base + C, ld, half ? ksm : 0, half ? nks : ksm, w, li, lg);
+    if (half) strip_to_lds(X, w, s, li, lg);
+    __syncthreads();
+    if (!half) {
+        f32x4_t s1[4];
+        strip_from_lds(X, w, s1, li, lg);
+        // accumulator element s[n][r] = S[16 w + 4 lg + r][16 n + li]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float m = -INFINITY;
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            s[n][r] *= scale2;
-            m = fmaxf(m, s[n][r]);
+            for (int n = 0; n < 4; ++n) {
+                s[n][r] = (s[n][r] + s1[n][r]) * scale2;
+                m = fmaxf(m, s[n][r]);
+            }
+            m = row16_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                s[n][r] = __expf(s[n][r] - m);
+                sum += s[n][r];
+            }
+            sum = row16_sum(sum);
+            const float inv = 1.0f / sum;
+            const int row = 16 * w + 4 * lg + r;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r] * inv);
+            if (lse != nullptr && li == 0) lse[(size_t)blockIdx.x * T64 + row] = m + __logf(sum);
         }
-        m = row16_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            s[n][r] = __expf(s[n][r] - m);
-            sum += s[n][r];
-        }
-        sum = row16_sum(sum);
-        const float inv = 1.0f / sum;
-        const int row = 16 * w + 4 * lg + r;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r] * inv);
-        if (lse != nullptr && li == 0) lse[(size_t)blockIdx.x * T64 + row] = m + __logf(sum);
     }
     __syncthreads();
     bf16x8_t pa[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) pa[ks] = *(const bf16x8_t*)(Pl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
-    strip_times_lds<T>(o + (size_t)blockIdx.x * T64 * C, C, pa, Vl, VP, C, w, li, lg);
+    const int nct = C / 16, ctm = nct / 2;
+    strip_times_lds<T>(o + (size_t)blockIdx.x * T64 * C, C, pa, Vl, VP, half ? ctm : 0, half ? nct : ctm, w, li, lg);
 }
 
 template <typename T>  // T = bf16_t or f16_t: the operand format tag (pointers carry raw 16-bit patterns)
-__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(NTA) void attn_mfma_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int C, float scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VP = C * 2 + 16;
@@ -143,7 +174,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
     char* const B1 = smem + T64 * VP;      // dO
     char* const Pl = smem + 2 * T64 * VP;  // P  [q][key]
     char* const Sl = Pl + T64 * PP;        // dS [q][key] (already times s^2)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
+    char* const X = Pl;                    // 4 x 4 KiB over P and dS (2 x 9 KiB), before they exist: dP on its way to the strip's other wave
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, half = w8 >> 2, li = lane & 15, lg = lane >> 4;
     const int ld = 3 * C;
     const bf16_t* base = qkv + (size_t)blockIdx.x * T64 * ld;
     const bf16_t* dob = d_o + (size_t)blockIdx.x * T64 * C;
@@ -151,56 +183,52 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const bf16_t* __rest
     stage_rows(B0, VP, base + C, ld, C);
     stage_rows(B1, VP, dob, C, C);
 
-    f32x4_t s[4] = {}, dp[4] = {};
-    strip_abt<T>(s, base, base + C, ld, C, w, li, lg);  // q k^T
-    {   // dO v^T: dO rows have pitch C, v rows pitch 3C -> two pointers, same loop shape as strip_abt
-        const bf16_t* ar = dob + (size_t)(16 * w + li) * C + 8 * lg;
-        const bf16_t* br = base + 2 * C + (size_t)li * ld + 8 * lg;
-#pragma unroll 4
-        for (int ks = 0; ks < C / 32; ++ks) {
-            const bf16x8_t av = *(const bf16x8_t*)(ar + 32 * ks);
+    // waves 0-3: S = q k^T; waves 4-7: dP = dO v^T (dO rows have pitch C, v rows pitch 3C) -- the same strip, side by side
+    f32x4_t s[4] = {}, dp[4];
+    if (!half) strip_abt<T>(s, base, ld, base + C, ld, 0, C / 32, w, li, lg);
+    else strip_abt<T>(s, dob, C, base + 2 * C, ld, 0, C / 32, w, li, lg);
+    if (half) strip_to_lds(X, w, s, li, lg);
+    __syncthreads();
+    if (!half) strip_from_lds(X, w, dp, li, lg);
+    __syncthreads();  // X is read: P and dS may take its place
+    if (!half) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + 4 * lg + r;
+            const float l = lse[(size_t)blockIdx.x * T64 + row];
+            float delta = 0.f;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const bf16x8_t bv = *(const bf16x8_t*)(br + (size_t)(16 * n) * ld + 32 * ks);
-                dp[n] = mfma16s<T>(av, bv, dp[n]);
+                s[n][r] = __expf(s[n][r] * scale2 - l);  // P
+                delta += s[n][r] * dp[n][r];
+            }
+            delta = row16_sum(delta);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float ds = s[n][r] * (dp[n][r] - delta) * scale2;
+                *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r]);
+                *(bf16_t*)(Sl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(ds);
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * w + 4 * lg + r;
-        const float l = lse[(size_t)blockIdx.x * T64 + row];
-        float delta = 0.f;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            s[n][r] = __expf(s[n][r] * scale2 - l);  // P
-            delta += s[n][r] * dp[n][r];
-        }
-        delta = row16_sum(delta);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const float ds = s[n][r] * (dp[n][r] - delta) * scale2;
-            *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(s[n][r]);
-            *(bf16_t*)(Sl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(ds);
-        }
-    }
     __syncthreads();
+    const int nct = C / 16, ctm = nct / 2, ct0 = half ? ctm : 0, ct1 = half ? nct : ctm;
     bf16x8_t a[2];
     // dq strip (query rows): dS . k
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a[ks] = *(const bf16x8_t*)(Sl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
-    strip_times_lds<T>(dbase, ld, a, B0, VP, C, w, li, lg);
+    strip_times_lds<T>(dbase, ld, a, B0, VP, ct0, ct1, w, li, lg);
     // dv strip (key rows): P^T . dO  -- A[m = key][k = query] = P[query][key]: transposing read of the P tile
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Pl, PP, 32 * ks, 16 * w, li, lg);
-    strip_times_lds<T>(dbase + 2 * C, ld, a, B1, VP, C, w, li, lg);
+    strip_times_lds<T>(dbase + 2 * C, ld, a, B1, VP, ct0, ct1, w, li, lg);
     __syncthreads();  // every wave is done with k before q replaces it
     stage_rows(B0, VP, base, ld, C);
     __syncthreads();
     // dk strip (key rows): dS^T . q
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Sl, PP, 32 * ks, 16 * w, li, lg);
-    strip_times_lds<T>(dbase + C, ld, a, B0, VP, C, w, li, lg);
+    strip_times_lds<T>(dbase + C, ld, a, B0, VP, ct0, ct1, w, li, lg);
 }
 
 // ---- forward for T = 64 * nb tokens (the 256^2 variant attends over 16 x 16 = 256): one workgroup per (image, block of 64
@@ -301,13 +329,13 @@ bool c2w_attention_mfma_eligible(int B, int Tn, int C, int dtype) {
 namespace {
 template <typename T>
 int fwd_launch(const void* qkv, void* o, float* lse, int B, int C, hipStream_t st) {
-    const int lds = T64 * (C * 2 + 16) + T64 * PP;
+    const int lds = T64 * (C * 2 + 16) + T64 * PP + 4 * 4096;
     static bool attr = false;
     if (!attr) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    attn_mfma_fwd_kernel<T><<<B, 256, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, C, 1.0f / sqrtf((float)C));
+    attn_mfma_fwd_kernel<T><<<B, NTA, lds, st>>>((const bf16_t*)qkv, (bf16_t*)o, lse, C, 1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
 template <typename T>
@@ -318,7 +346,7 @@ int bwd_launch(const void* qkv, const void* d_o, const float* lse, void* dqkv, i
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    attn_mfma_bwd_kernel<T><<<B, 256, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, (bf16_t*)dqkv, C, 1.0f / sqrtf((float)C));
+    attn_mfma_bwd_kernel<T><<<B, NTA, lds, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, (bf16_t*)dqkv, C, 1.0f / sqrtf((float)C));
     return (int)hipGetLastError();
 }
 template <typename T>

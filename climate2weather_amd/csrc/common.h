@@ -30,6 +30,7 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 // overflow -> inf).  Written as a 2-vector conversion: converted one at a time and or-ed together, hipcc emitted a v_cvt_pk per VALUE
 // plus a shift and an or per pair -- 16 instructions per 8 outputs instead of 4, in every epilogue (round 3, `hipcc -S`).
 typedef __attribute__((ext_vector_type(2))) float c2w_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 c2w_bf16x2_t;
 // The bf16 form is issued from a volatile asm statement: same instruction, but hipcc then keeps the conversions where the epilogues
 // wrote them (between the activation arithmetic of neighbouring values) instead of clustering them in front of the LDS writes.  Same-box
 // A/B on the fixed kernel, three rounds: SiLU epilogues of the dominant conv 547 -> 525 and 591 -> 572 us, step 48.48 -> 48.12 ms
@@ -40,6 +41,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return d;
 }
 
+// NOT for values that come straight out of the matrix core: hipcc's hazard recognizer does not look into an asm statement, so the wait
+// states between an MFMA and the first read of its result are missing and the conversion reads the registers too early (seen: NaNs in
+// the attention output product).  Such values go through pack_acc2 (the compiler's own conversion, hazards handled);
+// tests/test_kernel_resources.py looks for an MFMA result feeding an asm conversion in the ISA of every kernel.
+__device__ __forceinline__ uint32_t pack_bf16x2_plain(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((c2w_f32x2_t){lo, hi}, c2w_bf16x2_t));
+}
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((c2w_f32x2_t){lo, hi}, f16x2_t));
 }
@@ -47,6 +55,10 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+// two accumulator values (straight from an MFMA) -> one dword of two 16-bit values
+template <typename T> __device__ __forceinline__ uint32_t pack_acc2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack_acc2<bf16_t>(float lo, float hi) { return pack_bf16x2_plain(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack_acc2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
 template <typename T> __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi);
 template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t v, float& lo, float& hi) {
     lo = __uint_as_float(v << 16);

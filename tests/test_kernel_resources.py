@@ -14,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "climate2weather_amd", "csrc")
 FILES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch3.hip", "wgrad.hip", "wgrad_patch.hip"]
+ALL_FILES = FILES + ["pointwise.hip", "attention.hip", "attention_mfma.hip", "sampler.hip"]
 _CACHE = {}
 
 
@@ -102,3 +103,56 @@ def test_the_barrier_checker_sees_an_outstanding_read():
                      " s_waitcnt lgkmcnt(1)", " s_barrier", " s_waitcnt lgkmcnt(0)", " s_barrier", "_Zplain:", " ds_read_b32 v1, v2", " s_barrier"])
     found, kernels, barriers = lds_reads_outstanding_at_barriers(asm)
     assert kernels == 1 and barriers == 2 and len(found) == 1 and found[0][2] == ["ds_read_b128 v[6:9], v9 offset:16"]
+
+
+def asm_conversions_fed_by_mfma(asm: str, lookback: int = 24):
+    """[(line, conversion, mfma)]: a v_cvt_pk_* inside an inline-asm block (;;#ASMSTART ... ;;#ASMEND) one of whose source registers
+    is the destination of a v_mfma among the `lookback` instructions in front of it.  The compiler pads MFMA -> VALU reads of its own
+    instructions with wait states; it does not look into asm statements."""
+    ins, in_asm = [], False
+    for ln, raw in enumerate(asm.splitlines()):
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        t = t.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        ins.append((ln, t, in_asm))
+    found, seen = [], 0
+    for i, (ln, t, in_asm) in enumerate(ins):
+        m = re.match(r"v_cvt_pk_\w+ v(\d+), v(\d+), v(\d+)", t)
+        if not (in_asm and m):
+            continue
+        seen += 1
+        srcs = {int(m.group(2)), int(m.group(3))}
+        for ln2, t2, _ in ins[max(0, i - lookback):i]:
+            m2 = re.match(r"v_mfma\w+ v\[(\d+):(\d+)\]", t2)
+            if m2 and any(int(m2.group(1)) <= r <= int(m2.group(2)) for r in srcs):
+                found.append((ln, t, t2))
+    return found, seen
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_no_asm_conversion_reads_a_fresh_mfma_result():
+    """common.h: pack_bf16x2 is an asm statement (kept where the epilogues wrote it: 0.7 % of the step); the hazard recognizer does not
+    pad an MFMA result read by asm, so accumulator values must go through pack_acc2.  Seen once: NaNs out of the attention kernels."""
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        asms = [a for _, a in ex.map(_compile, ALL_FILES)]
+    seen = 0
+    for src, asm in zip(ALL_FILES, asms):
+        found, n = asm_conversions_fed_by_mfma(asm)
+        seen += n
+        assert not found, f"{src}: asm conversion reads an MFMA result: {found[:3]}"
+    assert seen >= 100
+
+
+def test_the_mfma_hazard_checker_sees_one():
+    asm = "\n".join(["k:", " v_mfma_f32_16x16x32_bf16 v[4:7], v[0:3], v[8:11], 0", " v_add_f32 v20, v21, v22", " ;;#ASMSTART",
+                     " v_cvt_pk_bf16_f32 v30, v5, v20", " ;;#ASMEND", " v_mfma_f32_16x16x32_bf16 v[12:15], v[0:3], v[8:11], 0",
+                     " v_cvt_pk_bf16_f32 v31, v12, v13"])
+    found, seen = asm_conversions_fed_by_mfma(asm)
+    assert seen == 1 and len(found) == 1 and found[0][1].startswith("v_cvt_pk_bf16_f32 v30")
