@@ -128,10 +128,13 @@ def asm_conversions_fed_by_mfma(asm: str, lookback: int = 24):
         if not (in_asm and m):
             continue
         seen += 1
-        srcs = {int(m.group(2)), int(m.group(3))}
+        # reads of an MFMA's destination (result not written yet) and writes into any of its operand ranges (still being read)
+        dst, srcs = int(m.group(1)), {int(m.group(2)), int(m.group(3))}
         for ln2, t2, _ in ins[max(0, i - lookback):i]:
-            m2 = re.match(r"v_mfma\w+ v\[(\d+):(\d+)\]", t2)
-            if m2 and any(int(m2.group(1)) <= r <= int(m2.group(2)) for r in srcs):
+            if not t2.startswith("v_mfma"):
+                continue
+            rng = [(int(a), int(b)) for a, b in re.findall(r"v\[(\d+):(\d+)\]", t2)]
+            if rng and (any(rng[0][0] <= r <= rng[0][1] for r in srcs) or any(a <= dst <= b for a, b in rng)):
                 found.append((ln, t, t2))
     return found, seen
 
