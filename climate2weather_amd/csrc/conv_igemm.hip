@@ -358,6 +358,7 @@ C2wKnobs read_knobs() {
     k.conv_pair = !off0("C2W_CONV_PAIR");
     k.conv_ts2_patch = !off0("C2W_CONV_TS2_PATCH");
     k.up_patch = getenv("C2W_NO_UP_PATCH") == nullptr;
+    k.wgrad_narrow = getenv("C2W_NO_NARROW") == nullptr;
     k.pool2 = getenv("C2W_NO_POOL2") == nullptr;
     k.ln_fusion = getenv("C2W_NO_LN_FUSION") == nullptr;
     k.lnf = getenv("C2W_NO_LNF") == nullptr;

@@ -96,7 +96,13 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int wm = wid & 1, wn = wid >> 1;
+    // EPI = 5: the elementwise family for at most 80 weight rows (the network's output conv: 65 rows, stored in rows of 128 channels).  The two 64-channel halves go to
+    // waves 0-3 / 4-7 instead of even / odd waves -- every SIMD hosts one of each -- and waves 4-7 (`light`) compute only their first
+    // 16-channel block; the weight pieces of channels 80-127 (waves 5-7) are not fetched: 20 instead of 32 MFMAs per SIMD and stage,
+    // 5 of 8 KiB of weights per stage.
+    constexpr bool NARROW = EPI == 5;
+    const int wm = NARROW ? wid >> 2 : wid & 1, wn = NARROW ? wid & 3 : wid >> 1;
+    const bool light = NARROW && wid >= 4;
 
     const int nN = (p.Cout + 127) / 128;
     int L;
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     };
     auto issue_w = [&](int chunk, int tap, int half, int wslot) {
         const uint32_t so = (uint32_t)(tap * p.Cin + chunk * 64 + half * 32) * ESZ;
+        if (NARROW && wid >= 5) return;  // pieces 5-7 = output channels 80-127: nobody reads them
 #pragma unroll
         for (int i = 0; i < CF::WPIECES; ++i) glds16(rw, smem + CF::PBYTES + wslot * T3_WBYTES + (i * NW + wid) * 1024, wvo_at(i), so);
     };
@@ -217,6 +224,17 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         u32x4_t a[4];
         auto mfmas = [&](auto KHc, auto hook) {
             constexpr int KH_ = decltype(KHc)::value;
+            if constexpr (NARROW) {
+#pragma unroll
+                for (int n = 0; n < 4 * NB; ++n) acc[n >> 2][0][n & 3] = mfma16<T>(a[0], bq[n + KH_], acc[n >> 2][0][n & 3]);
+                if (!light) {  // wave-uniform
+#pragma unroll
+                    for (int n = 0; n < 4 * NB; ++n)
+#pragma unroll
+                        for (int m = 1; m < 4; ++m) acc[n >> 2][m][n & 3] = mfma16<T>(a[m], bq[n + KH_], acc[n >> 2][m][n & 3]);
+                }
+                return;
+            }
 #pragma unroll
             for (int n = 0; n < 4 * NB; ++n) {
                 hook(n);
@@ -254,8 +272,11 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         const uint32_t offA = offA_at() + (uint32_t)(WS * T3_WBYTES);
         const uint32_t offB_kw = offB_at(KW) ^ (uint32_t)(half * 64);
         auto rowp = [&](int row) { return (const u32x4_t*)(smem + offB_kw + row * T3_PW * 128); };
+        a[0] = *(const u32x4_t*)(smem + offA);
+        if (!light) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = *(const u32x4_t*)(smem + offA + m * 1024);
+            for (int m = 1; m < 4; ++m) a[m] = *(const u32x4_t*)(smem + offA + m * 1024);
+        }
         {
             if constexpr (KH == 0) {
 #pragma unroll
@@ -352,6 +373,7 @@ int t3_launch(const C2wConvArgs& a, hipStream_t st) {
     if (TR == 16 && (a.flags & C2W_CONV_POOL2) == 0) {
         if (a.lnf_y != nullptr) return t3_launch_as<16, T, NW, 2>(a, st);
         if (a.ln_x != nullptr) return t3_launch_as<16, T, NW, 3>(a, st);
+        if (a.wrows <= 80 && a.Cout <= 128 && c2w_knobs().wgrad_narrow) return t3_launch_as<16, T, NW, 5>(a, st);  // the output conv: 65 weight rows
         return t3_launch_as<16, T, NW, 4>(a, st);
     }
     return t3_launch_as<TR, T, NW, 0>(a, st);

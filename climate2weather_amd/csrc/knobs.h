@@ -14,6 +14,7 @@ struct C2wKnobs {
     bool lnf;             // C2W_NO_LNF=1         no LayerNorm FORWARD emission only
     bool wgrad_atomics;   // C2W_WGRAD_ATOMICS=1  split-K partial sums by fp32 atomics even when a workspace is handed over
     bool attn_valu;       // C2W_ATTN_VALU=1      attention on the fp32 VALU kernels instead of the matrix-core ones
+    bool wgrad_narrow;    // C2W_NO_NARROW=1      edge convs (<= 80 output channels) NOT on the narrow forms of the halo-patch kernels
 };
 
 const C2wKnobs& c2w_knobs();

@@ -73,7 +73,10 @@ __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 
 
 // PAIR: 8-pixel-wide images (the 8x8 level): a K tile is the same 8 rows of TWO images side by side (tile columns 0..7 = image b,
 // 8..15 = image b + 1), each with its own zero halo -- patch columns 0..9 / 10..19, as in conv_patch_half_kernel<T, PAIR>.
-template <typename T, bool PAIR = false>
+// NARROW (16-bit only): at most 80 output channels (the network's output conv, 65).  The co-tile halves then go to waves 0-3 / 4-7
+// instead of even / odd waves -- every SIMD hosts one wave of each -- and waves 4-7 compute only their first co tile (channels 64-79):
+// 45 instead of 72 MFMAs per SIMD and K step; the dY rows past Cout were never fetched anyway (out-of-range lanes of the LDS-DMA).
+template <typename T, bool PAIR = false, bool NARROW = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p) {
     constexpr int ESZ = sizeof(T);
     constexpr bool BF = ESZ == 2;
@@ -85,8 +88,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int mt0 = BF ? (wid & 1) * 4 : (wid >> 1);  // first co tile of this wave
-    const int nt = BF ? (wid >> 1) : (wid & 1);       // its ci tile
+    static_assert(!NARROW || (BF && !PAIR), "narrow-M form: 16-bit, 16-pixel-wide tiles");
+    const int mt0 = BF ? (NARROW ? (wid >> 2) * 4 : (wid & 1) * 4) : (wid >> 1);  // first co tile of this wave
+    const int nt = BF ? (NARROW ? (wid & 3) : (wid >> 1)) : (wid & 1);             // its ci tile
+    const bool light = NARROW && wid >= 4;                                         // only its first co tile is live
 
     const int ncib = p.Cin / CIB;
     const int tilesM = (p.Cout + COT - 1) / COT;
@@ -302,8 +307,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 }
                 constexpr int PF = 2;  // patch fragments are read PF taps ahead of their MFMAs
                 tr_frag a[MTW], bq[PF + 1];
+                rd(a[0], sA, offA[0][0], offA[0][1], IC<ks * 32 * 256>{});
+                if (!light) {  // wave-uniform (false only in the NARROW form)
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) rd(a[m], sA, offA[m][0], offA[m][1], IC<ks * 32 * 256>{});
+                    for (int m = 1; m < MTW; ++m) rd(a[m], sA, offA[m][0], offA[m][1], IC<ks * 32 * 256>{});
+                }
                 static_for<PF>([&](auto Jc) {
                     constexpr int j = decltype(Jc)::value;
                     rd(bq[j], sP, offB[j][0], offB[j][1], IC<ks * 2 * PPITCH * 128>{});
@@ -317,12 +325,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     const bf16x8_t bfr = bq[tp % (PF + 1)].vec();
+                    acc[tp][0] = mfma16s<T>(a[0].vec(), bfr, acc[tp][0]);
+                    if (!light) {
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) acc[tp][m] = mfma16s<T>(a[m].vec(), bfr, acc[tp][m]);
+                        for (int m = 1; m < MTW; ++m) acc[tp][m] = mfma16s<T>(a[m].vec(), bfr, acc[tp][m]);
+                    }
                     if (tp == 8 && do_bias) {
                         const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
+                        accb[0] = mfma16s<T>(a[0].vec(), ones, accb[0]);
+                        if (!light) {
 #pragma unroll
-                        for (int m = 0; m < MTW; ++m) accb[m] = mfma16s<T>(a[m].vec(), ones, accb[m]);
+                            for (int m = 1; m < MTW; ++m) accb[m] = mfma16s<T>(a[m].vec(), ones, accb[m]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);  // the next reads overwrite fragment registers: not before these MFMAs are issued
                 });
@@ -448,7 +462,7 @@ static size_t ws_need(const C2wConvArgs& a) {
     return nsplit > 1 ? (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float) : 0;
 }
 
-template <typename T, bool PAIR>
+template <typename T, bool PAIR, bool NARROW = false>
 int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
@@ -460,12 +474,12 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
     split_plan<ESZ, PAIR>(a, p.ktiles, tilesMN, nsplit, p.ktiles_per_split);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_kernel<T, PAIR, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
     p.ws = (ws != nullptr && need <= ws_bytes && nsplit > 1 && !c2w_knobs().wgrad_atomics) ? ws : nullptr;
-    wgrad_patch_kernel<T, PAIR><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
+    wgrad_patch_kernel<T, PAIR, NARROW><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
         const int grid = (int)std::min<size_t>((per_split / 4 + C2W_RED_COLS - 1) / C2W_RED_COLS, 8192);
@@ -494,8 +508,9 @@ int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_
         return C2W_ERR_BAD_ARG;
     }
     if (dtype == C2W_DTYPE_F32) return launch<float, false>(a, dw, db, ws, ws_bytes, st);
-    if (dtype == C2W_DTYPE_BF16) return launch<bf16_t, false>(a, dw, db, ws, ws_bytes, st);
-    if (dtype == C2W_DTYPE_F16) return launch<f16_t, false>(a, dw, db, ws, ws_bytes, st);
+    const bool narrow = a.Cout <= 80 && c2w_knobs().wgrad_narrow;  // the output conv (65 channels)
+    if (dtype == C2W_DTYPE_BF16) return narrow ? launch<bf16_t, false, true>(a, dw, db, ws, ws_bytes, st) : launch<bf16_t, false>(a, dw, db, ws, ws_bytes, st);
+    if (dtype == C2W_DTYPE_F16) return narrow ? launch<f16_t, false, true>(a, dw, db, ws, ws_bytes, st) : launch<f16_t, false>(a, dw, db, ws, ws_bytes, st);
     return C2W_ERR_BAD_ARG;
 }
 

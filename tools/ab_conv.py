@@ -34,24 +34,28 @@ libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
 SHAPES = [(S1, 128, 128, 128), (S1, 64, 128, 128), (S1, 32, 256, 256), (S1, 16, 384, 384), (S1, 8, 512, 512), (S1, 64, 256, 128), (S1, 32, 384, 256),
           (S1, 16, 512, 384), (S2, 128, 128, 128), (S2, 64, 128, 256), (S2, 32, 256, 384), (S2, 16, 384, 512), (TS2, 64, 128, 128), (TS2, 32, 256, 128),
           (TS2, 16, 384, 256), (TS2, 8, 512, 384), (X1, 8, 512, 1536), (X1, 8, 512, 512)]
-if os.environ.get("SHAPES"):
+if os.environ.get("SHAPE"):  # one custom geometry: SHAPE=mode,H,Cin,Cout[,ldy] (Cout output channels in rows of ldy: the output conv is 65 of 128)
+    SHAPES = [tuple(int(v) for v in os.environ["SHAPE"].split(","))]
+elif os.environ.get("SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["SHAPES"].split(",")]
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for (mode, H, Cin, Cout) in SHAPES:
+for (mode, H, Cin, Cout, *rest) in SHAPES:
+    ldy = rest[0] if rest else Cout
+    wrows = rest[1] if len(rest) > 1 else Cout  # SHAPE=1,128,128,128,128,65: the output conv (65 weight rows, 128-wide output rows)
     Ho = H // 2 if mode == S2 else (H * 2 if mode in (UP, TS2) else H)
     taps = 1 if mode == X1 else 9
     x = torch.randn(B * H * H, Cin, device=dev).to(TD)
-    w = (torch.randn(Cout, taps, Cin, device=dev) / math.sqrt(taps * Cin)).to(TD)
+    w = (torch.randn(rest[1] if len(rest) > 1 else Cout, taps, Cin, device=dev) / math.sqrt(taps * Cin)).to(TD)
     if os.environ.get("ZERO"):  # all-zero operands: same instruction stream, far less switching energy -> shows what the clock governor takes
         x.zero_()
         w.zero_()
-    bias = torch.randn(Cout, device=dev)
-    ys = [torch.empty(B * Ho * Ho, Cout, device=dev, dtype=TD) for _ in libs]
+    bias = torch.randn(rest[1] if len(rest) > 1 else Cout, device=dev)
+    ys = [torch.zeros(B * Ho * Ho, ldy, device=dev, dtype=TD) for _ in libs]
     mac_pix = B * Ho * Ho if mode != TS2 else B * H * H
     gf = 2.0 * mac_pix * Cout * taps * Cin / 1e9
 
     def run(lib, y):
-        a = ConvArgs(x.data_ptr(), w.data_ptr(), bias.data_ptr() if BIAS else None, None, None, y.data_ptr(), None, B, H, H, Cin, Ho, Ho, Cout, Cout, Cout,
+        a = ConvArgs(x.data_ptr(), w.data_ptr(), bias.data_ptr() if BIAS else None, None, None, y.data_ptr(), None, B, H, H, Cin, Ho, Ho, Cout, ldy, wrows,
                      mode, ACT, 0)
         rc = lib.c2w_conv_forward(ctypes.byref(a), _lib.DTYPE_F16 if F16 else _lib.DTYPE_BF16, 0, st)
         assert rc == 0, rc

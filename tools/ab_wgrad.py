@@ -29,17 +29,20 @@ def load(path):
 libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
 SHAPES = [(S1, 128, 128, 128), (S1, 64, 128, 128), (S1, 32, 256, 256), (S1, 16, 384, 384), (S1, 8, 512, 512), (S1, 64, 256, 128), (S1, 32, 384, 256),
           (S1, 16, 512, 384), (S2, 128, 128, 128), (S2, 64, 128, 256), (S2, 32, 256, 384), (S2, 16, 384, 512), (X1, 8, 512, 1536), (X1, 8, 512, 512)]
-if os.environ.get("SHAPES"):
+if os.environ.get("SHAPE"):  # one custom geometry: SHAPE=mode,H,Cin,Cout (mode: S1 = 1, S2 = 2, 1x1 = 0)
+    SHAPES = [tuple(int(v) for v in os.environ["SHAPE"].split(","))]
+elif os.environ.get("SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["SHAPES"].split(",")]
 ws = torch.empty((96 << 20) // 4, dtype=torch.float32, device=dev)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for (mode, H, Cin, Cout) in SHAPES:
+for (mode, H, Cin, Cout, *rest) in SHAPES:
+    ldy = rest[0] if rest else Cout  # SHAPE=mode,H,Cin,Cout,ldy: Cout gradient rows of an ldy-wide dY (the output conv: 65 of 128)
     Ho = H // 2 if mode == S2 else H
     taps = 1 if mode == X1 else 9
     x = torch.randn(B * H * H, Cin, device=dev).bfloat16()
-    y = torch.randn(B * Ho * Ho, Cout, device=dev).bfloat16()
+    y = torch.randn(B * Ho * Ho, ldy, device=dev).bfloat16()
     dws = [torch.zeros(Cout * taps * Cin, device=dev) for _ in libs]
-    a = ConvArgs(x.data_ptr(), None, None, None, None, y.data_ptr(), None, B, H, H, Cin, Ho, Ho, Cout, Cout, Cout, mode, 0, 0)
+    a = ConvArgs(x.data_ptr(), None, None, None, None, y.data_ptr(), None, B, H, H, Cin, Ho, Ho, Cout, ldy, Cout, mode, 0, 0)
     gf = 2.0 * B * Ho * Ho * Cout * taps * Cin / 1e9
 
     def run(lib, dw):
