@@ -357,3 +357,36 @@ def test_trainer_forward_backward_at_bench_size_vs_cpu_oracle():
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "bench_step_parity.txt"), "a") as f:
         f.write("\n".join(report) + "\n")
+
+
+def test_two_stream_backward_reproduces_every_conv_weight_gradient_bit_for_bit():
+    """Run-to-run determinism of the step as bench.py runs it (forward / input gradients on one stream, weight gradients and their
+    reductions on a second): the same batch, (t, eps) and weights twelve times at B = 128.  The 70 conv kernels' gradients -- split-K
+    partial sums reduced in a fixed order from deterministic operands -- must be bit-identical every time; a race between workgroups
+    shows up here as one that changes (round 3's weight-ring race did, in the forward).  Biases, LayerNorm-modulation sums and the
+    Linear weights fed by them use fp32 atomics and may differ in the last bits: not compared.  tools/hunt_flake_step.py is the long form."""
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+    B, C, H = 128, 65, 128
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT).cuda()
+    gen = torch.Generator().manual_seed(128)
+    x = (torch.randn(B, C, H, H, generator=gen) * 0.5 + 0.5).cuda()
+    t = torch.rand(B, generator=gen).cuda()
+    eps = torch.randn(B, C, H, H, generator=gen).cuda()
+    tr = Trainer(net, precision="bf16", ema_rates=())
+    assert tr.eng.use_grad_stream
+    convs = [(n, p) for n, p in net.named_parameters() if p.dim() == 4]
+    assert len(convs) == 70
+    ref = None
+    for r in range(12):
+        tr.eng.flat_grad.zero_()
+        loss = tr._forward_backward(x, t, eps, sync=False)
+        torch.cuda.synchronize()
+        assert math.isfinite(loss.item())
+        cur = [p.grad.detach().clone() for _, p in convs]
+        if ref is None:
+            ref = cur
+            continue
+        changed = [n for (n, _), a, b in zip(convs, cur, ref) if not torch.equal(a, b)]
+        assert not changed, f"round {r}: {len(changed)} conv weight gradients changed between identical steps, first {changed[0]}"
