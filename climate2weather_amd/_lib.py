@@ -15,7 +15,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
-CONV_POOL2 = 1  # ConvArgs.flags
+CONV_POOL2, CONV_WPACKED = 1, 2  # ConvArgs.flags (bit set)
 KERNEL_GATHER, KERNEL_PATCH_8X16, KERNEL_PATCH_16X16, KERNEL_PATCH_PAIR, KERNEL_PATCH_TS2 = 0, 1, 2, 3, 4  # c2w_conv_dispatch
 
 
@@ -66,6 +66,8 @@ _PROTOS = {
     "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
     "c2w_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_weight_transpose_batched": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "c2w_pack_conv_weights_batched": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "c2w_conv_wpacked_supported": [POINTER(ConvArgs), c_int],
     "c2w_adamw_ema": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
                       c_float, c_int, c_float, c_float, c_void_p],
     "c2w_adamw_ema_scaled": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_float, c_float, c_float,

@@ -359,6 +359,7 @@ C2wKnobs read_knobs() {
     k.conv_ts2_patch = !off0("C2W_CONV_TS2_PATCH");
     k.up_patch = getenv("C2W_NO_UP_PATCH") == nullptr;
     k.wgrad_narrow = getenv("C2W_NO_NARROW") == nullptr;
+    k.wpacked = getenv("C2W_NO_WPACKED") == nullptr;
     k.pool2 = getenv("C2W_NO_POOL2") == nullptr;
     k.ln_fusion = getenv("C2W_NO_LN_FUSION") == nullptr;
     k.lnf = getenv("C2W_NO_LNF") == nullptr;
@@ -396,6 +397,12 @@ extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     return c2w_conv_patch_eligible(*a) && !c2w_knobs().force_gather && c2w_knobs().ln_fusion ? 1 : 0;
 }
 
+extern "C" int c2w_conv_wpacked_supported(const C2wConvArgs* a, int dtype) {
+    if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
+    if (a->ln_x != nullptr) return 0;  // the fused LayerNorm backward has no packed-weights instantiation (two spilled registers)
+    return !c2w_knobs().force_gather && c2w_knobs().wpacked && c2w_conv_patch_eligible(*a) && c2w_conv_patch3_wanted(*a, dtype) ? 1 : 0;
+}
+
 extern "C" int c2w_conv_dispatch(const C2wConvArgs* a, int dtype) {
     if (a == nullptr) return C2W_ERR_BAD_ARG;
     const bool gather = c2w_knobs().force_gather;
@@ -419,6 +426,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if ((a->flags & C2W_CONV_POOL2) != 0 && (naive != 0 || !c2w_conv_pool2_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
+    if ((a->flags & C2W_CONV_WPACKED) != 0 && (naive != 0 || !c2w_conv_wpacked_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no other kernel reads that layout
     const bool patch = naive == 0 && !c2w_knobs().force_gather;
     if (patch && c2w_conv_patch_eligible(*a)) return c2w_conv_patch_s1(*a, dtype, st);
     if (patch && c2w_conv_pair_eligible(*a)) return c2w_conv_patch_pair(*a, dtype, st);

@@ -83,7 +83,9 @@ template <int WPIECES> __device__ __forceinline__ void t3_wait(bool more) {
     }
 }
 
-template <int TR, typename T = bf16_t, int NW = 4, int EPI = 0>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
+// WPK: the weights are the stage-major packed copy (C2W_CONV_WPACKED) -- its own instantiation: with both addressing forms in one
+// kernel (a select, or a uniform branch) either the fp16 or the bf16 build spilled 2-3 registers
+template <int TR, typename T = bf16_t, int NW = 4, int EPI = 0, bool WPK = false>  // T: bf16_t or f16_t (same bytes, other MFMA opcode and conversions)
 __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv_patch_t3_kernel(const C2wConvArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     typedef T3Cfg<TR, NW> CF;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
 
     const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)(WPK ? nN * 128 : p.wrows) * 9 * p.Cin * ESZ));
 
     // patch pieces (rounds past the end repeat the last piece).  The source offsets are recomputed at every chunk start instead
     // of living in VGPRs through the loop: anything spilled would come back through scratch loads, which return out of order
@@ -146,6 +148,9 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         }
     };
     // weight stage: 128 rows x 4 slots of 16 B = 2 rounds; lane -> row = (round * 4 + wave) * 16 + lane / 4, slot = lane & 3
+    // C2W_CONV_WPACKED: the stage-major copy (c2w_pack_conv_weights_batched): the 128 rows x 64 B of a (tap, 32-channel half) lie in one
+    // 8 KiB block, swizzle baked in -- a piece is 1 KiB of consecutive bytes (8 cache lines) instead of 16 half-used lines
+    constexpr bool wpk = WPK;
     auto wvo_at = [&](int i) {
         int l = lane;
         const int row = (i * NW + wid) * 16 + (l >> 2);
@@ -153,8 +158,15 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         return (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (cg << 4);
     };
     auto issue_w = [&](int chunk, int tap, int half, int wslot) {
-        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * 64 + half * 32) * ESZ;
         if (NARROW && wid >= 5) return;  // pieces 5-7 = output channels 80-127: nobody reads them
+        if constexpr (wpk) {
+            const uint32_t so = (uint32_t)(((tap * (p.Cin >> 5) + chunk * 2 + half) * (nN * 128) + co0) * 64);
+#pragma unroll
+            for (int i = 0; i < CF::WPIECES; ++i)
+                glds16(rw, smem + CF::PBYTES + wslot * T3_WBYTES + (i * NW + wid) * 1024, (uint32_t)(i * NW * 1024 + tid * 16), so);
+            return;
+        }
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * 64 + half * 32) * ESZ;
 #pragma unroll
         for (int i = 0; i < CF::WPIECES; ++i) glds16(rw, smem + CF::PBYTES + wslot * T3_WBYTES + (i * NW + wid) * 1024, wvo_at(i), so);
     };
@@ -354,18 +366,27 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     }
 }
 
-template <int TR, typename T, int NW, int EPI>
-int t3_launch_as(const C2wConvArgs& a, hipStream_t st) {
+template <int TR, typename T, int NW, int EPI, bool WPK>
+int t3_launch_wpk(const C2wConvArgs& a, hipStream_t st) {
     typedef T3Cfg<TR, NW> CF;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_t3_kernel<TR, T, NW, EPI, WPK>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr = true;
     }
     const int nN = (a.Cout + 127) / 128;
     const int nM = a.B * (a.Hout / TR) * (a.Wout >> 4);
-    conv_patch_t3_kernel<TR, T, NW, EPI><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
+    conv_patch_t3_kernel<TR, T, NW, EPI, WPK><<<nM * nN, CF::NTHR, CF::LDS, st>>>(a);
     return (int)hipGetLastError();
+}
+template <int TR, typename T, int NW, int EPI>
+int t3_launch_as(const C2wConvArgs& a, hipStream_t st) {
+    if constexpr (EPI == 3) {  // LayerNorm backward: its packed-weights instantiation spills two registers (not built, not offered)
+        if ((a.flags & C2W_CONV_WPACKED) != 0) return C2W_ERR_BAD_SHAPE;
+        return t3_launch_wpk<TR, T, NW, EPI, false>(a, st);
+    } else {
+        return (a.flags & C2W_CONV_WPACKED) != 0 ? t3_launch_wpk<TR, T, NW, EPI, true>(a, st) : t3_launch_wpk<TR, T, NW, EPI, false>(a, st);
+    }
 }
 
 template <int TR, typename T, int NW>

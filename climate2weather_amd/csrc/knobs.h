@@ -15,6 +15,7 @@ struct C2wKnobs {
     bool wgrad_atomics;   // C2W_WGRAD_ATOMICS=1  split-K partial sums by fp32 atomics even when a workspace is handed over
     bool attn_valu;       // C2W_ATTN_VALU=1      attention on the fp32 VALU kernels instead of the matrix-core ones
     bool wgrad_narrow;    // C2W_NO_NARROW=1      edge convs (<= 80 output channels) NOT on the narrow forms of the halo-patch kernels
+    bool wpacked;         // C2W_NO_WPACKED=1     c2w_conv_wpacked_supported answers 0 (callers hand over the plain [rows][9][Cin] weights)
 };
 
 const C2wKnobs& c2w_knobs();

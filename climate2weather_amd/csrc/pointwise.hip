@@ -647,6 +647,28 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const flo
     }
 }
 
+// Stage-major weight copies for conv_patch_t3_kernel (c2w_pack_conv_weights_batched in c2w_hip.h): one thread per 16-byte slot of the
+// destination; blockIdx.y = matrix, blockIdx.x strides over its 9 * (cin / 32) * rows_pad * 4 slots.
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const uint16_t* __restrict__ srcb, uint16_t* __restrict__ dstb,
+                                                                const long long* __restrict__ desc) {
+    const long long* d = desc + (size_t)blockIdx.y * 4;
+    const uint16_t* src = srcb + d[0];
+    uint16_t* dst = dstb + d[1];
+    const int rows = (int)d[2], cin = (int)d[3], nh = cin >> 5, rows_pad = (rows + 127) & ~127;
+    const long long nslot = (long long)9 * nh * rows_pad * 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (long long)gridDim.x * 256) {
+        const int s = (int)(i & 3);            // destination slot of the 64-byte row
+        const long long rr = i >> 2;
+        const int r = (int)(rr % rows_pad);
+        const int th = (int)(rr / rows_pad);   // tap * nh + h
+        const int tap = th / nh, h = th - tap * nh;
+        const int q = s ^ ((4 - ((r >> 2) & 3)) & 3);  // source chunk that lands in slot s (t3_wswz)
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (r < rows) v = *(const u32x4_t*)(src + ((size_t)r * 9 + tap) * cin + h * 32 + q * 8);
+        *(u32x4_t*)(dst + (size_t)i * 8) = v;
+    }
+}
+
 // Fused AdamW (torch.optim.AdamW, train.py:176-181) + EMA (src/thor/ema.py:23-27) + low-precision shadow refresh.
 // With a scaler state (c2w_grad_scaler_*): gradients are divided by the loss scale; a step whose gradients held inf/nan changes
 // nothing but the EMA (GradScaler.step skips optimizer.step, the reference still calls ema.update: training_loop.py:383-389);
@@ -948,6 +970,13 @@ extern "C" int c2w_weight_transpose_batched(const float* flat, void* out, const 
     if (!flat || !out || !desc || nconv <= 0) return C2W_ERR_BAD_ARG;
     dim3 grid(256, nconv);
     DISPATCH_T(dtype, (weight_transpose_batched_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(flat, (T*)out, desc)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_pack_conv_weights_batched(const void* src, void* dst, const long long* desc, int n, int dtype, void* stream) {
+    if (!src || !dst || !desc || n <= 0 || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return C2W_ERR_BAD_ARG;
+    dim3 grid(128, n);
+    pack_conv_weights_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)src, (uint16_t*)dst, desc);
     return (int)hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
 
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
-         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0):
+         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
     dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.
@@ -53,9 +53,28 @@ def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=
     conv_lnfwd_supported(g, dtype) says so."""
     a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf)
     if pool2:  # y: [B][Hout/2][Wout/2][ldy] <- 2x2 sums of the result (only where conv_pool2_supported says so)
-        a.flags = _lib.CONV_POOL2
+        a.flags |= _lib.CONV_POOL2
+    if wpacked:  # w: the stage-major copy made by pack_conv_weights_batched (only where conv_wpacked_supported says so)
+        a.flags |= _lib.CONV_WPACKED
     a.kvalid = int(kvalid)  # promise: input channels >= kvalid are all zero in x or in w (0: no promise)
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
+
+
+def conv_wpacked_supported(g: dict, dtype: int) -> bool:
+    """True when c2w_conv_forward takes this geometry with stage-major packed weights (it goes to the 16x16-tile kernel)."""
+    a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                 g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+    return bool(_lib.load().c2w_conv_wpacked_supported(ctypes.byref(a), dtype))
+
+
+def packed_conv_weights_numel(rows: int, cin: int) -> int:
+    """Elements of one stage-major packed 3x3 weight matrix (rows padded to 128)."""
+    return 9 * cin * ((rows + 127) // 128 * 128)
+
+
+def pack_conv_weights_batched(src, dst, desc, n: int, dtype: int) -> None:
+    """c2w_pack_conv_weights_batched: desc = int64 tensor [n][4] = (src_off, dst_off, rows, cin), offsets in elements."""
+    check(_lib.load().c2w_pack_conv_weights_batched(_p(src), _p(dst), _p(desc), n, dtype, _stream()), "c2w_pack_conv_weights_batched")
 
 
 def knobs_reload() -> None:

@@ -42,7 +42,7 @@ enum {
  * y = max(a, 0), y2 = (a > 0) -- the backward pass multiplies by y2 with C2W_MUL_PLAIN. */
 enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1, C2W_ACT_SILU_PAIR = 2, C2W_ACT_RELU = 3, C2W_ACT_RELU_PAIR = 4 };
 enum { C2W_MUL_PLAIN = 0, C2W_MUL_DSILU = 1 };
-enum { C2W_CONV_POOL2 = 1 }; /* C2wConvArgs.flags */
+enum { C2W_CONV_POOL2 = 1, C2W_CONV_WPACKED = 2 }; /* C2wConvArgs.flags (bit set) */
 
 /* y[q][co] = act( sum_{tap,ci} w[co][tap][ci] * x[src(q,tap)][ci] + bias[co] ) (* mul' ) (+ res)
  * q runs over the B*Hout*Wout output pixels in NHWC raster order. */
@@ -73,6 +73,8 @@ typedef struct C2wConvArgs {
     int32_t flags;      /* C2W_CONV_POOL2: y is [B][Hout/2][Wout/2][ldy] and receives the 2x2 SUMS of the result -- the adjoint of
                          * Upsample(nearest, x2) (model/nn.py:184) applied to the input gradient of the conv behind it, on chip: the
                          * full-resolution gradient is never written (see c2w_conv_pool2_supported) */
+                        /* C2W_CONV_WPACKED: w is the stage-major copy c2w_pack_conv_weights_batched makes ([tap][Cin / 32][rows padded to 128][32 ci],
+                         * 8 KiB per K stage of the 16x16-tile kernel in one piece); accepted only where c2w_conv_wpacked_supported says so */
     /* Optional fused LayerNorm FORWARD of the consumer (see c2w_conv_lnfwd_supported): with lnf_y != NULL the kernel also
      * writes lnf_y = LN_C(y + lnf_m[b]) -- c2w_ln_forward(x = y as stored, m = lnf_m, ldm = ln_ldm, eps = ln_eps,
      * unbiased = ln_unbiased) -- i.e. the next residual block's normalised input (model/nn.py:28,154) leaves the conv that
@@ -189,6 +191,17 @@ int c2w_weight_transpose(const float* w, void* out, int R, int NT, int K, int ld
 /* the same for nconv weight matrices in one launch: desc (device memory) holds 8 int64 per matrix
  * {w_off, out_off, R, NT, K, ldk, ldr, flip}, offsets in elements into flat / out */
 int c2w_weight_transpose_batched(const float* flat, void* out, const long long* desc, int nconv, int dtype, void* stream);
+/* Stage-major copies of 16-bit 3x3 conv weights for the 16x16-tile kernel (C2W_CONV_WPACKED), n matrices in one launch:
+ * desc[j] = {src_off, dst_off, rows, cin} (offsets in ELEMENTS into src / dst; src matrix [rows][9][cin], cin a multiple of 32):
+ *   dst[((tap * (cin / 32) + h) * rows_pad + r) * 32 + ((q ^ swz(r)) * 8) + e] = src[r][tap][h * 32 + q * 8 + e],  rows_pad = rows
+ *   rounded up to 128, zero for r >= rows, swz(r) = (4 - ((r >> 2) & 3)) & 3 (the kernel's LDS swizzle, baked in).
+ * The kernel then fetches the 128 rows x 64 B of a (tap, 32-channel half) as ONE contiguous 8 KiB block instead of 128 row pieces
+ * 9 * cin * 2 bytes apart: 4.7 % of the dominant launch (profiles/r03_experiments.md section 11).  Size of a packed matrix:
+ * 9 * cin * rows_pad elements. */
+int c2w_pack_conv_weights_batched(const void* src, void* dst, const long long* desc, int n, int dtype, void* stream);
+/* 1 when c2w_conv_forward takes args with C2W_CONV_WPACKED set (the launch goes to the 16x16-tile halo-patch kernel and does not carry
+ * the fused LayerNorm backward), else 0. */
+int c2w_conv_wpacked_supported(const C2wConvArgs* args, int dtype);
 /* fused torch.optim.AdamW step (train.py:176-181) + EMA (src/thor/ema.py:23-27) + bf16 shadow refresh over a flat
  * parameter buffer; ema / shadow_bf16 may be NULL; g is multiplied by grad_scale first. */
 int c2w_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, long long n, float lr,

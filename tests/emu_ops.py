@@ -71,7 +71,13 @@ def conv_pool2_supported(g, dtype):
     return conv_patch_supported(g, dtype) and g["mode"] == CONV_S1 and g["Win"] != 8
 
 
-def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False, kvalid=0):
+def conv_wpacked_supported(g, dtype):
+    return False  # the emulation reads the plain [rows][taps][Cin] weights only: the engine never hands it a packed copy
+
+
+def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False, kvalid=0,
+         wpacked=False):
+    assert not wpacked
     # kvalid: a promise that input channels >= kvalid are zero (the HIP kernels may skip them); the restatement multiplies everything
     if lnf is not None:  # second output: LN of the stored result (+ the consumer's modulation)
         assert ln is None and mul is None and y2 is None and act == ACT_NONE

@@ -390,3 +390,68 @@ def test_two_stream_backward_reproduces_every_conv_weight_gradient_bit_for_bit()
             continue
         changed = [n for (n, _), a, b in zip(convs, cur, ref) if not torch.equal(a, b)]
         assert not changed, f"round {r}: {len(changed)} conv weight gradients changed between identical steps, first {changed[0]}"
+
+
+PACKED_CASES = [  # (name, B, H, Cin, Cout, wrows, epilogue)
+    ("128->128 @128^2 bias+SiLU pair", 16, 128, 128, 128, 128, "pair"),
+    ("128->128 @128^2 residual + LayerNorm emission", 16, 128, 128, 128, 128, "res+lnf"),
+    ("256->256 @32^2 (two 128-row tiles) multiplier + residual", 128, 32, 256, 256, 256, "mulp+res"),
+    ("256->128 @64^2", 64, 64, 256, 128, 128, "bias"),
+    ("output conv 128->65(128) @128^2 (narrow form)", 16, 128, 128, 128, 65, "bias"),
+    ("padded K: 160(192)->128 @128^2 with kvalid", 16, 128, 192, 128, 128, "kvalid"),
+]
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("case", PACKED_CASES, ids=[c[0] for c in PACKED_CASES])
+def test_stage_major_packed_weights_give_the_same_bits(case, dt):
+    """C2W_CONV_WPACKED: the 16x16-tile kernel fed the stage-major copy of the weights (c2w_pack_conv_weights_batched) must reproduce
+    the launch with the plain [rows][9][Cin] weights bit for bit -- same arithmetic, another address for the same bytes -- over the
+    epilogue families, two-tile output rows, the narrow output-conv form and a kvalid launch; and the launches that cannot take it
+    (fused LayerNorm backward) must say so."""
+    name, B, H, Cin, Cout, wrows, ep = case
+    g = geom(B, H, H, Cin, H, H, Cout, Cout, wrows, S1)
+    assert ops.conv_wpacked_supported(g, dt), name
+    npix = B * H * H
+    x = rnd((npix, Cin), dt, 1)
+    w = rnd((wrows, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    kvalid = 0
+    if ep == "kvalid":
+        kvalid = 160
+        x[:, kvalid:] = 0
+    wp = torch.empty(ops.packed_conv_weights_numel(wrows, Cin) + 64, dtype=TD[dt], device=dev()).fill_(7.0)
+    desc = torch.tensor([[0, 0, wrows, Cin]], dtype=torch.int64, device=dev())
+    ops.pack_conv_weights_batched(w, wp, desc, 1, dt)
+    assert torch.all(wp[-64:] == 7.0)  # nothing written past the packed matrix
+    bias = rnd((wrows,), F32, 3)
+    kw = {}
+    outs = []
+    for packed in (False, True):
+        y = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev())
+        kw = dict(kvalid=kvalid)
+        extra = []
+        if ep == "pair":
+            y2 = torch.full_like(y, 3.0)
+            kw.update(act=ops.ACT_SILU_PAIR, y2=y2)
+            extra.append(y2)
+        if "res" in ep:
+            kw["res"] = rnd((npix, Cout), dt, 4)
+        if "mulp" in ep:
+            kw.update(mul=rnd((npix, Cout), dt, 5), mulmode=ops.MUL_PLAIN)
+        if "lnf" in ep:
+            hn = torch.full_like(y, 3.0)
+            kw["lnf"] = dict(y=hn, m=rnd((B, Cout), F32, 6).view(-1), ldm=Cout, eps=1e-5, unbiased=True)
+            extra.append(hn)
+        ops.conv(x, wp if packed else w, bias, y, g, dt, wpacked=packed, **kw)
+        torch.cuda.synchronize()
+        outs.append([y] + extra)
+    for a, b in zip(*outs):
+        assert a.float().abs().sum().item() > 0 and torch.equal(a, b), name
+    # the fused LayerNorm backward has no packed instantiation: the query says no and the launch refuses instead of misreading the weights
+    if Cout == 128 and wrows == 128 and Cin == 128 and dt == BF16:
+        xs, ms = rnd((npix, Cout), dt, 7), rnd((B, Cout), F32, 8)
+        dm = torch.zeros(B, Cout, device=dev())
+        ln = dict(x=xs, m=ms.view(-1), dm=dm.view(-1), ldm=Cout, eps=1e-5, unbiased=True)
+        y = torch.empty((npix, Cout), dtype=TD[dt], device=dev())
+        with pytest.raises(Exception):
+            ops.conv(x, wp, None, y, g, dt, res=rnd((npix, Cout), dt, 4), ln=ln, wpacked=True)
