@@ -399,7 +399,6 @@ extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
 
 extern "C" int c2w_conv_wpacked_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
-    if (a->ln_x != nullptr) return 0;  // the fused LayerNorm backward has no packed-weights instantiation (two spilled registers)
     return !c2w_knobs().force_gather && c2w_knobs().wpacked && c2w_conv_patch_eligible(*a) && c2w_conv_patch3_wanted(*a, dtype) ? 1 : 0;
 }
 

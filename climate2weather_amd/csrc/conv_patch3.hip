@@ -174,12 +174,12 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // fragment read offsets.  A: row = wm*64 + m*16 + li, its swizzle depends on (row >> 2) & 3 = (li >> 2) & 3 only, not on m, so
     // A[m] = offA + m * 1024; B: pixel (wn*4*NB + n + kh, li + kw): offB[kw] + (n + kh) * pitch; k-half 1 flips slot bit 2.
     const uint32_t offA_held = (uint32_t)(CF::PBYTES + (wm * 64 + li) * 64 + (((uint32_t)lg ^ t3_wswz(li)) << 4));
-    // NOTE the second, never-taken form (the base recomputed from the lane id: what a schedule without a register to hold it
-    // would do).  The kernel sits at exactly 128 VGPRs; without these dead statements hipcc (ROCm 7.2) allocates the bf16 LayerNorm-
+    // NOTE the second form (the base recomputed from the lane id: what a schedule without a register to hold it would do), taken
+    // only by the packed-weights LayerNorm-backward instantiation.  The kernel sits at exactly 128 VGPRs; without these dead statements hipcc (ROCm 7.2) allocates the bf16 LayerNorm-
     // emission instantiation differently and spills one register inside the loop -- which the counted vmcnt waits do not survive.
     // tests/test_kernel_resources.py fails the build on any spill; keep the two together.
     auto offA_at = [&]() {
-        if constexpr (true) return offA_held;
+        if constexpr (!(WPK && EPI == 3)) return offA_held;  // packed LayerNorm backward: recomputed per stage (held, it spills 2 registers)
         int l = lane;
         asm volatile("" : "+v"(l));
         const int li_ = l & 15;
@@ -381,12 +381,7 @@ int t3_launch_wpk(const C2wConvArgs& a, hipStream_t st) {
 }
 template <int TR, typename T, int NW, int EPI>
 int t3_launch_as(const C2wConvArgs& a, hipStream_t st) {
-    if constexpr (EPI == 3) {  // LayerNorm backward: its packed-weights instantiation spills two registers (not built, not offered)
-        if ((a.flags & C2W_CONV_WPACKED) != 0) return C2W_ERR_BAD_SHAPE;
-        return t3_launch_wpk<TR, T, NW, EPI, false>(a, st);
-    } else {
-        return (a.flags & C2W_CONV_WPACKED) != 0 ? t3_launch_wpk<TR, T, NW, EPI, true>(a, st) : t3_launch_wpk<TR, T, NW, EPI, false>(a, st);
-    }
+    return (a.flags & C2W_CONV_WPACKED) != 0 ? t3_launch_wpk<TR, T, NW, EPI, true>(a, st) : t3_launch_wpk<TR, T, NW, EPI, false>(a, st);
 }
 
 template <int TR, typename T, int NW>

@@ -391,7 +391,7 @@ class Engine:
         """(operand, wpacked flag) for a conv launch of geometry ``g``: the packed copy where the launch goes to the 16x16-tile kernel
         (ops.conv_wpacked_supported; -4.6 % on the dominant launch, bit-identical results), else the plain one."""
         plain = self._w(rec, dt) if kind == "f" else self._wT(rec, dt)
-        if not self.use_packed_weights or fused_ln_bwd or dt == DTYPE_F32:
+        if not self.use_packed_weights or dt == DTYPE_F32:
             return plain, False
         key = (kind, rec.name, dt, g["B"], g["Hin"], g["Win"], g["Hout"], g["Wout"], g["Cout"], g["mode"])
         ok = self._pk_ok.get(key)

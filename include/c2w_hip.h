@@ -199,8 +199,7 @@ int c2w_weight_transpose_batched(const float* flat, void* out, const long long* 
  * 9 * cin * 2 bytes apart: 4.7 % of the dominant launch (profiles/r03_experiments.md section 11).  Size of a packed matrix:
  * 9 * cin * rows_pad elements. */
 int c2w_pack_conv_weights_batched(const void* src, void* dst, const long long* desc, int n, int dtype, void* stream);
-/* 1 when c2w_conv_forward takes args with C2W_CONV_WPACKED set (the launch goes to the 16x16-tile halo-patch kernel and does not carry
- * the fused LayerNorm backward), else 0. */
+/* 1 when c2w_conv_forward takes args with C2W_CONV_WPACKED set (the launch goes to the 16x16-tile halo-patch kernel), else 0. */
 int c2w_conv_wpacked_supported(const C2wConvArgs* args, int dtype);
 /* fused torch.optim.AdamW step (train.py:176-181) + EMA (src/thor/ema.py:23-27) + bf16 shadow refresh over a flat
  * parameter buffer; ema / shadow_bf16 may be NULL; g is multiplied by grad_scale first. */

@@ -447,11 +447,15 @@ def test_stage_major_packed_weights_give_the_same_bits(case, dt):
         outs.append([y] + extra)
     for a, b in zip(*outs):
         assert a.float().abs().sum().item() > 0 and torch.equal(a, b), name
-    # the fused LayerNorm backward has no packed instantiation: the query says no and the launch refuses instead of misreading the weights
-    if Cout == 128 and wrows == 128 and Cin == 128 and dt == BF16:
-        xs, ms = rnd((npix, Cout), dt, 7), rnd((B, Cout), F32, 8)
-        dm = torch.zeros(B, Cout, device=dev())
-        ln = dict(x=xs, m=ms.view(-1), dm=dm.view(-1), ldm=Cout, eps=1e-5, unbiased=True)
-        y = torch.empty((npix, Cout), dtype=TD[dt], device=dev())
-        with pytest.raises(Exception):
-            ops.conv(x, wp, None, y, g, dt, res=rnd((npix, Cout), dt, 4), ln=ln, wpacked=True)
+    # the fused LayerNorm backward (its packed instantiation recomputes a fragment base per stage to stay inside 128 registers)
+    if Cout == 128 and wrows == 128 and Cin == 128:
+        xs, ms, rs = rnd((npix, Cout), dt, 7), rnd((B, Cout), F32, 8), rnd((npix, Cout), dt, 4)
+        got = []
+        for packed in (False, True):
+            dm = torch.zeros(B, Cout, device=dev())
+            y = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev())
+            ops.conv(x, wp if packed else w, None, y, g, dt, res=rs, ln=dict(x=xs, m=ms.view(-1), dm=dm.view(-1), ldm=Cout, eps=1e-5, unbiased=True),
+                     wpacked=packed)
+            torch.cuda.synchronize()
+            got.append(y)
+        assert torch.equal(got[0], got[1]), name + " (fused LayerNorm backward)"
