@@ -151,10 +151,10 @@ class LaunchTimer:
             if rec.dg_off >= 0:
                 self.dg[eng._wT(rec, d).data_ptr()] = rec
             if eng.use_packed_weights and not rec.lin:  # the stage-major copies the 16x16-tile launches are handed instead
-                pf = eng._packed("f", rec, d)
+                pf = eng._packed("f", rec, d) if rec.name in eng._pk_want.get(("f", d), ()) else None  # only what the warm-up steps asked for
                 if pf is not None:
                     self.fw[pf.data_ptr()] = rec
-                pd = eng._packed("d", rec, d) if rec.dg_off >= 0 else None
+                pd = eng._packed("d", rec, d) if rec.name in eng._pk_want.get(("d", d), ()) else None
                 if pd is not None:
                     self.dg[pd.data_ptr()] = rec
             self.gw[eng._gw(rec).data_ptr()] = rec

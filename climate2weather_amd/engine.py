@@ -197,6 +197,7 @@ class Engine:
         self._pk_ver: Dict[tuple, object] = {}
         self._pk_tab: Dict[tuple, tuple] = {}
         self._pk_ok: Dict[tuple, bool] = {}    # launch geometry -> does c2w_conv_forward take packed weights there
+        self._pk_want: Dict[tuple, set] = {}   # (kind, dtype) -> names of the matrices that are kept packed
         self.use_packed_weights = os.environ.get("C2W_NO_WPACKED") is None
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
@@ -242,6 +243,7 @@ class Engine:
         self._pk_ver.clear()
         self._pk_tab.clear()
         self._pk_ok.clear()
+        self._pk_want.clear()
         self._gwpad.clear()
 
     def is_attached(self, net) -> bool:
@@ -353,11 +355,17 @@ class Engine:
         if dt == DTYPE_F32 or rec.lin or rec.taps != 9:
             return None
         key = (kind, dt)
+        want = self._pk_want.setdefault(key, set())
+        if rec.name not in want:  # packed on demand: only the matrices some launch asked for (at B = 128 the levels the 16x16-tile
+            want.add(rec.name)    # kernel serves hold 11 of the 72 M parameters); a new one rebuilds the table once
+            self._pk_tab.pop(key, None)
+            self._pk.pop(key, None)
+            self._pk_ver.pop(key, None)
         tab = self._pk_tab.get(key)
         if tab is None:
             offs, rows_t, total = {}, [], 0
             for r in self.layout.convs.values():
-                if r.lin or r.taps != 9:
+                if r.lin or r.taps != 9 or r.name not in want:
                     continue
                 if kind == "f":
                     if r.kstride != r.cin or r.cin % 32:
