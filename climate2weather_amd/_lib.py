@@ -85,6 +85,8 @@ _PROTOS = {
     "c2w_sampler_correct": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_void_p],
     "c2w_guidance": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                      c_void_p],
+    "c2w_guidance_per_variable": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                  c_void_p],
     "c2w_pool_stride": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_affine_channels": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
 }

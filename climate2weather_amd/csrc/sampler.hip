@@ -97,12 +97,14 @@ __global__ __launch_bounds__(256) void correct_kernel(float* __restrict__ x, con
 
 // Gaussian-likelihood guidance with the reference's measurement operator A = AvgPool2d(s) o x[::t_step]
 // (exp/downscaling.py:129-132) and exact_grad=False (src/thor/score.py:28-57, all shipped configs):
-//   x0 = (x - sigma eps)/mu ; err = y - A(x0) ; var = std_c^2 + gamma (sigma/mu)^2
+//   x0 = (x - sigma eps)/mu ; err = y - A(x0) ; var = std_c^2 + gamma_c (sigma/mu)^2
+// (std and gamma per variable c: exp/downscaling.py:219-233 builds both as (1, C, 1, 1) tensors for list-valued settings;
+//  gammav == nullptr: the scalar `gamma` for every variable)
 //   eps <- eps - sigma * (1/mu) * A^T(err/var)          (A^T spreads err/(var s^2) over the s x s cell)
 // one wave per (observed frame, channel, pooled cell)
 __global__ __launch_bounds__(256) void guidance_kernel(const float* __restrict__ x, float* __restrict__ eps, const float* __restrict__ yobs,
-                                                       const float* __restrict__ stdv, int nobs, int F, int H, int W, int s, int t_step,
-                                                       float mu, float sigma, float gamma) {
+                                                       const float* __restrict__ stdv, const float* __restrict__ gammav, int nobs, int F, int H,
+                                                       int W, int s, int t_step, float mu, float sigma, float gamma) {
     const int lane = threadIdx.x & 63;
     const int PH = H / s, PW = W / s;
     const long long ncell = (long long)nobs * F * PH * PW;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void guidance_kernel(const float* __restrict__
     const float mean = wave_sum(acc) / (float)(s * s);
     const float sd = stdv[c];
     const float ratio = sigma / mu;
-    const float var = sd * sd + gamma * ratio * ratio;
+    const float var = sd * sd + (gammav != nullptr ? gammav[c] : gamma) * ratio * ratio;
     const float err = yobs[(((long long)o * F + c) * PH + ph) * PW + pw] - mean;
     const float corr = sigma * (err / var) / (mu * (float)(s * s));
     for (int q = lane; q < s * s; q += 64) {
@@ -226,13 +228,24 @@ extern "C" int c2w_sampler_correct(float* x, const float* eps, const float* z, c
     return (int)hipGetLastError();
 }
 
-extern "C" int c2w_guidance(const float* x, float* eps, const float* yobs, const float* stdv, int nobs, int F, int H, int W, int s_step,
-                            int t_step, float mu, float sigma, float gamma, void* stream) {
+static int guidance_launch(const float* x, float* eps, const float* yobs, const float* stdv, const float* gammav, int nobs, int F, int H, int W,
+                           int s_step, int t_step, float mu, float sigma, float gamma, void* stream) {
     if (!x || !eps || !yobs || !stdv || nobs <= 0 || s_step <= 0 || H % s_step || W % s_step || t_step <= 0) return C2W_ERR_BAD_SHAPE;
     const long long ncell = (long long)nobs * F * (H / s_step) * (W / s_step);
     const long long blocks = (ncell + 3) / 4;
-    guidance_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma);
+    guidance_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, eps, yobs, stdv, gammav, nobs, F, H, W, s_step, t_step, mu, sigma, gamma);
     return (int)hipGetLastError();
+}
+
+extern "C" int c2w_guidance(const float* x, float* eps, const float* yobs, const float* stdv, int nobs, int F, int H, int W, int s_step,
+                            int t_step, float mu, float sigma, float gamma, void* stream) {
+    return guidance_launch(x, eps, yobs, stdv, nullptr, nobs, F, H, W, s_step, t_step, mu, sigma, gamma, stream);
+}
+
+extern "C" int c2w_guidance_per_variable(const float* x, float* eps, const float* yobs, const float* stdv, const float* gammav, int nobs, int F,
+                                         int H, int W, int s_step, int t_step, float mu, float sigma, void* stream) {
+    if (!gammav) return C2W_ERR_BAD_ARG;
+    return guidance_launch(x, eps, yobs, stdv, gammav, nobs, F, H, W, s_step, t_step, mu, sigma, 0.f, stream);
 }
 
 extern "C" int c2w_pool_stride(const float* x, float* y, int nobs, int F, int H, int W, int s_step, int t_step, void* stream) {

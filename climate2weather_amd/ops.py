@@ -302,6 +302,11 @@ def sampler_correct(x, eps, z, sumsq_buf, nan_flag, n, tau, sigma_next):
 
 
 def guidance(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma):
+    """``gamma``: a float, or a device tensor of F values (one per variable, exp/downscaling.py:228-233)."""
+    if isinstance(gamma, torch.Tensor):
+        check(_lib.load().c2w_guidance_per_variable(_p(x), _p(eps), _p(yobs), _p(stdv), _p(gamma), nobs, F, H, W, s_step, t_step, mu, sigma,
+                                                    _stream()), "c2w_guidance_per_variable")
+        return
     check(_lib.load().c2w_guidance(_p(x), _p(eps), _p(yobs), _p(stdv), nobs, F, H, W, s_step, t_step, mu, sigma, gamma, _stream()),
           "c2w_guidance")
 

@@ -41,9 +41,9 @@ class PoolStrideOperator:
 
 
 def per_channel_std(std, y) -> Optional[torch.Tensor]:
-    """The observation noise as the fused guidance kernel indexes it -- one value, or one per variable -- or None when ``std``
-    broadcasts against ``err = y - A(x0)`` of shape (nobs, F, h, w) in any other way (src/thor/score.py:55: ``std**2``
-    broadcasts like any tensor; the experiments pass (1, F, 1, 1), exp/downscaling.py:236-242)."""
+    """``std`` (likewise ``gamma``) as the fused guidance kernel indexes it -- one value, or one per variable -- or None when it
+    broadcasts against ``err = y - A(x0)`` of shape (nobs, F, h, w) in any other way (src/thor/score.py:55: ``std**2`` and ``gamma``
+    broadcast like any tensor; the experiments pass floats or (1, F, 1, 1) tensors, exp/downscaling.py:219-242)."""
     std = torch.as_tensor(std, dtype=torch.float32)
     if std.numel() == 1:
         return std.reshape(1)
@@ -51,6 +51,9 @@ def per_channel_std(std, y) -> Optional[torch.Tensor]:
     if F is not None and std.numel() == F and std.dim() >= 3 and tuple(std.shape[-3:]) == (F, 1, 1):
         return std.reshape(F)
     return None
+
+
+per_channel = per_channel_std  # the same rule serves gamma
 
 
 class AbstractScoreFunction:
@@ -101,16 +104,17 @@ class AbstractScoreFunction:
             # the observation follows the state: the reference keeps both on the host, the device-resident sampler in HBM
             yy = y.to(x.device) if isinstance(y, torch.Tensor) else y
             sd = std.to(x.device) if isinstance(std, torch.Tensor) else std
+            gm = gamma.to(x.device) if isinstance(gamma, torch.Tensor) else gamma  # (1, F, 1, 1) for list-valued settings (exp/downscaling.py:228-233)
             err = yy - A(x0_pred)
-            var = sd**2 + gamma * (sigma / mu) ** 2
+            var = sd**2 + gm * (sigma / mu) ** 2
             return -(err**2 / var).sum() / 2, (eps_pred, sigma)
 
         self.likelihood = log_p
         self._fused_guidance = None
         if isinstance(A, PoolStrideOperator) and not exact_grad:
-            std_c = per_channel_std(std, y)
-            if std_c is not None:  # any other broadcastable std (per pixel, per observation, ...) takes the autograd path above
-                self._fused_guidance = dict(A=A, y=y, std=std_c, gamma=float(gamma))
+            std_c, gam_c = per_channel_std(std, y), per_channel(gamma, y)
+            if std_c is not None and gam_c is not None:  # any other broadcastable std / gamma (per pixel, per observation, ...) takes the autograd path above
+                self._fused_guidance = dict(A=A, y=y, std=std_c, gamma=float(gam_c) if gam_c.numel() == 1 else gam_c)
         return self
 
     def _guided_fused(self, x, t):
@@ -122,15 +126,16 @@ class AbstractScoreFunction:
             g["y_dev"] = g["y"].to(device=dev, dtype=torch.float32).contiguous()
             std = g["std"].to(dev)
             g["std_dev"] = (std.expand(F) if std.numel() == 1 else std).contiguous()
+            g["gamma_dev"] = g["gamma"].to(dev).contiguous() if isinstance(g["gamma"], torch.Tensor) else g["gamma"]  # one per variable, or a float
             g["dev"] = dev
         eps = self.score_fn(xd, t)
         mu, sigma = self.noise_process._mu_sigma_f(float(t))
         nobs = g["y_dev"].shape[0]
         if xd.dim() == 5:  # co-sampled ensemble members: the same observation guides every member, frame-locally
             for m in range(xd.shape[0]):
-                ops.guidance(xd[m], eps[m], g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma"])
+                ops.guidance(xd[m], eps[m], g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma_dev"])
         else:
-            ops.guidance(xd, eps, g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma"])
+            ops.guidance(xd, eps, g["y_dev"], g["std_dev"], nobs, F, H, W, g["A"].s_step, g["A"].t_step, mu, sigma, g["gamma_dev"])
         return eps if x.device == dev else eps.to(x.device)
 
 

@@ -118,7 +118,11 @@ class TimeShardedScoreFunction(BatchedScoreFunction):
         if std is None:
             raise NotImplementedError("time-sharded guidance takes a scalar std or one value per variable, shape (1, F, 1, 1)")
         std = std.to(self.device)
-        self._guide = dict(A=A, y=y_loc, std=std, gamma=float(gamma), off=first - self.s, nobs=nobs)
+        gam = per_channel_std(gamma, y)  # a float, or one value per variable as exp/downscaling.py:228-233 builds it
+        if gam is None:
+            raise NotImplementedError("time-sharded guidance takes a scalar gamma or one value per variable, shape (1, F, 1, 1)")
+        gam = float(gam) if gam.numel() == 1 else gam.to(self.device).contiguous()
+        self._guide = dict(A=A, y=y_loc, std=std, gamma=gam, off=first - self.s, nobs=nobs)
         return self
 
     @property

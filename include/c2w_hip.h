@@ -253,6 +253,10 @@ int c2w_sampler_correct(float* x, const float* eps, const float* z, const float*
  * (src/thor/score.py:24-57): eps -= sigma/mu * A^T((y - A((x - sigma eps)/mu)) / (std_c^2 + gamma (sigma/mu)^2)), in place */
 int c2w_guidance(const float* x, float* eps, const float* yobs, const float* stdv, int nobs, int F, int H, int W,
                  int s_step, int t_step, float mu, float sigma, float gamma, void* stream);
+/* the same with one gamma per variable, gammav[F] in device memory: what exp/downscaling.py:228-233 hands condition_on for a
+ * list-valued `likelihood_gamma` (a (1, C, 1, 1) tensor that src/thor/score.py:55 broadcasts against err) */
+int c2w_guidance_per_variable(const float* x, float* eps, const float* yobs, const float* stdv, const float* gammav, int nobs,
+                              int F, int H, int W, int s_step, int t_step, float mu, float sigma, void* stream);
 /* the measurement operator itself: y[o][c][ph][pw] = mean of the s x s cell of x[o*t_step][c] (exp/downscaling.py:129-132) */
 int c2w_pool_stride(const float* x, float* y, int nobs, int F, int H, int W, int s_step, int t_step, void* stream);
 /* per-variable affine map over (planes = L*F) planes of HW values: y = x * scale[c] + shift[c], c = plane % F -- the quantile

@@ -387,7 +387,8 @@ def guidance(x, eps, yobs, stdv, nobs, F, H, W, s_step, t_step, mu, sigma, gamma
     Ev = eps.reshape(-1)[: L * F * H * W].view(L, F, H, W)
     x0 = (X[::t_step][:nobs] - sigma * Ev[::t_step][:nobs]) / mu
     err = yobs.reshape(nobs, F, H // s_step, W // s_step) - torch.nn.functional.avg_pool2d(x0, s_step)
-    var = stdv.reshape(1, F, 1, 1) ** 2 + gamma * (sigma / mu) ** 2
+    gam = gamma.reshape(1, F, 1, 1) if isinstance(gamma, torch.Tensor) else gamma
+    var = stdv.reshape(1, F, 1, 1) ** 2 + gam * (sigma / mu) ** 2
     g = (err / var).repeat_interleave(s_step, 2).repeat_interleave(s_step, 3) / (s_step * s_step)
     Ev[::t_step][:nobs] -= sigma * g / mu
 

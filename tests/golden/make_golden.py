@@ -229,6 +229,53 @@ def full_net_fingerprint():
     np.savez_compressed(os.path.join(HERE, "full_net_slice.npz"), y_slice=y[:, :, ::16, ::16].numpy())
 
 
+def sampler_tensor_gamma():
+    """Guided trajectories with the per-variable ``gamma`` the reference driver builds for a list-valued ``likelihood_gamma``
+    (exp/downscaling.py:228-233: ``torch.zeros(1, C, 1, 1)`` filled per variable; src/thor/score.py:55 broadcasts it): the same tiny
+    net, observation, std and noise draws as sampler(), written to a file of its own so sampler.npz stays byte for byte what it was."""
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **TINY)
+    g0 = np.load(os.path.join(HERE, "tiny_net.npz"))
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), g0["sd." + k]), k
+    s0 = np.load(os.path.join(HERE, "sampler.npz"))
+    pipe = pipelines.SDAPipeline()
+    L, Fv, k, H = 9, 2, 1, 32
+
+    def A(x):
+        return torch.nn.functional.avg_pool2d(x[::2], 8)
+
+    y_obs, std = torch.from_numpy(s0["y_obs"]), torch.from_numpy(s0["std"])
+    gamma = torch.zeros(1, Fv, 1, 1)
+    for c, gv in enumerate([1e-2, 2.5e-1]):  # as exp/downscaling.py:229-231 fills it
+        gamma[:, c, ...] = gv
+    out = {"gamma": gamma.numpy()}
+    for name, corrections, exact in [("cond_c0_gvec", 0, False), ("cond_c1_gvec_exact", 1, True)]:
+        torch.manual_seed(1)
+        noise = torch.randn(L, Fv, H, H)
+        assert np.array_equal(noise.numpy(), s0["cond_c0.noise"])
+        state = torch.get_rng_state()
+        sf = score.DefaultScoreFunction(net, markov_order=k, noise_process=pipe)
+        sfb = score.BatchedScoreFunction(net, markov_order=k, batch_size=4, device=CPU, noise_process=pipe)
+        sf.condition_on(A=A, y=y_obs, std=std, gamma=gamma, exact_grad=exact)
+        sfb.condition_on(A=A, y=y_obs, std=std, gamma=gamma, exact_grad=exact)
+        xs = pipe.sample(sf, noise, steps=4, corrections=corrections, tau=0.5, device=CPU, show_progressbar=False)
+        torch.set_rng_state(state)
+        xb = pipe.sample(sfb, noise, steps=4, corrections=corrections, tau=0.5, device=CPU, show_progressbar=False)
+        assert (xs - xb).abs().max() <= 1e-5 * xs.abs().max(), (name, (xs - xb).abs().max())  # Default == Batched up to fp32 summation order
+        torch.set_rng_state(state)
+        zs = [torch.empty_like(noise).normal_().numpy() for _ in range(4 * corrections)]
+        out[name + ".x"] = xs.numpy()
+        if zs:
+            out[name + ".z"] = np.stack(zs)
+        print(name, "max|x|", xs.abs().max().item(), "vs scalar-gamma trajectory", np.abs(xs.numpy() - s0["cond_c0.x"]).max())
+    # one guided score evaluation (the term the fused kernel computes), exact_grad=False
+    sf = score.DefaultScoreFunction(net, markov_order=k, noise_process=pipe)
+    sf.condition_on(A=A, y=y_obs, std=std, gamma=gamma, exact_grad=False)
+    out["score_guided_gvec"] = sf(torch.from_numpy(s0["score_x"]), torch.tensor(0.7)).numpy()
+    np.savez_compressed(os.path.join(HERE, "sampler_gamma.npz"), **out)
+
+
 # Representative gradient tensors of the default network (SURVEY.md A1) kept as strided slices: the network-input conv, a residual
 # conv at full resolution, a stride-2 head, the up-conv back to full resolution, the output conv, attention qkv / proj, a modulation
 # projection and the time MLP.  (step over dim 0, step over dim 1)
@@ -293,12 +340,15 @@ if __name__ == "__main__":
         full_net_gradients()
     elif sys.argv[1:] == ["tiny_net_relu"]:
         tiny_net_relu()
+    elif sys.argv[1:] == ["sampler_tensor_gamma"]:
+        sampler_tensor_gamma()
     else:
         kats()
         ops()
         net = tiny_net()
         tiny_net_relu()
         sampler(net)
+        sampler_tensor_gamma()
         ema_kat()
         full_net_fingerprint()
         full_net_gradients()

@@ -127,6 +127,34 @@ def test_sampler_trajectories_vs_golden(golden_dir, name, corrections, cond, exa
     assert (xs.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("name,corrections,exact,op", [("cond_c0_gvec", 0, False, "pool"), ("cond_c0_gvec", 0, False, "generic"),
+                                                       ("cond_c1_gvec_exact", 1, True, "pool")])
+@pytest.mark.parametrize("fused", [True, False])
+def test_sampler_trajectories_with_per_variable_gamma(golden_dir, name, corrections, exact, op, fused):
+    """condition_on(gamma=<(1, F, 1, 1) tensor>), the form exp/downscaling.py:228-233 builds for a list-valued likelihood_gamma
+    (src/thor/score.py:55 broadcasts it), with the tensor handed over on the HOST as the reference driver does: fused guidance
+    kernel (per-variable gamma vector), generic-operator autograd route, exact gradient -- against the imported reference's
+    trajectories (tests/golden/sampler_gamma.npz)."""
+    s, sg = _golden(golden_dir, "sampler.npz"), _golden(golden_dir, "sampler_gamma.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    dev = torch.device("cuda", 0)
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=dev, noise_process=pipe)
+    A = PoolStrideOperator(8, 2) if op == "pool" else (lambda z: F.avg_pool2d(z[::2], 8))
+    gamma = torch.from_numpy(sg["gamma"])
+    assert gamma.shape == (1, 2, 1, 1) and not gamma.is_cuda
+    sf.condition_on(A=A, y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]), gamma=gamma, exact_grad=exact)
+    assert (sf._fused_guidance is not None) == (op == "pool" and not exact)
+    sf.device_resident = fused
+    zs = [torch.from_numpy(z) for z in sg[name + ".z"]] if corrections else None
+    xs = pipe.sample(sf, torch.from_numpy(s["cond_c0.noise"]), steps=4, corrections=corrections, tau=0.5,
+                     device=dev if fused else torch.device("cpu"), show_progressbar=False, z_draws=zs)
+    ref = torch.from_numpy(sg[name + ".x"])
+    assert (xs.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+    # and it is not the scalar-gamma trajectory
+    assert (ref - torch.from_numpy(s["cond_c0.x"])).abs().max().item() > 1e-2 * ref.abs().max().item()
+
+
 def test_score_functions_vs_golden(golden_dir):
     s = _golden(golden_dir, "sampler.npz")
     net = _tiny().eval()
@@ -240,6 +268,18 @@ def test_guidance_kernel_vs_emulation_and_autograd(L, Fv, H, s_step, t_step):
     logp = -(err ** 2 / var).sum() / 2
     (J,) = torch.autograd.grad(logp, xa)
     assert torch.allclose(e.cpu(), eps - sigma * J, rtol=1e-4, atol=1e-5)
+    # one gamma per variable (exp/downscaling.py:228-233): c2w_guidance_per_variable
+    gvec = torch.rand(Fv, generator=gen) * 0.2 + 1e-3
+    e2 = eps.cuda()
+    ops.guidance(x.cuda(), e2, yobs.cuda(), std.cuda(), nobs, Fv, H, H, s_step, t_step, mu, sigma, gvec.cuda())
+    var = std.view(1, Fv, 1, 1) ** 2 + gvec.view(1, Fv, 1, 1) * (sigma / mu) ** 2
+    xa = x.clone().requires_grad_(True)
+    logp = -((yobs - F.avg_pool2d(((xa - sigma * eps) / mu)[::t_step], s_step)) ** 2 / var).sum() / 2
+    (J,) = torch.autograd.grad(logp, xa)
+    assert torch.allclose(e2.cpu(), eps - sigma * J, rtol=1e-4, atol=1e-5)
+    e3 = eps.cuda()  # a constant vector == the scalar entry point, bit for bit
+    ops.guidance(x.cuda(), e3, yobs.cuda(), std.cuda(), nobs, Fv, H, H, s_step, t_step, mu, sigma, torch.full((Fv,), gamma).cuda())
+    assert torch.equal(e3, e)
 
 
 # ------------------------------------------------------------------------------------------------ time-sharded sampler (f1)

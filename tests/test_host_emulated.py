@@ -244,6 +244,41 @@ def test_score_function_and_sampler_match_golden(emu, golden_dir):
             assert (xs - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), (name, fused)
 
 
+def test_condition_on_per_variable_gamma_matches_reference(emu, golden_dir):
+    """condition_on(gamma=<(1, F, 1, 1) tensor>) -- what exp/downscaling.py:228-233 builds for a list-valued likelihood_gamma and
+    src/thor/score.py:55 broadcasts -- on the fused guidance kernel, on the generic operator route and with exact_grad=True, against
+    trajectories of the imported reference (tests/golden/sampler_gamma.npz)."""
+    s, sg = _golden(golden_dir, "sampler.npz"), _golden(golden_dir, "sampler_gamma.npz")
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    y_obs, std, gamma = torch.from_numpy(s["y_obs"]), torch.from_numpy(s["std"]), torch.from_numpy(sg["gamma"])
+
+    def A_generic(z):
+        return F.avg_pool2d(z[::2], 8)
+
+    for name, corrections, exact, A, fused_kernel in [("cond_c0_gvec", 0, False, PoolStrideOperator(8, 2), True),
+                                                      ("cond_c0_gvec", 0, False, A_generic, False),
+                                                      ("cond_c1_gvec_exact", 1, True, PoolStrideOperator(8, 2), False)]:
+        sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+        sf.condition_on(A=A, y=y_obs, std=std, gamma=gamma, exact_grad=exact)
+        assert (sf._fused_guidance is not None) == fused_kernel
+        zs = [torch.from_numpy(z) for z in sg[name + ".z"]] if corrections else None
+        for fused in (True, False):
+            sf.device_resident = fused
+            xs = _sample(pipe, sf, torch.from_numpy(s["cond_c0.noise"]), corrections, zs, torch.device("cpu"), fused)
+            ref = torch.from_numpy(sg[name + ".x"])
+            assert (xs - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), (name, fused)
+    # one guided evaluation; a gamma that is neither a scalar nor per variable (here per pixel) takes the autograd route
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)
+    sf.condition_on(A=PoolStrideOperator(8, 2), y=y_obs, std=std, gamma=gamma, exact_grad=False)
+    out = sf(torch.from_numpy(s["score_x"]), torch.tensor(0.7))
+    ref = torch.from_numpy(sg["score_guided_gvec"])
+    assert (out - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    sf.condition_on(A=PoolStrideOperator(8, 2), y=y_obs, std=std, gamma=torch.full((1, 1, 4, 4), 0.01), exact_grad=False)
+    assert sf._fused_guidance is None
+    sf(torch.from_numpy(s["score_x"]), torch.tensor(0.7))
+
+
 def test_fused_guidance_only_for_per_variable_std(emu, golden_dir):
     """The guidance kernel indexes std by variable.  Any other broadcastable shape (src/thor/score.py:55 broadcasts ``std**2``
     like any tensor) must take the generic autograd route and give what the reference's formula gives -- here a per-pixel std
@@ -330,8 +365,9 @@ def test_time_sharded_sampler_two_ranks_equals_reference_trajectory(golden_dir, 
     s = _golden(golden_dir, "sampler.npz")
     r0, r1 = (torch.load(tmp_path / f"shard{r}.pt", weights_only=False) for r in (0, 1))
     assert r0["uncond_c0.bounds"] == [(0, 5), (5, 9)]
-    for name in ("uncond_c0", "uncond_c1", "cond_c0"):
-        ref = torch.from_numpy(s[name + ".x"])
+    sg = _golden(golden_dir, "sampler_gamma.npz")  # per-variable gamma as exp/downscaling.py:228-233 builds it
+    for name in ("uncond_c0", "uncond_c1", "cond_c0", "cond_c0_gvec"):
+        ref = torch.from_numpy(sg[name + ".x"] if name.endswith("_gvec") else s[name + ".x"])
         assert torch.equal(r0[name], r1[name]), name  # gather=True: every rank holds the whole trajectory
         assert (r0[name] - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), name
 

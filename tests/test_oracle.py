@@ -137,6 +137,32 @@ def test_window_fold_unfold_and_sampler(golden_dir):
         assert (x - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), name
 
 
+def test_sampler_with_per_variable_gamma(golden_dir):
+    """gamma as the (1, F, 1, 1) tensor exp/downscaling.py:228-233 builds for a list-valued likelihood_gamma
+    (src/thor/score.py:55 broadcasts it): trajectories of the imported reference, tests/golden/make_golden.py::sampler_tensor_gamma."""
+    g = _load(golden_dir, "tiny_net.npz")
+    s = _load(golden_dir, "sampler.npz")
+    sg = _load(golden_dir, "sampler_gamma.npz")
+    sd = _tiny_sd(g)
+    net = lambda a, b: ou.score_unet_forward(sd, a, b, **TINY)
+
+    def A(x):
+        return F.avg_pool2d(x[::2], 8)
+
+    y_obs, std, gamma = _t(s["y_obs"]), _t(s["std"]), _t(sg["gamma"])
+    assert gamma.shape == (1, 2, 1, 1)
+    for name, corrections, exact in [("cond_c0_gvec", 0, False), ("cond_c1_gvec_exact", 1, True)]:
+        fn = od.GuidedScore(net, 1, A, y_obs, std, gamma, exact, batch_size=4)
+        zs = [_t(z) for z in sg[name + ".z"]] if corrections else None
+        x = od.sample(fn, _t(s["cond_c0.noise"]), steps=4, corrections=corrections, tau=0.5, z_draws=zs)
+        ref = _t(sg[name + ".x"])
+        assert (x - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), name
+    fn = od.GuidedScore(net, 1, A, y_obs, std, gamma, False, batch_size=4)
+    out = fn(_t(s["score_x"]), torch.tensor(0.7))
+    ref = _t(sg["score_guided_gvec"])
+    assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
 def test_ema_and_adamw(golden_dir):
     g = _load(golden_dir, "ema.npz")
     for rate in (0.9, 0.999):
