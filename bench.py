@@ -83,11 +83,13 @@ def visible_gpus(run=subprocess.run):
         return None
 
 
-def launch(a, popen=subprocess.Popen, count=visible_gpus, grace=15.0) -> int:
+def launch(a, popen=subprocess.Popen, count=visible_gpus, grace=15.0, straggler_grace=120.0) -> int:
     """`--gpus N` without a launcher's environment: one child process per GPU (what fabric.launch() does for the reference,
     train.py:93-100), rendezvous on 127.0.0.1, rank 0's stdout is relayed, everything else goes to stderr.  This parent makes no HIP
     call; the children are fresh interpreters.  A rank that dies takes the job down: the survivors (stuck in the rendezvous or in a
-    collective) are killed `grace` seconds later and the exit status is the failure's."""
+    collective) are killed `grace` seconds later and the exit status is the failure's.  A rank that is still running
+    `straggler_grace` seconds after the FIRST rank has exited cleanly (every rank leaves the same barrier; one stuck in
+    destroy_process_group or a collective would otherwise keep this loop spinning forever) is killed too and the job fails."""
     import threading
     visible = count()
     if visible is not None and visible < a.gpus:
@@ -106,23 +108,28 @@ def launch(a, popen=subprocess.Popen, count=visible_gpus, grace=15.0) -> int:
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].communicate()[0]), daemon=True)  # drains rank 0's pipe while we watch
     reader.start()
-    deadline = None
+    deadline, failed_armed, killed = None, False, False
     while True:
         rcs = [p.poll() for p in procs]
         if all(rc is not None for rc in rcs):
             break
-        if deadline is None and any(rc not in (None, 0) for rc in rcs):
-            deadline = time.time() + grace
+        if not failed_armed and any(rc not in (None, 0) for rc in rcs):
+            failed_armed = True
+            deadline = time.time() + grace if deadline is None else min(deadline, time.time() + grace)
+        elif deadline is None and any(rc == 0 for rc in rcs):
+            deadline = time.time() + straggler_grace
         if deadline is not None and time.time() >= deadline:
             for p in procs:
                 if p.poll() is None:
                     p.kill()
+                    killed = True
             deadline = float("inf")
         time.sleep(0.05)
     reader.join(timeout=30)
     sys.stdout.write((out0[0] if out0 and out0[0] else b"").decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    rc = max(abs(rc) for rc in rcs)
+    return rc if rc or not killed else 1  # a straggler that had to be killed is a failure even if every other rank exited 0
 
 
 # ----------------------------------------------------------------------------------------------------------------- kernel timing

@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // NOT for values that come straight out of the matrix core: hipcc's hazard recognizer does not look into an asm statement, so the wait
 // states between an MFMA and the first read of its result are missing and the conversion reads the registers too early (seen: NaNs in
 // the attention output product).  Such values go through pack_acc2 (the compiler's own conversion, hazards handled);
-// tests/test_kernel_resources.py looks for an MFMA result feeding an asm conversion in the ISA of every kernel.
+// climate2weather_amd/build.py (isa_checks.py) looks for an MFMA result feeding an asm conversion in the ISA of every kernel it compiles and refuses to link one.
 __device__ __forceinline__ uint32_t pack_bf16x2_plain(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((c2w_f32x2_t){lo, hi}, c2w_bf16x2_t));
 }

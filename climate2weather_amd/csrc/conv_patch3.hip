@@ -21,7 +21,7 @@
 //     kernels the residual / multiplier rows of BOTH 8-row blocks are requested before the first block is finished.
 // MFMA shape and the epilogue (conv_epilogue.h) are those of conv_patch_half_kernel; A = weights, B = pixels.
 // Nothing may spill: scratch loads return out of order with the LDS-DMA loads and break the counted vmcnt waits (seen once as wrong
-// weight rows at chunk boundaries with 40 spilled registers; tests/test_kernel_resources.py guards it at build time).
+// weight rows at chunk boundaries with 40 spilled registers; build.py refuses to link such an object: isa_checks.py).
 //
 // The schedule / epilogue experiments that were measured and rejected (two-group wave schedule, four-slot ring, direct stores from
 // the accumulators, staggered workgroup start, LDS-DMA placement variants, the 4-wave and 8-row-tile forms), the ablation and
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // fragment read offsets.  A: row = wm*64 + m*16 + li, its swizzle depends on (row >> 2) & 3 = (li >> 2) & 3 only, not on m, so
     // A[m] = offA + m * 1024; B: pixel (wn*4*NB + n + kh, li + kw): offB[kw] + (n + kh) * pitch; k-half 1 flips slot bit 2.
     const uint32_t offA_held = (uint32_t)(CF::PBYTES + (wm * 64 + li) * 64 + (((uint32_t)lg ^ t3_wswz(li)) << 4));
-    // NOTE the second form (the base recomputed from the lane id: what a schedule without a register to hold it would do), taken
-    // only by the packed-weights LayerNorm-backward instantiation.  The kernel sits at exactly 128 VGPRs; without these dead statements hipcc (ROCm 7.2) allocates the bf16 LayerNorm-
-    // emission instantiation differently and spills one register inside the loop -- which the counted vmcnt waits do not survive.
-    // tests/test_kernel_resources.py fails the build on any spill; keep the two together.
+    // Register budget (128 VGPRs = four waves per SIMD = two workgroups per CU): the A-fragment base is HELD in a register except in the
+    // packed-weights LayerNorm-backward instantiation, which recomputes it per stage from the lane id (held, that instantiation needs
+    // 130).  Neither a spill nor a 129th register can ship: climate2weather_amd/build.py refuses to link this translation unit if any
+    // kernel with hand-counted vmcnt waits uses scratch or if a conv_patch_t3 instantiation exceeds 128 VGPRs (isa_checks.py).
     auto offA_at = [&]() {
         if constexpr (!(WPK && EPI == 3)) return offA_held;  // packed LayerNorm backward: recomputed per stage (held, it spills 2 registers)
         int l = lane;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         // own lgkmcnt waits at their first use, and it sinks MFMAs below the barrier -- with the packed 16-bit conversions of round 3
         // it left stage 5's last weight fragment (a[3], first used after the barrier) outstanding across the barrier of stage 6, and
         // about one forward in 200 under four concurrent streams computed (tap 7, m = 3) with tap 8's weights for one wave
-        // (profiles/r03_experiments.md "weight ring race"; tests/test_kernel_resources.py checks every barrier of every LDS-DMA
+        // (profiles/r03_experiments.md "weight ring race"; build.py / isa_checks.py checks every barrier of every LDS-DMA
         // kernel in the ISA).  Measured cost of the explicit wait: none (step 48.45 ms either way).
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

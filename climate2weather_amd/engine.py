@@ -194,10 +194,11 @@ class Engine:
         # stage-major packed copies of the 3x3 weights for the 16x16-tile kernel (ops.pack_conv_weights_batched): "f" forward operands
         # (from the 16-bit shadow), "d" input-gradient operands (from the transposed copies); (kind, dtype) -> buffer / version / table
         self._pk: Dict[tuple, torch.Tensor] = {}
-        self._pk_ver: Dict[tuple, object] = {}
         self._pk_tab: Dict[tuple, tuple] = {}
         self._pk_ok: Dict[tuple, bool] = {}    # launch geometry -> does c2w_conv_forward take packed weights there
-        self._pk_want: Dict[tuple, set] = {}   # (kind, dtype) -> names of the matrices that are kept packed
+        self._pk_want: Dict[tuple, dict] = {}   # (kind, dtype) -> {name of a matrix that is kept packed: weight version of its copy}
+        self._pk_desc: Dict[tuple, torch.Tensor] = {}  # ((kind, dtype), names) -> descriptor table of one pack launch
+        self._pk_sync: Dict[tuple, tuple] = {}  # (kind, dtype) -> (event behind the last pack launch, ids of the streams ordered behind it)
         self.use_packed_weights = os.environ.get("C2W_NO_WPACKED") is None
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
@@ -240,10 +241,11 @@ class Engine:
         self._dg_desc.clear()
         self._wpad.clear()
         self._pk.clear()
-        self._pk_ver.clear()
         self._pk_tab.clear()
         self._pk_ok.clear()
         self._pk_want.clear()
+        self._pk_desc.clear()
+        self._pk_sync.clear()
         self._gwpad.clear()
 
     def is_attached(self, net) -> bool:
@@ -319,8 +321,10 @@ class Engine:
         self.refresh_version()
         for rec in self.layout.convs.values():
             self._w(rec, DTYPE_F32 if rec.lin else dt)
-            if self.use_packed_weights:
-                self._packed("f", rec, dt)
+        if self.use_packed_weights:
+            # only what earlier launches asked for (the levels the 16x16-tile kernel serves at the batch sizes seen so far), one launch;
+            # a matrix that a later geometry asks for first is packed on the stream that asks and the others wait on its event (_packed)
+            self.repack_wanted(dt)
 
     def _b(self, rec: ConvRec) -> torch.Tensor:
         return self.flat[rec.b_off:]
@@ -350,50 +354,74 @@ class Engine:
 
     def _packed(self, kind: str, rec: ConvRec, dt: int) -> Optional[torch.Tensor]:
         """Stage-major packed copy of ``rec``'s forward (kind "f") or input-gradient (kind "d") operand in the 16-bit format ``dt``, or
-        None when the matrix has none (1x1 / Linear / fp32 / the padded network-input operand).  All matrices of a kind are repacked by
-        ONE launch when the weights changed (after the shadow / the transposed copies they are made from)."""
+        None when the matrix has none (1x1 / Linear / fp32 / the padded network-input operand).
+
+        Addresses are STABLE: the buffer of a (kind, dtype) is laid out once for every eligible matrix (72 M elements = 144 MB of address
+        space, touched only where something is packed) and never reallocated, so a captured hipGraph that reads a packed matrix
+        (score_fn._score_graphed) stays valid when another launch geometry later asks for a matrix that was not packed before.  Only the
+        matrices some launch asked for are kept packed (at B = 128 the levels the 16x16-tile kernel serves hold 11 of the 72 M
+        parameters): one launch repacks all of them when the weights changed, one launch packs a newcomer."""
         if dt == DTYPE_F32 or rec.lin or rec.taps != 9:
             return None
         key = (kind, dt)
-        want = self._pk_want.setdefault(key, set())
-        if rec.name not in want:  # packed on demand: only the matrices some launch asked for (at B = 128 the levels the 16x16-tile
-            want.add(rec.name)    # kernel serves hold 11 of the 72 M parameters); a new one rebuilds the table once
-            self._pk_tab.pop(key, None)
-            self._pk.pop(key, None)
-            self._pk_ver.pop(key, None)
         tab = self._pk_tab.get(key)
-        if tab is None:
-            offs, rows_t, total = {}, [], 0
+        if tab is None:  # fixed offsets of every eligible matrix, in layout order
+            offs, total = {}, 0
             for r in self.layout.convs.values():
-                if r.lin or r.taps != 9 or r.name not in want:
+                if r.lin or r.taps != 9:
                     continue
                 if kind == "f":
                     if r.kstride != r.cin or r.cin % 32:
                         continue
-                    src, rows, k = r.w_off, r.rows, r.cin
+                    ent = (r.w_off, r.rows, r.cin)
                 else:
                     if r.dg_off < 0 or r.dg_ld % 32:
                         continue
-                    src, rows, k = r.dg_off, r.cin, r.dg_ld
-                offs[r.name] = total
-                rows_t += [src, total, rows, k]
-                total += ops.packed_conv_weights_numel(rows, k)
-            desc = torch.tensor(rows_t, dtype=torch.int64, device=self.flat.device) if rows_t else None
-            tab = self._pk_tab[key] = (offs, desc, len(rows_t) // 4, total)
-        offs, desc, n, total = tab
-        if rec.name not in offs:
+                    ent = (r.dg_off, r.cin, r.dg_ld)
+                offs[r.name] = (total,) + ent
+                total += ops.packed_conv_weights_numel(ent[1], ent[2])
+            tab = self._pk_tab[key] = (offs, total)
+        offs, total = tab
+        ent = offs.get(rec.name)
+        if ent is None:
             return None
         if kind == "f":
             src = self.shadow_for(dt)
         else:
             self._wT(rec, dt)  # refreshes the transposed copies if the weights changed
             src = self.dg[dt]
-        if key not in self._pk:
-            self._pk[key] = torch.empty(max(total, 1), dtype=TORCH_DTYPE[dt], device=self.flat.device)
-        if self._pk_ver.get(key) != self._version():
-            ops.pack_conv_weights_batched(src, self._pk[key], desc, n, dt)
-            self._pk_ver[key] = self._version()
-        return self._pk[key][offs[rec.name]:]
+        buf = self._pk.get(key)
+        if buf is None:
+            buf = self._pk[key] = torch.empty(max(total, 1), dtype=TORCH_DTYPE[dt], device=self.flat.device)
+        want = self._pk_want.setdefault(key, {})  # name -> weight version its packed copy was made from
+        ver = self._version()
+        if want.get(rec.name) != ver:
+            want[rec.name] = None
+            stale = tuple(n for n, v in want.items() if v != ver)  # everything wanted after an update; the newcomer alone otherwise
+            desc = self._pk_desc.get((key, stale))
+            if desc is None:
+                rows_t = [v for n in stale for v in (offs[n][1], offs[n][0], offs[n][2], offs[n][3])]
+                desc = self._pk_desc[(key, stale)] = torch.tensor(rows_t, dtype=torch.int64, device=self.flat.device)
+            ops.pack_conv_weights_batched(src, buf, desc, len(stale), dt)
+            for n in stale:
+                want[n] = ver
+            if buf.is_cuda:  # forwards on OTHER streams (score_fn: window batches alternate between streams) must see this launch
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pk_sync[key] = (ev, {torch.cuda.current_stream().cuda_stream})
+        elif buf.is_cuda and key in self._pk_sync:
+            ev, seen = self._pk_sync[key]
+            sid = torch.cuda.current_stream().cuda_stream
+            if sid not in seen:  # once per (pack launch, stream): order this stream behind the launch that wrote the copies
+                torch.cuda.current_stream().wait_event(ev)
+                seen.add(sid)
+        return buf[ent[0]:]
+
+    def repack_wanted(self, dt: int) -> None:
+        """Refresh, with one launch per kind, the packed copies earlier launches asked for (prepare_forward)."""
+        for (kind, d), want in self._pk_want.items():
+            if d == dt and want:
+                self._packed(kind, self.layout.convs[next(iter(want))], dt)
 
     def _conv_weights(self, kind: str, rec: ConvRec, dt: int, g: dict, fused_ln_bwd: bool = False):
         """(operand, wpacked flag) for a conv launch of geometry ``g``: the packed copy where the launch goes to the 16x16-tile kernel
@@ -401,7 +429,7 @@ class Engine:
         plain = self._w(rec, dt) if kind == "f" else self._wT(rec, dt)
         if not self.use_packed_weights or dt == DTYPE_F32:
             return plain, False
-        key = (kind, rec.name, dt, g["B"], g["Hin"], g["Win"], g["Hout"], g["Wout"], g["Cout"], g["mode"])
+        key = (kind, rec.name, dt, g["B"], g["Hin"], g["Win"], g["Hout"], g["Wout"], g["Cout"], g["mode"], ops.KNOBS_GENERATION)
         ok = self._pk_ok.get(key)
         if ok is None:
             ok = self._pk_ok[key] = bool(ops.conv_wpacked_supported(g, dt))

@@ -77,9 +77,14 @@ def pack_conv_weights_batched(src, dst, desc, n: int, dtype: int) -> None:
     check(_lib.load().c2w_pack_conv_weights_batched(_p(src), _p(dst), _p(desc), n, dtype, _stream()), "c2w_pack_conv_weights_batched")
 
 
+KNOBS_GENERATION = 0  # bumped by knobs_reload(): callers that memoise dispatch answers (engine._pk_ok) key them on it
+
+
 def knobs_reload() -> None:
     """Re-read the library's run-time knobs (C2W_* dispatch overrides) from the environment: it reads them once, at load."""
+    global KNOBS_GENERATION
     _lib.load().c2w_knobs_reload()
+    KNOBS_GENERATION += 1
 
 
 def conv_patch_supported(g: dict, dtype: int) -> bool:

@@ -71,13 +71,33 @@ def conv_pool2_supported(g, dtype):
     return conv_patch_supported(g, dtype) and g["mode"] == CONV_S1 and g["Win"] != 8
 
 
+PACKED_FROM_PIXELS = None  # tests set a pixel count: 3x3 launches with at least that many output pixels "take packed weights"
+
+
 def conv_wpacked_supported(g, dtype):
-    return False  # the emulation reads the plain [rows][taps][Cin] weights only: the engine never hands it a packed copy
+    """Off by default: the emulation reads the plain [rows][taps][Cin] weights.  With PACKED_FROM_PIXELS set it exercises the engine's
+    packed-copy bookkeeping (offsets, versions, stable addresses): pack_conv_weights_batched below stores every row XOR-ed with a tag,
+    which the emulated conv undoes when it is told the operand is the packed copy -- a plain operand passed as packed (or a stale
+    packed copy) gives wrong numbers."""
+    return PACKED_FROM_PIXELS is not None and g["mode"] in (CONV_S1, CONV_UP) and dtype != DTYPE_F32 and \
+        g["B"] * g["Hout"] * g["Wout"] >= PACKED_FROM_PIXELS
+
+
+def packed_conv_weights_numel(rows, cin):
+    return 9 * cin * ((rows + 127) // 128 * 128)
+
+
+def pack_conv_weights_batched(src, dst, desc, n, dtype):
+    for so, do, rows, k in desc.view(-1, 4)[:n].tolist():
+        m = rows * 9 * k
+        dst.reshape(-1)[do:do + m] = -src.reshape(-1)[so:so + m]  # "layout" of the emulated packed copy: the negated matrix
 
 
 def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False, kvalid=0,
          wpacked=False):
-    assert not wpacked
+    if wpacked:
+        assert conv_wpacked_supported(g, dtype)
+        return conv(x, -w.reshape(-1)[: g["wrows"] * 9 * g["Cin"]], bias, y, g, dtype, act, res, mul, mulmode, naive, y2, ln, lnf, pool2, kvalid)
     # kvalid: a promise that input channels >= kvalid are zero (the HIP kernels may skip them); the restatement multiplies everything
     if lnf is not None:  # second output: LN of the stored result (+ the consumer's modulation)
         assert ln is None and mul is None and y2 is None and act == ACT_NONE

@@ -43,7 +43,7 @@ class FakeProc:
         self.killed = True
 
 
-def _launch(n, rcs=None, hang=None, count=lambda: 8, grace=0.2):
+def _launch(n, rcs=None, hang=None, count=lambda: 8, grace=0.2, straggler_grace=0.3):
     procs = []
 
     def popen(argv, env=None, stdout=None):
@@ -53,7 +53,7 @@ def _launch(n, rcs=None, hang=None, count=lambda: 8, grace=0.2):
         procs.append(p)
         return p
     a = argparse.Namespace(gpus=n)
-    return bench.launch(a, popen=popen, count=count, grace=grace), procs
+    return bench.launch(a, popen=popen, count=count, grace=grace, straggler_grace=straggler_grace), procs
 
 
 def test_launcher_wires_one_rank_per_gpu(capsys, monkeypatch):
@@ -84,6 +84,18 @@ def test_launcher_reports_a_dead_rank_and_kills_the_ranks_it_leaves_stuck(monkey
     assert procs[0].killed and not procs[1].killed and rc == 9
     rc, procs = _launch(2, hang=1, rcs={0: 5}, grace=0.2)
     assert procs[1].killed and rc == 9
+
+
+def test_launcher_kills_a_rank_that_outlives_a_clean_exit(monkeypatch, capsys):
+    """Every rank exits 0 except one that hangs (destroy_process_group / a collective nobody joins any more): no rank FAILED, so the
+    failure deadline never arms -- the straggler deadline, armed by the first clean exit, ends the job and reports a failure, and
+    rank 0's line is still relayed (round-3 advice: this case used to spin forever)."""
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    rc, procs = _launch(2, rcs={0: 0}, hang=1, straggler_grace=0.3)
+    assert procs[1].killed and not procs[0].killed and rc == 9
+    assert capsys.readouterr().out == '{"metric": "m", "n_gpus": 2}\n'
+    rc, procs = _launch(3, hang=0, straggler_grace=0.3)  # rank 0 itself is the straggler
+    assert procs[0].killed and rc == 9
 
 
 def test_launcher_refuses_more_ranks_than_gpus_and_never_calls_hip(monkeypatch, capsys):

@@ -211,6 +211,60 @@ def test_weight_caches_follow_writes_through_the_parameters(emu, golden_dir, pre
         assert torch.equal(a.grad, b.grad), n
 
 
+def test_packed_weight_copies_keep_their_addresses_and_follow_the_weights(emu, golden_dir, monkeypatch):
+    """The stage-major packed copies (engine._packed; here the emulation's stand-in layout) are handed to launches above a size
+    threshold.  (i) results equal the plain-operand run; (ii) a geometry that asks for more matrices later must not move the copies
+    a captured hipGraph may still be reading -- the buffer and every offset stay where they were (round-3 advice: the buffer used to be
+    reallocated); (iii) a weight update refreshes exactly the copies that are in use; (iv) prepare_forward packs nothing new."""
+    g = _golden(golden_dir, "tiny_net.npz")
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    hc = [64, 128]
+
+    def run(net, xx):
+        net.zero_grad()
+        loss = od.loss(net, xx, t, eps[:, :, : xx.shape[-2], : xx.shape[-1]]).mean()
+        loss.backward()
+        return loss.item(), [p.grad.clone() for p in net.parameters()]
+
+    plain = _tiny(hidden_channels=hc)
+    plain.precision = "bf16"
+    ref16 = run(plain, x)
+    net = _tiny(hidden_channels=hc)
+    net.precision = "bf16"
+    monkeypatch.setattr(emu_ops, "PACKED_FROM_PIXELS", 2 * 16 * 16)  # only the 16x16 level of a 16x16 input "takes packed weights"
+    calls = []
+    orig = c2w_ops.pack_conv_weights_batched
+    monkeypatch.setattr(c2w_ops, "pack_conv_weights_batched", lambda src, dst, desc, n, dt: (calls.append(n), orig(src, dst, desc, n, dt)))
+    out = run(net, x)
+    assert out[0] == ref16[0] and all(torch.equal(a, b) for a, b in zip(out[1], ref16[1]))
+    eng = net._get_engine()
+    kf = ("f", c2w_ops.DTYPE_BF16)
+    want0 = set(eng._pk_want[kf])
+    assert want0 and all(".residue." in n or "tails" in n for n in want0) and len(want0) < sum(r.taps == 9 for r in eng.layout.convs.values())
+    ptr0 = eng._pk[kf].data_ptr()
+    offs0 = dict(eng._pk_tab[kf][0])
+    n_calls = len(calls)
+    eng.prepare_forward(c2w_ops.DTYPE_BF16)  # nothing changed: no launch, nothing new wanted
+    assert len(calls) == n_calls and set(eng._pk_want[kf]) == want0
+    # a larger input: the 32x32 -> 16x16 level now crosses the threshold too -> newcomers are packed, nothing moves
+    x32 = torch.from_numpy(g["x32"])[:2]
+    e32 = torch.randn(2, 6, 32, 32, generator=torch.Generator().manual_seed(0))
+    net.zero_grad()
+    l32 = od.loss(net, x32, t, e32).mean()
+    plain.zero_grad()
+    assert l32.item() == od.loss(plain, x32, t, e32).mean().item()
+    assert set(eng._pk_want[kf]) > want0 and eng._pk[kf].data_ptr() == ptr0 and dict(eng._pk_tab[kf][0]) == offs0
+    assert all(n <= len(eng._pk_want[kf]) - len(want0) or n <= len(eng._pk_want[("d", c2w_ops.DTYPE_BF16)]) for n in calls[n_calls:])
+    # weights change through the Parameter objects: the copies in use are refreshed, results follow
+    with torch.no_grad():
+        for p, q in zip(net.parameters(), plain.parameters()):
+            p.mul_(0.5)
+            q.mul_(0.5)
+    a, b = run(net, x), run(plain, x)
+    assert a[0] == b[0] and all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
+    assert eng._pk[kf].data_ptr() == ptr0
+
+
 def test_fp16_snapshot_module_round_trip_runs(emu):
     """training_loop.py:254-265 pickles ``deepcopy(ema).cpu().eval().requires_grad_(False).to(torch.float16)`` and
     exp/downscaling.py:110-126 unpickles it and calls it: the half-precision module object itself must run (the engine keeps
