@@ -61,6 +61,8 @@ _PROTOS = {
     "c2w_nchw_to_nhwc_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_windows_to_nhwc_noise": [c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_mse_loss_grad_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p],
+    "c2w_sq_err": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "c2w_sq_err_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_timestep_embedding": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],
     "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],

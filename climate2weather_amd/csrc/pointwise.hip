@@ -565,6 +565,52 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_tiled_kernel(const T* __rest
     }
 }
 
+// Unreduced training loss of the module path (src/thor/pipelines.py:35: ``(eps_pred - eps) ** 2``, the caller takes .mean()):
+// out[b][c][px] (NCHW fp32) = (y[b][px][c] - eps[b][c][px])^2 through the same LDS tile; eps read from memory (SQ == 1) or
+// regenerated from the step's Philox stream (SQ == 2: four consecutive pixels of a channel plane are one counter).  HW % 4 == 0.
+template <typename T, int SQ>
+__global__ __launch_bounds__(256) void sq_err_tiled_kernel(const T* __restrict__ y, const float* __restrict__ eps, float* __restrict__ out,
+                                                           float* __restrict__ loss_sum, int B, int C, int HW, int ldc, uint32_t k0, uint32_t k1) {
+    constexpr int P = Elem<T>::PER16;
+    extern __shared__ float lt_tile[];
+    const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P;
+    float local = 0.f;
+    for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
+        const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
+        const int npx = min(LT_PT, HW - p0);
+        for (int i = threadIdx.x; i < npx * nvec; i += 256) {
+            const int px = i / nvec, v = i - px * nvec;
+            float f[P];
+            unpack16<T>(*(const u32x4_t*)(y + ((size_t)b * HW + p0) * ldc + (size_t)i * P), f);
+#pragma unroll
+            for (int e = 0; e < P; ++e) lt_tile[(v * P + e) * LT_LD + px] = f[e];
+        }
+        __syncthreads();
+        const int q = threadIdx.x & (LT_PT / 4 - 1), cb = threadIdx.x / (LT_PT / 4);
+        if (4 * q < npx) {
+#pragma unroll 2
+            for (int c = cb; c < C; c += 256 / (LT_PT / 4)) {
+                const size_t o = ((size_t)b * C + c) * HW + p0 + 4 * q;
+                const f32x4_t e = SQ == 2 ? philox_normal4(k0, k1, (unsigned long long)o >> 2) : *(const f32x4_t*)(eps + o);
+                const float* t = lt_tile + c * LT_LD + 4 * q;
+                // eps as VALUES before the subtraction: without the (empty) asm statements hipcc contracts the Box-Muller product inside
+                // philox_normal4 with the difference (fma(-r, cos, y): one rounding less than y - eps of the materialised stream)
+                float e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+                const float d0 = t[0] - e0, d1 = t[1] - e1, d2 = t[2] - e2, d3 = t[3] - e3;
+                const f32x4_t sq = (f32x4_t){__fmul_rn(d0, d0), __fmul_rn(d1, d1), __fmul_rn(d2, d2), __fmul_rn(d3, d3)};
+                *(f32x4_t*)(out + o) = sq;
+                local += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+            }
+        }
+        __syncthreads();
+    }
+    if (loss_sum != nullptr) {  // sum of the tensor just written: the caller's .mean() without a second pass over it
+        local = wave_sum(local);
+        if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
+    }
+}
+
 // timestep_embedding (model/score.py:14-34): out[b] = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(max_period) i/half)
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim, float max_period) {
     const int half = dim / 2;
@@ -939,6 +985,31 @@ extern "C" int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, v
     DISPATCH_T(dtype, (mse_loss_grad_tiled_kernel<T, true><<<nblk, 256, lds, (hipStream_t)stream>>>(
                           (const T*)y, nullptr, (T*)dy, loss_sum, B, C, HW, ldc, gscale, scaler_state, (uint32_t)seed, (uint32_t)(seed >> 32))));
     return (int)hipGetLastError();
+}
+
+static int sq_err_launch(const void* y, const float* eps, unsigned long long seed, bool regen, float* out, float* loss_sum, int B, int C, int HW,
+                         int ldc, int dtype, void* stream) {
+    if (!y || !out || (!regen && !eps) || !vec_ok(dtype, ldc) || ldc < C) return C2W_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)ldc * LT_LD * sizeof(float);
+    if (lds > 64 * 1024 || (HW & 3) != 0 || ((uintptr_t)out & 15) != 0 || (eps && ((uintptr_t)eps & 15) != 0)) return C2W_ERR_UNSUPPORTED;
+    const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 4096);  // bounded: one atomic per wave
+    if (regen) {
+        DISPATCH_T(dtype, (sq_err_tiled_kernel<T, 2><<<nblk, 256, lds, (hipStream_t)stream>>>((const T*)y, nullptr, out, loss_sum, B, C, HW, ldc,
+                                                                                              (uint32_t)seed, (uint32_t)(seed >> 32))));
+    } else {
+        DISPATCH_T(dtype, (sq_err_tiled_kernel<T, 1><<<nblk, 256, lds, (hipStream_t)stream>>>((const T*)y, eps, out, loss_sum, B, C, HW, ldc, 0u,
+                                                                                              0u)));
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_sq_err(const void* y, const float* eps, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype, void* stream) {
+    return sq_err_launch(y, eps, 0ull, false, out, loss_sum, B, C, HW, ldc, dtype, stream);
+}
+
+extern "C" int c2w_sq_err_noise(const void* y, unsigned long long seed, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype,
+                                void* stream) {
+    return sq_err_launch(y, nullptr, seed, true, out, loss_sum, B, C, HW, ldc, dtype, stream);
 }
 
 extern "C" int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {

@@ -27,7 +27,23 @@ from . import ops
 from .nn import BlockSpec, LevelSpec
 from .ops import (ACT_NONE, ACT_RELU, ACT_RELU_PAIR, ACT_SILU, ACT_SILU_PAIR, CONV_1X1, CONV_S1, CONV_S2, CONV_TS2, CONV_UP, DTYPE_BF16, DTYPE_F16, DTYPE_F32, MUL_DSILU, MUL_PLAIN, TORCH_DTYPE)
 
+import weakref
+
 LN_EPS = 1e-5
+_ENGINE_BY_PARAM_ID: Dict[int, "weakref.ReferenceType"] = {}  # id(Parameter) -> weakref(Engine); nothing is stored ON the Parameter (they are pickled / deep-copied)
+
+
+def engine_of_parameter(p):
+    """The Engine whose flat buffer the Parameter OBJECT ``p`` is bound to, or None (optim.AdamW finds its engine through this).
+    An engine keeps its Parameters alive, so an id cannot be recycled while its entry is valid; the identity check covers the rest."""
+    ref = _ENGINE_BY_PARAM_ID.get(id(p))
+    eng = ref() if ref is not None else None
+    if eng is None:
+        _ENGINE_BY_PARAM_ID.pop(id(p), None)
+        return None
+    return eng if eng._bound_by_id.get(id(p)) is p else None
+
+
 ALIGN = 64  # elements; keeps every region 256-B aligned in fp32 and 128-B aligned in the bf16 shadow
 
 
@@ -230,6 +246,11 @@ class Engine:
         # `p.data = view` leaves each Parameter its own version counter: writes through the Parameter objects (torch.optim steps,
         # load_state_dict, EMA copies) never bump flat._version, so the cache key folds the Parameters' counters in (_version)
         self._bound = [params[name] for name in lay.views]
+        me = weakref.ref(self)
+        self._bound_by_id = {id(prm): prm for prm in self._bound}
+        for i in self._bound_by_id:
+            _ENGINE_BY_PARAM_ID[i] = me
+        self.generation = getattr(self, "generation", 0) + 1  # bumped per (re-)attach: holders of flat-layout plans re-validate
         self._pver = self._param_versions()
         self.flat = flat
         self.flat_grad = None

@@ -77,6 +77,7 @@ def pack_conv_weights_batched(src, dst, desc, n: int, dtype: int) -> None:
     check(_lib.load().c2w_pack_conv_weights_batched(_p(src), _p(dst), _p(desc), n, dtype, _stream()), "c2w_pack_conv_weights_batched")
 
 
+EMULATED = False  # tests/emu_ops.install sets it: the launchers below are PyTorch restatements running on CPU tensors
 KNOBS_GENERATION = 0  # bumped by knobs_reload(): callers that memoise dispatch answers (engine._pk_ok) key them on it
 
 
@@ -230,6 +231,20 @@ def mse_loss_grad_noise(y, seed, dy, loss_sum, B, C, HW, ldc, gscale, dtype, sca
     if rc == -3:
         return False
     check(rc, "c2w_mse_loss_grad_noise")
+    return True
+
+
+def sq_err(y, eps, out, loss_sum, B, C, HW, ldc, dtype) -> bool:
+    """out (B,C,H,W) fp32 = (y - eps)^2 from NHWC rows ``y``; loss_sum[0] += its sum; ``eps``: an fp32 (B,C,H,W) tensor, or an int seed
+    (the stream the *_noise launchers regenerate).  False if the shape is not supported (caller converts the layout and uses tensor
+    arithmetic)."""
+    if isinstance(eps, int):
+        rc = _lib.load().c2w_sq_err_noise(_p(y), int(eps), _p(out), _p(loss_sum), B, C, HW, ldc, dtype, _stream())
+    else:
+        rc = _lib.load().c2w_sq_err(_p(y), _p(eps), _p(out), _p(loss_sum), B, C, HW, ldc, dtype, _stream())
+    if rc == -3:
+        return False
+    check(rc, "c2w_sq_err")
     return True
 
 

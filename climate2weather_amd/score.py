@@ -35,10 +35,12 @@ class _TapeHolder:
     lives exactly as long as something references the holder or the context -- no global table, no finalizers (a context of
     a grad-disabled level can die between two ``setup_context`` calls of the same forward: seen under the reference's
     ``torch.func.jacrev(log_p)`` with ``exact_grad=False``)."""
-    __slots__ = ("tape",)
+    __slots__ = ("tape", "loss", "loss_sum")
 
-    def __init__(self):
+    def __init__(self, loss=None):
         self.tape = None
+        self.loss = loss  # fused-loss request of SDAPipeline.loss: dict(eps=<int seed | (B,C,H,W) tensor>, eta=float), else None
+        self.loss_sum = None
 
 
 class _ScoreUNetFn(torch.autograd.Function):
@@ -49,7 +51,10 @@ class _ScoreUNetFn(torch.autograd.Function):
     def forward(x, t, net, dt, holder, *params):
         eng = net._get_engine()
         tape = Tape()
-        y = eng.forward(x, t, dt, tape=tape, want_dx=True)
+        if holder.loss is not None:  # noise process + network + unreduced loss in one node (src/thor/pipelines.py:27-35)
+            y, holder.loss_sum = _forward_loss(eng, x, t, dt, holder.loss, tape)
+        else:
+            y = eng.forward(x, t, dt, tape=tape, want_dx=True)
         holder.tape = tape
         return y
 
@@ -58,7 +63,7 @@ class _ScoreUNetFn(torch.autograd.Function):
         x, t, net, dt, holder = inputs[:5]
         ctx.net = net
         ctx.tape = holder.tape
-        ctx.x_needs_grad = x.requires_grad
+        ctx.x_needs_grad = bool(getattr(x, "requires_grad", False)) and holder.loss is None
         ctx.set_materialize_grads(False)
 
     @staticmethod
@@ -78,15 +83,109 @@ class _ScoreUNetFn(torch.autograd.Function):
         eng.flat_grad = torch.zeros_like(eng.flat)
         try:
             dt = m["dt"]
-            gy = gy.contiguous().float()
             g_nhwc = torch.empty((m["B"] * m["H"] * m["W"], lay.cout_pad), dtype=TORCH_DTYPE[dt], device=gy.device)
-            ops.nchw_to_nhwc(gy, None, None, g_nhwc, m["B"], m["C"], m["H"] * m["W"], lay.cout_pad, dt)
+            if "loss" in m:
+                _loss_output_gradient(m, gy, g_nhwc, lay, dt)
+            else:
+                gy = gy.contiguous().float()
+                ops.nchw_to_nhwc(gy, None, None, g_nhwc, m["B"], m["C"], m["H"] * m["W"], lay.cout_pad, dt)
             dx = eng.backward(tape, g_nhwc, want_dx=ctx.x_needs_grad)
             fg = eng.flat_grad
         finally:
             eng.flat_grad = saved
         grads = tuple(torch.as_strided(fg, shape, strides, off) for (off, shape, strides) in lay.views.values())
         return (dx, None, None, None, None) + grads
+
+
+def _forward_loss(eng: Engine, x, t, dt: int, req: dict, tape: Optional[Tape]):
+    """The training-side composition of the reference in one launch sequence (src/thor/pipelines.py:22-35 around model/score.py:59-70):
+    x_t = mu(t) x + sigma(t) eps fused into the input conversion, the network, and the unreduced loss (eps_pred - eps)^2 written
+    straight from the network's NHWC output rows.  ``req["eps"]``: the seed of the regenerated noise stream, or the noise tensor.
+    Returns (loss tensor (B,C,H,W) fp32, 1-element sum of it)."""
+    from . import ops
+    lay = eng.layout
+    B, C, H, W = x.shape
+    dev = x.device
+    eps = req["eps"]
+    tt = t.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    if tt.numel() != B:
+        raise ValueError("the loss draws one t per batch item (src/thor/pipelines.py:29)")
+    musig = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    ops.mu_sigma(tt, musig, B, float(req["eta"]))
+    y = eng.forward(x, tt, dt, tape=tape, noise=(eps, musig), nhwc_out=True)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    if not ops.sq_err(y, eps, out, loss_sum, B, C, H * W, lay.cout_pad, dt):  # shape outside the fused kernel: layout pass + tensor arithmetic
+        yn = torch.empty_like(out)
+        ops.nhwc_to_nchw(y, yn, B, C, H * W, lay.cout_pad, dt)
+        out = (yn - _materialize_eps(eps, out)) ** 2
+        loss_sum = out.sum().reshape(1)
+    if tape is not None:
+        tape.meta["loss"] = dict(y=y, eps=eps)
+    return out, loss_sum
+
+
+def _materialize_eps(eps, like: torch.Tensor) -> torch.Tensor:
+    if not isinstance(eps, int):
+        return eps
+    from . import ops
+    e = torch.empty_like(like)
+    ops.philox_normal(e, e.numel(), eps)
+    return e
+
+
+def _loss_output_gradient(m: dict, gy: torch.Tensor, g_nhwc: torch.Tensor, lay, dt: int) -> None:
+    """d/dy of the unreduced loss (y - eps)^2 given the gradient ``gy`` of that tensor: g_nhwc = 2 (y - eps) gy.  ``.mean()`` (and a
+    GradScaler's scale on top) hands back ONE value broadcast over the tensor (stride 0: _LossTensor.mean below keeps it that way,
+    torch's own mean_backward materialises it): the fused loss-gradient kernel then reads the factor from device memory and eps is
+    regenerated -- no host synchronisation, no pass over ``gy``.  Any other gradient takes tensor arithmetic."""
+    from . import ops
+    B, C, H, W = m["B"], m["C"], m["H"], m["W"]
+    y, eps = m["loss"]["y"], m["loss"]["eps"]
+    dummy = torch.zeros(1, dtype=torch.float32, device=gy.device)
+    if gy.dtype == torch.float32 and all(s == 0 for s in gy.stride()):
+        if isinstance(eps, int):
+            if ops.mse_loss_grad_noise(y, eps, g_nhwc, dummy, B, C, H * W, lay.cout_pad, 2.0, dt, scaler=gy):
+                return
+            eps = _materialize_eps(eps, torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device))
+        ops.mse_loss_grad(y, eps.contiguous(), g_nhwc, dummy, B, C, H * W, lay.cout_pad, 2.0, dt, scaler=gy)
+        return
+    yn = torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device)
+    ops.nhwc_to_nchw(y, yn, B, C, H * W, lay.cout_pad, dt)
+    g = (2.0 * (yn - _materialize_eps(eps, yn)) * gy).contiguous().float()
+    ops.nchw_to_nhwc(g, None, None, g_nhwc, B, C, H * W, lay.cout_pad, dt)
+
+
+class _MeanOfLoss(torch.autograd.Function):
+    """mean() of the loss tensor from the sum its kernel already accumulated; the gradient goes back as ONE value broadcast over the
+    tensor (an expanded view), where ``mean_backward`` would write -- and the loss node would have to read -- all B*C*H*W copies."""
+
+    @staticmethod
+    def forward(ctx, sq, loss_sum):
+        ctx.shape = sq.shape
+        return (loss_sum / sq.numel()).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        return (g / n).reshape((1,) * len(ctx.shape)).expand(ctx.shape), None
+
+
+class _LossTensor(torch.Tensor):
+    """What the fused ``SDAPipeline.loss`` returns: the (B,C,H,W) tensor of squared errors, a plain tensor in every respect except
+    that a full ``.mean()`` (training_loop.py:377) is answered by _MeanOfLoss.  Every other operation sees an ordinary tensor."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.Tensor.mean, torch.mean) and len(args) == 1 and not kwargs and isinstance(args[0], _LossTensor):
+            ls = getattr(args[0], "_c2w_loss_sum", None)
+            if ls is not None:
+                return _MeanOfLoss.apply(args[0].as_subclass(torch.Tensor), ls)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
 
 
 class ScoreUNet(torch.nn.Module):
@@ -173,6 +272,17 @@ class ScoreUNet(torch.nn.Module):
         eng = self._get_engine()
         dt = self.compute_dtype()
         params = [p for _, p in self._ordered_params(eng)]
+        req = self.__dict__.pop("_loss_request", None)  # set by SDAPipeline.loss around this call: return the unreduced loss instead
+        if req is not None:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                holder = _TapeHolder(loss=req)
+                out = _ScoreUNetFn.apply(x, t, self, dt, holder, *params)
+                ls = holder.loss_sum
+            else:
+                out, ls = _forward_loss(eng, x, t, dt, req, None)
+            out = out.as_subclass(_LossTensor)
+            out._c2w_loss_sum = ls
+            return out
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         shape = x.shape
         x4 = x.reshape(-1, *shape[-3:]) if x.dim() != 4 else x

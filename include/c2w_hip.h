@@ -179,6 +179,14 @@ int c2w_windows_to_nhwc_noise(const float* data, const long long* img_off, unsig
                               int HW, int ldc, int dtype, void* stream);
 int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
                             float gscale, const float* scaler_state, int dtype, void* stream);
+/* The UNREDUCED loss tensor src/thor/pipelines.py:35 returns, `(eps_pred - eps) ** 2` (the caller takes .mean(), training_loop.py:377),
+ * for the module path: out[b][c][px] (NCHW fp32) = (y[b][px][c] - eps[b][c][px])^2 from the network's NHWC output rows; eps read
+ * from memory (c2w_sq_err) or regenerated from the step's stream (c2w_sq_err_noise); loss_sum (optional) += the sum of `out`, so
+ * the caller's mean costs no second pass.  C2W_ERR_UNSUPPORTED: HW % 4 != 0 or rows too wide for the LDS tile (caller converts the
+ * layout and uses tensor arithmetic). */
+int c2w_sq_err(const void* y, const float* eps, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype, void* stream);
+int c2w_sq_err_noise(const void* y, unsigned long long seed, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype,
+                     void* stream);
 /* model/score.py:14-34 */
 int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream);
 /* src/thor/pipelines.py:13-20: musig[i] = {mu(t_i), sigma(t_i)} */

@@ -244,8 +244,11 @@ def nhwc_to_nchw(y, out, B, C, HW, ldc, dtype):
 
 
 def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=None):
-    if scaler is not None:
-        gscale = gscale * float(scaler[0])
+    if scaler is not None:  # the kernel multiplies by the float at the pointer: element 0 of a scaler state or of a broadcast gradient
+        sc = scaler
+        while sc.dim() > 0:
+            sc = sc[0]
+        gscale = gscale * float(sc)
     Y = _rows(y, B * HW, ldc)[:, :C].float()
     E = eps.reshape(-1)[: B * C * HW].view(B, C, HW).permute(0, 2, 1).reshape(B * HW, C).float()
     d = Y - E
@@ -253,6 +256,16 @@ def mse_loss_grad(y, eps, dy, loss_sum, B, C, HW, ldc, gscale, dtype, scaler=Non
     D = _rows(dy, B * HW, ldc)
     D[:] = 0
     D[:, :C] = (d * gscale).to(TD[dtype])
+
+
+def sq_err(y, eps, out, loss_sum, B, C, HW, ldc, dtype):
+    assert not isinstance(eps, int), "the emulation has no Philox stream: callers inject eps on the CPU"
+    Y = _rows(y, B * HW, ldc)[:, :C].float().view(B, HW, C).permute(0, 2, 1)
+    sq = (Y - eps.reshape(B, C, HW).float()) ** 2
+    out.reshape(-1)[: B * C * HW] = sq.reshape(-1)
+    if loss_sum is not None:
+        loss_sum.reshape(-1)[0] += sq.sum()
+    return True
 
 
 def timestep_embedding(t, out, n, dim, max_period=10000.0):
@@ -434,3 +447,4 @@ def install(monkeypatch, target):
     for name in ALL:
         if hasattr(target, name) and name not in ("install",):
             monkeypatch.setattr(target, name, getattr(me, name))
+    monkeypatch.setattr(target, "EMULATED", True)
