@@ -198,6 +198,9 @@ class LaunchTimer:
             self.events.append((rec, "wgrad", g, e0, e1))
         self.ops.conv, self.ops.conv_wgrad = conv, conv_wgrad
 
+    def uninstall(self):
+        self.ops.conv, self.ops.conv_wgrad = self._conv, self._wgrad
+
     @staticmethod
     def flop(rec, kind, g) -> float:
         """ALGORITHMIC FLOP of one launch: 2 x output pixels of the layer's forward x rows x taps x REAL input channels (padding
@@ -240,25 +243,36 @@ class LaunchTimer:
 
 
 def pmc_traffic(a):
-    """roofline.traffic: HBM bytes per forward launch of the dominant layers, from the PMC passes over this same training step
+    """roofline.traffic: HBM bytes per forward launch of the dominant layers, from PMC passes over this same training step
     (tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate runs, FETCH_SIZE
-    doubled for gfx950; summary committed as profiles/r03_pmc_step.json).  PMC counters cannot be read from inside this process, so the
-    figure is the committed profile's, valid for the default workload only -- null otherwise."""
-    path = os.path.join(REPO, "profiles", "r03_pmc_step.json")
-    if not (a.size == 128 and a.batch == 128 and a.precision == "bf16" and a.vars == 5 and os.path.exists(path)):
+    doubled for gfx950; tools/pmc_step_summary.py -> profiles/r0N_pmc_step.json).  PMC counters cannot be read from inside this
+    process, so the figure is a committed profile's -- and only if that profile was taken with a library built from the SAME sources
+    as the one loaded now (the summary records c2w_sources_sha256); for any other build, workload or round it is null."""
+    from climate2weather_amd import build as c2w_build
+    mine = c2w_build.embedded_digest()
+    prof, path = None, None
+    for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_pmc_step.json")), reverse=True):
+        try:
+            pr = json.load(open(os.path.join(REPO, "profiles", cand)))
+        except (OSError, ValueError):
+            continue
+        if pr.get("c2w_sources_sha256") == mine and mine is not None:
+            prof, path = pr, "profiles/" + cand
+            break
+    if prof is None or not (a.size == 128 and a.batch == 128 and a.precision == "bf16" and a.vars == 5):
         return dict(traffic=None, from_profile=None)
     try:
-        prof = json.load(open(path))
         fd = prof["forward_dominant_launches"]
-        k = {(e["kernel"], e["workgroups"]): e for e in prof["kernels"]}
-        lnf = k.get(("conv_patch_t3_kernel<16, unsigned short, 8, 2>", 8192), {})
-    except (OSError, KeyError, ValueError):
+        lnf = next((e for e in prof["kernels"] if e["kernel"].startswith("conv_patch_t3_kernel<16, unsigned short, 8, 2") and e["workgroups"] == 8192
+                    and e.get("mfma_busy") is not None), {})
+    except (KeyError, ValueError):
         return dict(traffic=None, from_profile=None)
     return dict(traffic=fd["hbm_bytes"],
-                from_profile=dict(note="PMC passes over this training step on another box (tools/pmc_step.sh; rocprofv3 --kernel-trace --pmc, one counter group per run; "
-                                       "FETCH_SIZE x 2 for gfx950 + WRITE_SIZE): mean over the forward launches of 8192 workgroups with the epilogues the step runs "
-                                       "(SiLU pair: 537 MB in + 2 x 537 MB out algorithmic; residual + LayerNorm emission: 2 x 537 MB in + 2 x 537 MB out)",
-                                  source="profiles/r03_pmc_step.json", traffic_bytes_per_launch=fd["hbm_bytes"], hbm_read_bytes=fd["hbm_read_bytes"],
+                from_profile=dict(note="PMC passes over this training step on another box, library built from the same sources (tools/pmc_step.sh; rocprofv3 "
+                                       "--kernel-trace --pmc, one counter group per run; FETCH_SIZE x 2 for gfx950 + WRITE_SIZE): mean over the forward launches of "
+                                       "8192 workgroups with the epilogues the step runs (SiLU pair: 537 MB in + 2 x 537 MB out algorithmic; residual + LayerNorm "
+                                       "emission: 2 x 537 MB in + 2 x 537 MB out)",
+                                  source=path, c2w_sources_sha256=mine, traffic_bytes_per_launch=fd["hbm_bytes"], hbm_read_bytes=fd["hbm_read_bytes"],
                                   hbm_write_bytes=fd["hbm_write_bytes"], launches_profiled=fd["launches"],
                                   mfma_busy_layernorm_emission_flavour=lnf.get("mfma_busy"), clock_ghz_under_load=lnf.get("clock_ghz"),
                                   mfma_busy_by_kernel_in_step={f"{e['kernel']} x{e['workgroups']} workgroups": dict(
@@ -339,6 +353,12 @@ def cpu_baseline(C, size, cfg):
                 cpu_model=_cpu_model(), logical_cpus=ncpu, thread_sweep_forward_windows_per_s=sweep, legs=legs)
 
 
+def _step_stats(ms):
+    """per-step GPU times between consecutive step-boundary events of rank 0 (ms_per_step above is the wall clock of the whole region)"""
+    srt = sorted(ms)
+    return dict(median=round(srt[len(srt) // 2], 3), min=round(srt[0], 3), max=round(srt[-1], 3), mean=round(sum(ms) / len(ms), 3), n=len(ms))
+
+
 # ----------------------------------------------------------------------------------------------------------------- one rank
 def run_rank(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -392,9 +412,12 @@ def run_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     timer.mode = "dominant"
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # step boundaries on the main stream (which joins the gradient stream inside every step)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = one_step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -443,7 +466,8 @@ def run_rank(a):
                                         f"{a.precision} training step, {a.batch} windows/GPU/step",
                                global_batch=a.batch * world, parallelism=f"dp{world}", params=sum(p.numel() for p in net.parameters())),
                    world_size_rccl=dist.get_world_size() if dist.is_initialized() else 1,
-                   optimizer_steps_per_s=round(a.steps / elapsed, 4), final_loss=round(loss_val, 5), roofline=roof)
+                   optimizer_steps_per_s=round(a.steps / elapsed, 4), final_loss=round(loss_val, 5),
+                   step_ms=_step_stats([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]), roofline=roof)
         if gf_fwd:
             tf = value * (3 * gf_fwd - 1.96) / 1e3  # fwd + dgrad + wgrad minus the input conv's unused dgrad
             out["model_tflops_per_gpu"] = round(tf / world, 1)
@@ -530,7 +554,10 @@ def run_rank(a):
 
     # ---- BASELINE configs[4] (outside the headline region): deep variant, 80 ch x 256x256, fp16 MFMA, hipGraph-replayed sampler step
     if extras and a.size == 128 and world == 1:
-        del trainer, feed, ds
+        timer.uninstall()
+        del trainer, feed, ds, timer
+        torch.cuda.empty_cache()
+        out["module_api"] = module_api(dev, a, out["value"])
         torch.cuda.empty_cache()
         out["deep_variant"] = deep_variant(dev)
         torch.cuda.empty_cache()
@@ -544,6 +571,92 @@ def run_rank(a):
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def module_api(dev, a, trainer_windows_per_s):
+    """What a maintainer gets who changes ONLY the five class_name / func_name strings of train.py:164-193 and
+    leaves training_loop.py alone: the loop of training_loop.py:369-391, statement for statement -- optimizer.zero_grad(); data =
+    next(dataset_iterator) (a dense (B,C,H,W) tensor); loss = pipeline.loss(net, data).mean().mul(loss_scaling) under autocast;
+    backward; lr written into the param groups; optimizer.step(); loss.item(); ema.update() -- on the default network at the
+    benchmarked size.  Two legs: bf16 autocast, and the reference's own arithmetic (Fabric "16-mixed", train.py:98) = fp16 autocast +
+    torch.amp.GradScaler stepping the optimizer.  Plus the fused Trainer in fp16 (device-resident loss scale) for comparison."""
+    from climate2weather_amd.data import DeviceWindowFeed, SyntheticWindowDataset
+    from climate2weather_amd.ema import StandardEMA
+    from climate2weather_amd.lr import linear_learning_rate_schedule
+    from climate2weather_amd.optim import AdamW
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+    w = 2 * a.markov_order + 1
+    C, B = a.vars * w, a.batch
+    steps, warm = max(a.steps, 5), max(a.warmup, 2)
+    total_ndata = B * (steps + warm + 2) * 4
+    res = dict(note="training_loop.py:369-391 with network / optimizer / pipeline / EMA / lr schedule resolved from this package's class names; B = %d, "
+                    "C = %d, %dx%d; loss.item() every step as the reference does; vs_trainer = windows/s over the headline Trainer's" % (B, C, a.size, a.size),
+               trainer_windows_per_s=trainer_windows_per_s)
+
+    def timed(step):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            step()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return dict(windows_per_s=round(B / dt, 1), ms_per_step=round(1e3 * dt, 3), vs_trainer=round(B / dt / trainer_windows_per_s, 4),
+                    step_ms=_step_stats([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]))
+
+    for name, ac, use_scaler in (("bf16_autocast", torch.bfloat16, False), ("fp16_autocast_gradscaler", torch.float16, True)):
+        torch.manual_seed(0)
+        net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
+        net.train()
+        pipeline = SDAPipeline()
+        optimizer = AdamW(params=net.parameters(), lr=1e-4, weight_decay=1e-3, betas=[0.9, 0.999])  # train.py:176-181 through the class_name seam
+        ema = StandardEMA(net=net)
+        scaler = torch.amp.GradScaler("cuda") if use_scaler else None  # what Fabric's "16-mixed" precision plugin wraps backward / step in
+        ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+        feed = DeviceWindowFeed(ds, dev, seed=0)
+        state = dict(cur_ndata=0, losses=[])
+
+        def step():
+            optimizer.zero_grad()
+            data = feed.next_batch(B)
+            with torch.autocast("cuda", dtype=ac):
+                loss = pipeline.loss(net=net, x=data).mean().mul(1.0)
+            (scaler.scale(loss) if scaler is not None else loss).backward()
+            lr = linear_learning_rate_schedule(state["cur_ndata"], total_ndata, 1e-4)
+            for g in optimizer.param_groups:
+                g["lr"] = lr
+            if scaler is not None:
+                scaler.step(optimizer)
+                scaler.update()
+            else:
+                optimizer.step()
+            state["losses"].append(loss.detach().item())
+            state["cur_ndata"] += B
+            ema.update(cur_ndata=state["cur_ndata"], batch_size=B)
+
+        r = timed(step)
+        r.update(final_loss=round(state["losses"][-1], 5), flat_optimizer_path=bool(optimizer._flat), optimizer_steps_taken=optimizer.steps_taken(),
+                 loss_scale=scaler.get_scale() if scaler is not None else None)
+        res[name] = r
+        del net, optimizer, ema, feed, ds, pipeline, step
+        torch.cuda.empty_cache()
+    # the fused Trainer in the reference's arithmetic type (loss scale, inf check and skipped steps on the device)
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
+    tr = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4), weight_decay=1e-3, ema_rates=[0.9999],
+                 precision="fp16", batch_size=B, seed=1000)
+    ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+    feed = DeviceWindowFeed(ds, dev, seed=0)
+    r = timed(lambda: tr.step(feed.next_batch(B, lazy=True)))
+    r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale())
+    res["trainer_fp16"] = r
+    return res
 
 
 def deep_variant(dev, B=32):
@@ -571,6 +684,31 @@ def deep_variant(dev, B=32):
     dt = (time.perf_counter() - t0) / n
     res["train_windows_per_s"] = round(B / dt, 1)
     res["train_model_tflops"] = round(B / dt * (3 * GFLOP_FWD_DEEP - 7.9) / 1e3, 1)
+    res["train_mfma_frac"] = round(res["train_model_tflops"] / MFMA_PEAK_TFLOPS, 4)
+    # its own by_kernel: every implicit-GEMM launch of one more step, streams serialised (the same pass as the headline's)
+    from climate2weather_amd import ops as _ops
+    kt = LaunchTimer(_ops, tr.eng, tr.dt, B)
+    kt.install()
+    try:
+        kt.index_layers()
+        prev = tr.eng.use_grad_stream
+        tr.eng.use_grad_stream = False
+        tr.step(x)
+        torch.cuda.synchronize()
+        kt.mode = "all"
+        ts0 = time.perf_counter()
+        tr.step(x)
+        torch.cuda.synchronize()
+        ser_ms = 1e3 * (time.perf_counter() - ts0)
+        kt.mode = "off"
+        tr.eng.use_grad_stream = prev
+        fam = kt.summarise(steps=1)
+        gemm_ms = sum(v["ms_per_step"] for v in fam.values())
+        res["by_kernel"] = dict(serialised_step_ms=round(ser_ms, 2), implicit_gemm_ms_per_step=round(gemm_ms, 2),
+                                everything_else_ms_per_step=round(ser_ms - gemm_ms, 2),
+                                kernels=[dict(kernel=k, **v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])][:24])
+    finally:
+        kt.uninstall()
     net.precision = "fp16"
     tt = torch.rand(B, device=dev)
     with torch.no_grad():

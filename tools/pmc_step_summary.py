@@ -75,6 +75,12 @@ def forward_dominant(g, counter):
 fr, nf, kf = forward_dominant("fetch", "FETCH_SIZE")
 wr, nw, kw_ = forward_dominant("write", "WRITE_SIZE")
 summary = dict(kernels=res)
+try:  # provenance: the digest of the sources the profiled library was built from (bench.py refuses the figure for another build)
+    sys.path.insert(0, ".")
+    from climate2weather_amd import build as _b
+    summary["c2w_sources_sha256"] = _b.embedded_digest()
+except Exception:  # pragma: no cover
+    summary["c2w_sources_sha256"] = None
 if fr is not None and wr is not None:
     summary["forward_dominant_launches"] = dict(
         note="conv_patch_t3 launches of 8192 workgroups inside the forward pass of the profiled steps (14 per step: 12 residual-block convs + the padded network-input / output convs); FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KB -> bytes",
