@@ -573,7 +573,7 @@ def run_rank(a):
         dist.destroy_process_group()
 
 
-def module_api(dev, a, trainer_windows_per_s):
+def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16"), item=True, lazy=False):
     """What a maintainer gets who changes ONLY the five class_name / func_name strings of train.py:164-193 and
     leaves training_loop.py alone: the loop of training_loop.py:369-391, statement for statement -- optimizer.zero_grad(); data =
     next(dataset_iterator) (a dense (B,C,H,W) tensor); loss = pipeline.loss(net, data).mean().mul(loss_scaling) under autocast;
@@ -611,6 +611,8 @@ def module_api(dev, a, trainer_windows_per_s):
                     step_ms=_step_stats([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]))
 
     for name, ac, use_scaler in (("bf16_autocast", torch.bfloat16, False), ("fp16_autocast_gradscaler", torch.float16, True)):
+        if name not in legs:
+            continue
         torch.manual_seed(0)
         net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
         net.train()
@@ -624,7 +626,7 @@ def module_api(dev, a, trainer_windows_per_s):
 
         def step():
             optimizer.zero_grad()
-            data = feed.next_batch(B)
+            data = feed.next_batch(B, lazy=lazy)
             with torch.autocast("cuda", dtype=ac):
                 loss = pipeline.loss(net=net, x=data).mean().mul(1.0)
             (scaler.scale(loss) if scaler is not None else loss).backward()
@@ -636,26 +638,31 @@ def module_api(dev, a, trainer_windows_per_s):
                 scaler.update()
             else:
                 optimizer.step()
-            state["losses"].append(loss.detach().item())
+            state["losses"].append(loss.detach().item() if item else loss.detach())
             state["cur_ndata"] += B
             ema.update(cur_ndata=state["cur_ndata"], batch_size=B)
 
         r = timed(step)
-        r.update(final_loss=round(state["losses"][-1], 5), flat_optimizer_path=bool(optimizer._flat), optimizer_steps_taken=optimizer.steps_taken(),
+        r.update(final_loss=round(float(state["losses"][-1]), 5), flat_optimizer_path=bool(optimizer._flat), optimizer_steps_taken=optimizer.steps_taken(),
                  loss_scale=scaler.get_scale() if scaler is not None else None)
         res[name] = r
         del net, optimizer, ema, feed, ds, pipeline, step
         torch.cuda.empty_cache()
     # the fused Trainer in the reference's arithmetic type (loss scale, inf check and skipped steps on the device)
-    torch.manual_seed(0)
-    net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
-    tr = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4), weight_decay=1e-3, ema_rates=[0.9999],
-                 precision="fp16", batch_size=B, seed=1000)
-    ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
-    feed = DeviceWindowFeed(ds, dev, seed=0)
-    r = timed(lambda: tr.step(feed.next_batch(B, lazy=True)))
-    r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale())
-    res["trainer_fp16"] = r
+    for prec in ("fp16", "bf16"):
+        if "trainer_" + prec not in legs:
+            continue
+        torch.manual_seed(0)
+        net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
+        tr = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4), weight_decay=1e-3, ema_rates=[0.9999],
+                     precision=prec, batch_size=B, seed=1000)
+        ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+        feed = DeviceWindowFeed(ds, dev, seed=0)
+        r = timed(lambda: tr.step(feed.next_batch(B, lazy=True)))
+        r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale())
+        res["trainer_" + prec] = r
+        del tr, net, feed, ds
+        torch.cuda.empty_cache()
     return res
 
 

@@ -12,31 +12,56 @@ import torch
 
 
 class InfiniteSampler(torch.utils.data.Sampler):
-    """dataset.py:11-40: walks ``order[(start_idx + rank + j*num_replicas) % N]`` over per-epoch permutations seeded with
-    ``hash((seed, epoch)) % 2**31``.  (The reference calls ``Sampler.__init__(dataset)``, which torch >= 2.2 rejects.)"""
+    """The index stream of dataset.py:11-40 -- item j of a rank is ``perm[e][p % N]`` with ``p = start_idx + rank + j * num_replicas``,
+    ``e = p // N`` and ``perm[e]`` the permutation ``RandomState(hash((seed, e)) % 2**31).shuffle(arange(N))`` -- kept as a CURSOR
+    instead of a generator: ``take(n)`` returns the next n indices as one array (a batch is one vectorised gather per epoch it
+    touches, not n Python iterations), ``positions(n)`` the raw (epoch, offset) arithmetic for a device-side gather
+    (DeviceWindowFeed), and iteration (the torch Sampler protocol: DataLoader, ``next(iter(...))``) draws from the same cursor in
+    blocks.  The sequence is a bit-exact contract with the reference (tests/golden/kat.json).  (The reference's ``__init__`` calls
+    ``Sampler.__init__(dataset)``, which torch >= 2.2 rejects.)"""
 
     def __init__(self, dataset, rank=0, num_replicas=1, shuffle=True, seed=0, start_idx=0):
-        assert len(dataset) > 0
-        assert num_replicas > 0
-        assert 0 <= rank < num_replicas
-        self.dataset_size = len(dataset)
+        n = len(dataset)
+        if n <= 0 or num_replicas <= 0 or not 0 <= rank < num_replicas:
+            raise AssertionError("InfiniteSampler: empty dataset or rank outside [0, num_replicas)")
+        self.dataset_size, self.stride, self.shuffle, self.seed = n, num_replicas, shuffle, seed
         self.start_idx = start_idx + rank
-        self.stride = num_replicas
-        self.shuffle = shuffle
-        self.seed = seed
+        self.cursor = self.start_idx  # position p of the next item
+        self._perm = {}  # epoch -> permutation (the two most recent are kept)
+
+    def permutation(self, epoch: int) -> np.ndarray:
+        perm = self._perm.get(epoch)
+        if perm is None:
+            perm = np.arange(self.dataset_size)
+            if self.shuffle:
+                np.random.RandomState(hash((self.seed, epoch)) % (1 << 31)).shuffle(perm)
+            for old in [e for e in self._perm if e < epoch - 1]:
+                del self._perm[old]
+            self._perm[epoch] = perm
+        return perm
+
+    def positions(self, n: int):
+        """Advance the cursor by n items; -> [(epoch, first offset inside the epoch, count)] runs of constant epoch, offsets stepping
+        by ``self.stride`` inside a run."""
+        p, runs = self.cursor, []
+        left = n
+        while left > 0:
+            e, off = divmod(p, self.dataset_size)
+            cnt = min(left, (self.dataset_size - off + self.stride - 1) // self.stride)
+            runs.append((e, off, cnt))
+            p += cnt * self.stride
+            left -= cnt
+        self.cursor = p
+        return runs
+
+    def take(self, n: int) -> np.ndarray:
+        parts = [self.permutation(e)[off: off + cnt * self.stride: self.stride] for e, off, cnt in self.positions(n)]
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def __iter__(self) -> Iterator[int]:
-        idx = self.start_idx
-        epoch = None
-        order = None
         while True:
-            if epoch != idx // self.dataset_size:
-                epoch = idx // self.dataset_size
-                order = np.arange(self.dataset_size)
-                if self.shuffle:
-                    np.random.RandomState(hash((self.seed, epoch)) % (1 << 31)).shuffle(order)
-            yield int(order[idx % self.dataset_size])
-            idx += self.stride
+            for i in self.take(256).tolist():
+                yield i
 
 
 class SyntheticWindowDataset(torch.utils.data.Dataset):
@@ -148,19 +173,33 @@ class DeviceWindowFeed:
     def __init__(self, dataset, device, rank=0, num_replicas=1, seed=0, start_idx=0, shuffle=True):
         self.data = dataset.data.to(device)
         self.window = dataset.window
-        self.sampler = iter(InfiniteSampler(dataset, rank, num_replicas, shuffle, seed, start_idx))
+        self.sampler = InfiniteSampler(dataset, rank, num_replicas, shuffle, seed, start_idx)
         self._ar = torch.arange(self.window, device=device)
+        self._perm_dev = {}  # epoch -> that epoch's permutation in HBM (uploaded once per epoch, not once per batch)
+        self._steps = {}  # batch size -> arange(batch) * stride on the device
+
+    def _indices(self, batch: int) -> torch.Tensor:
+        """First frame of each of the next ``batch`` windows, int64 on the device.  The index stream lives on the device too: an
+        epoch's permutation is uploaded once, a batch is ``perm[off + arange(batch) * stride]`` -- one small gather, no host list, no
+        pinned staging, no host->device copy on the step's critical path."""
+        dev = self.data.device
+        runs = self.sampler.positions(batch)
+        parts = []
+        for e, off, cnt in runs:
+            perm = self._perm_dev.get(e)
+            if perm is None:
+                for old in [k for k in self._perm_dev if k < e - 1]:
+                    del self._perm_dev[old]
+                perm = self._perm_dev[e] = torch.from_numpy(self.sampler.permutation(e)).to(dev)
+            steps = self._steps.get(cnt)
+            if steps is None:
+                steps = self._steps[cnt] = torch.arange(cnt, device=dev, dtype=torch.int64) * self.sampler.stride
+            parts.append(perm[steps + off])
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
 
     def next_batch(self, batch: int, lazy: bool = False):
         """``lazy``: return a WindowBatch (indices only) instead of the gathered (B, w*F, H, W) tensor; Trainer.step takes either."""
-        idx = torch.tensor([next(self.sampler) for _ in range(batch)], dtype=torch.int64)
-        if self.data.is_cuda:
-            # pinned + asynchronous: a pageable host -> device copy blocks the host until the stream reaches it, i.e. until the PREVIOUS
-            # training step has finished on the GPU -- the launch queue then runs dry once per step (0.5 ms of 50.6, rocprof trace).
-            # The pinned block belongs to torch's caching host allocator, which does not hand it out again before the copy has run.
-            idx = idx.pin_memory().to(self.data.device, non_blocking=True)
-        else:
-            idx = idx.to(self.data.device)
+        idx = self._indices(batch)
         if lazy:
             return WindowBatch(self.data, idx, self.window)
         frames = self.data[(idx[:, None] + self._ar[None, :])]  # (B, w, F, H, W)

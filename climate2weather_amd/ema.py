@@ -21,7 +21,8 @@ def _flat_buffers(src, dst) -> Optional[Tuple[torch.Tensor, "object"]]:
     """(flat buffer of ``src``, engine of ``dst``) when both modules keep their weights in a flat GPU buffer of the same device."""
     if not (hasattr(src, "_get_engine") and hasattr(dst, "_get_engine")):
         return None
-    if not all(p.is_cuda for p in src.parameters()):
+    first = next(iter(src.parameters()), None)
+    if first is None or not (first.is_cuda or ops.EMULATED):  # CPU modules: the per-tensor primitives (and no engine is created for them)
         return None
     e_src, e_dst = src._get_engine(), dst._get_engine()
     if e_src.flat is None or e_dst.flat is None or e_src.flat.device != e_dst.flat.device or e_src.flat.numel() != e_dst.flat.numel():

@@ -251,6 +251,8 @@ class Engine:
         for i in self._bound_by_id:
             _ENGINE_BY_PARAM_ID[i] = me
         self.generation = getattr(self, "generation", 0) + 1  # bumped per (re-)attach: holders of flat-layout plans re-validate
+        self._slots, self._slots_net = None, (lambda: None)
+        self._offs4 = [4 * off for off, _, _ in lay.views.values()]
         self._pver = self._param_versions()
         self.flat = flat
         self.flat_grad = None
@@ -270,13 +272,19 @@ class Engine:
         self._gwpad.clear()
 
     def is_attached(self, net) -> bool:
+        """Are the module's parameters still the objects bound at attach() AND still views into the flat buffer?  Runs at the top of
+        every forward (and of every EMA / optimizer call that looks the engine up), on the host's critical path when the caller
+        synchronises once per step (training_loop.py:385: loss.item()): the (module, attribute) slots are resolved once per attach."""
         if self.flat is None:
             return False
+        slots = self._slots
+        if slots is None or self._slots_net() is not net:
+            slots = self._slots = [_resolve(net, name) for name in self.layout.views]
+            self._slots_net = weakref.ref(net)
         base = self.flat.data_ptr()
-        for name, (off, _, _) in self.layout.views.items():
-            mod, attr = _resolve(net, name)
+        for (mod, attr), bound, off in zip(slots, self._bound, self._offs4):
             p = mod._parameters[attr]
-            if p.dtype != torch.float32 or p.data_ptr() != base + 4 * off:
+            if p is not bound or p.data_ptr() != base + off or p.dtype != torch.float32:
                 return False
         return True
 

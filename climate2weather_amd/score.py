@@ -271,7 +271,7 @@ class ScoreUNet(torch.nn.Module):
         assert forcing is None, "forcing_dim == 0"
         eng = self._get_engine()
         dt = self.compute_dtype()
-        params = [p for _, p in self._ordered_params(eng)]
+        params = eng._bound  # the Parameter objects in layout order (is_attached has just verified they are the module's)
         req = self.__dict__.pop("_loss_request", None)  # set by SDAPipeline.loss around this call: return the unreduced loss instead
         if req is not None:
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):

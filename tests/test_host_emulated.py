@@ -428,6 +428,32 @@ def test_ema_module_api(emu, golden_dir):
     e2.load_state_dict(sd)
 
 
+@pytest.mark.parametrize("N,rank,R,seed,start", [(10, 0, 1, 0, 0), (7, 1, 3, 5, 2), (13, 3, 4, 42, 100), (5, 0, 7, 1, 3), (1, 0, 1, 0, 0), (64, 1, 2, 0, 0)])
+def test_cursor_sampler_is_the_reference_index_stream(N, rank, R, seed, start):
+    """InfiniteSampler as a vectorised cursor (take / positions / iteration in blocks) yields exactly the stream oracle/host.py restates
+    from dataset.py:28-40 -- across epoch boundaries, for strides larger than the dataset, ragged take() sizes, and through the
+    device-side gather of DeviceWindowFeed (an epoch's permutation uploaded once, a batch = perm[off + arange * stride])."""
+    class _D:
+        data = torch.zeros(N + 2, 1, 2, 2)
+        window = 3
+
+        def __len__(self):
+            return N
+    want = oh.infinite_order(N, rank, R, seed, start, 200)
+    s = InfiniteSampler(_D(), rank, R, True, seed, start)
+    got = []
+    for k in (1, 3, 17, 64, 115):
+        got += s.take(k).tolist()
+    assert got == want
+    it = iter(InfiniteSampler(_D(), rank, R, True, seed, start))
+    assert [next(it) for _ in range(200)] == want
+    feed = DeviceWindowFeed(_D(), torch.device("cpu"), rank=rank, num_replicas=R, seed=seed, start_idx=start)
+    got = []
+    for k in (5, 1, 30, 64):
+        got += feed.next_batch(k, lazy=True).first.tolist()
+    assert got == want[:100]
+
+
 def test_data_feed_and_seam(golden_dir):
     kat = json.load(open(os.path.join(golden_dir, "kat.json")))
     ds = SyntheticWindowDataset(n_frames=12, n_vars=2, height=8, width=8, window=3, seed=0)

@@ -1,40 +1,27 @@
-"""Throughput of the reference-style loop (only the class names change; torch autograd, torch.optim.AdamW,
-StandardEMA, autocast) next to the fused Trainer, same network / batch as bench.py."""
-import os, sys, time
-sys.path.insert(0, os.getcwd())
-import torch
-from climate2weather_amd.ema import StandardEMA
-from climate2weather_amd.pipelines import SDAPipeline
-from climate2weather_amd.score import ScoreUNet
+"""The reference-shaped loop (bench.py::module_api) on its own: `python tools/bench_module_api.py [--legs bf16_autocast,...] [--steps N]`.
+Used under rocprofv3 (kernel-trace stats of the drop-in path) and for A/B runs; bench.py reports the same legs in `module_api`."""
+import argparse
+import json
+import os
+import sys
 
-dev = torch.device("cuda:0")
-CFG = dict(embedding_dim=512, hidden_blocks=[3] * 5, hidden_channels=[128, 128, 256, 384, 512], kernel_size=3, padding_mode="zeros", attention_levels=[4])
-B = int(os.environ.get("B", "128"))
-torch.manual_seed(0)
-net = ScoreUNet(channels=65, spatial=2, activation=torch.nn.SiLU, **CFG).to(dev)
-ema = StandardEMA(net, rates=[0.9999])
-opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3)
-pipe = SDAPipeline()
-x = torch.randn(B, 65, 128, 128, device=dev) * 0.5 + 0.5
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
 
+import bench  # noqa: E402
 
-def step():
-    opt.zero_grad(set_to_none=True)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        loss = pipe.loss(net, x).mean()
-    loss.backward()
-    opt.step()
-    ema.update()
-    return loss
-
-
-for _ in range(2):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-n = 5
-for _ in range(n):
-    l = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-print(f"module-API loop B={B}: {1e3 * dt:.1f} ms/step  {B / dt:.1f} windows/s  loss {l.item():.4f}")
+p = argparse.ArgumentParser()
+p.add_argument("--steps", type=int, default=10)
+p.add_argument("--warmup", type=int, default=3)
+p.add_argument("--batch", type=int, default=128)
+p.add_argument("--vars", type=int, default=5)
+p.add_argument("--markov-order", type=int, default=6)
+p.add_argument("--size", type=int, default=128)
+p.add_argument("--legs", default="bf16_autocast,fp16_autocast_gradscaler,trainer_fp16,trainer_bf16")
+p.add_argument("--no-item", action="store_true", help="drop the per-step loss.item() of training_loop.py:385 (diagnostic)")
+p.add_argument("--lazy", action="store_true", help="hand pipeline.loss the un-gathered WindowBatch (diagnostic)")
+a = p.parse_args()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+res = bench.module_api(dev, a, 1.0, legs=tuple(a.legs.split(",")), item=not a.no_item, lazy=a.lazy)
+print(json.dumps(res, indent=1))
