@@ -395,7 +395,7 @@ def run_rank(a):
     total_ndata = a.batch * world * (a.steps + a.warmup + a.kernel_steps + 2) * 4
     trainer = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4),
                       weight_decay=1e-3, ema_rates=[0.9999], precision=a.precision, batch_size=a.batch * world, seed=1000)
-    ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+    ds = SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
     feed = DeviceWindowFeed(ds, dev, rank=rank, num_replicas=world, seed=0)
 
     timer = LaunchTimer(ops, trainer.eng, trainer.dt, a.batch)
@@ -557,9 +557,12 @@ def run_rank(a):
         timer.uninstall()
         del trainer, feed, ds, timer
         torch.cuda.empty_cache()
-        out["module_api"] = module_api(dev, a, out["value"])
-        torch.cuda.empty_cache()
+        import gc
         out["deep_variant"] = deep_variant(dev)
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["module_api"] = module_api(dev, a, out["value"])
+        gc.collect()
         torch.cuda.empty_cache()
         out["sampler_configs3"] = sampler_configs3(dev, a.precision if a.precision != "fp32" else "bf16")
 
@@ -620,7 +623,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         optimizer = AdamW(params=net.parameters(), lr=1e-4, weight_decay=1e-3, betas=[0.9, 0.999])  # train.py:176-181 through the class_name seam
         ema = StandardEMA(net=net)
         scaler = torch.amp.GradScaler("cuda") if use_scaler else None  # what Fabric's "16-mixed" precision plugin wraps backward / step in
-        ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+        ds = SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
         feed = DeviceWindowFeed(ds, dev, seed=0)
         state = dict(cur_ndata=0, losses=[])
 
@@ -656,7 +659,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
         tr = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4), weight_decay=1e-3, ema_rates=[0.9999],
                      precision=prec, batch_size=B, seed=1000)
-        ds = SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+        ds = SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
         feed = DeviceWindowFeed(ds, dev, seed=0)
         r = timed(lambda: tr.step(feed.next_batch(B, lazy=True)))
         r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale())

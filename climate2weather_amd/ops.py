@@ -29,7 +29,10 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream on the current device: 0.5 us, against 7 us through torch.cuda.current_stream() (a
+    # Stream object per call) -- 640 launches per training step, and every one of the first launches of a step sits on the host's
+    # critical path when the caller synchronises once per step (training_loop.py:385)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=None) -> ConvArgs:

@@ -22,7 +22,7 @@ net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **bench.DEFAULT
 pipeline, optimizer, ema = SDAPipeline(), AdamW(params=net.parameters(), lr=1e-4, weight_decay=1e-3, betas=[0.9, 0.999]), StandardEMA(net=net)
 scaler = torch.amp.GradScaler("cuda") if "--fp16" in sys.argv else None
 ac = torch.float16 if scaler is not None else torch.bfloat16
-feed = DeviceWindowFeed(SyntheticWindowDataset(n_frames=64 + w - 1, n_vars=5, height=128, width=128, window=w, seed=0), dev, seed=0)
+feed = DeviceWindowFeed(SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=5, height=128, width=128, window=w, seed=0), dev, seed=0)
 first_conv = [None]
 orig_conv = ops.conv
 
