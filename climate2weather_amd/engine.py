@@ -219,6 +219,7 @@ class Engine:
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
         self._wg_stream = None  # second HIP stream for the weight-gradient launches (see _wg)
+        self._dg_ready = None  # event behind input-gradient operands that were rebuilt on the gradient stream (prefetch_backward_operands)
         # C2W_WGRAD_STREAM=0 (read once, here; or set the attribute): weight gradients on the caller's stream, every kernel alone on the
         # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
@@ -451,6 +452,28 @@ class Engine:
         for (kind, d), want in self._pk_want.items():
             if d == dt and want:
                 self._packed(kind, self.layout.convs[next(iter(want))], dt)
+
+    def prefetch_backward_operands(self, dt: int) -> None:
+        """Rebuild the input-gradient operands (transposed copies of every weight matrix, and the packed copies the 16x16-tile launches
+        asked for) NOW, on the gradient stream, behind everything enqueued so far on the current stream (= the optimizer's update):
+        0.18 ms of HBM-bound passes that then run next to the following forward's matrix-core launches instead of in front of the
+        backward.  ``backward`` waits for them (``_dg_ready``); without a gradient stream nothing happens and backward builds them itself."""
+        side = self.grad_stream()
+        if side is None:
+            return
+        self.refresh_version()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for grp_lin in (False, True):
+                rec0 = next((r for r in self.layout.convs.values() if r.dg_off >= 0 and r.lin == grp_lin), None)
+                if rec0 is not None:
+                    self._wT(rec0, DTYPE_F32 if grp_lin else dt)
+            want = self._pk_want.get(("d", dt))
+            if want and self.use_packed_weights:
+                self._packed("d", self.layout.convs[next(iter(want))], dt)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._dg_ready = ev
 
     def _conv_weights(self, kind: str, rec: ConvRec, dt: int, g: dict, fused_ln_bwd: bool = False):
         """(operand, wpacked flag) for a conv launch of geometry ``g``: the packed copy where the launch goes to the 16x16-tile kernel
@@ -916,6 +939,9 @@ class Engine:
         [B*H*W][cout_pad] (padding channels zero).  Parameter gradients are ACCUMULATED into ``flat_grad``."""
         if self.flat_grad is None:
             raise RuntimeError("call ensure_grad_buffer() before backward")
+        if self._dg_ready is not None:  # operands prefetched on the gradient stream: this stream reads them from here on
+            torch.cuda.current_stream().wait_event(self._dg_ready)
+            self._dg_ready = None
         # Build the input-gradient operands (transposed copies of ALL weights, read from the flat buffer) before the first launch on
         # the gradient stream: whoever updates a finished part of the flat buffer from that stream while backward is still running
         # (Trainer: optimizer chasing the backward) is then ordered behind these reads by the stream's first wait on this one.

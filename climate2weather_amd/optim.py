@@ -147,6 +147,8 @@ class AdamW(torch.optim.Optimizer):
         if amp is not None:  # count the step unless it was skipped, clear found_inf (scale untouched: growth = backoff = 1)
             ops.grad_scaler_update(amp, 1.0, 1.0, 1 << 30)
         eng.weights_changed(shadow_fresh=sdt)
+        if sdt is not None:
+            eng.prefetch_backward_operands(sdt)  # the next backward's transposed / packed operands, on the gradient stream, next to the next forward
 
     def steps_taken(self, gi: int = 0) -> int:
         """AdamW steps actually applied to group ``gi`` (skipped overflow steps excluded; synchronises under AMP)."""

@@ -183,6 +183,7 @@ class Trainer:
         for rate, e in zip(self.ema_rates[1:], self.ema_flats[1:]):
             ops.ema_update(e, eng.flat, n, float(rate))
         eng.weights_changed(shadow_fresh=self.dt if shadow is not None else None)
+        eng.prefetch_backward_operands(self.dt)  # next step's input-gradient operands, next to its forward instead of in front of its backward
         B = sum(b.shape[0] for b in batches)
         self.cur_ndata += self.batch_size if self.batch_size is not None else B * self.world
         if eng.flat.is_cuda:
