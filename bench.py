@@ -551,6 +551,22 @@ def run_rank(a):
         dts = time.perf_counter() - ts
         if out is not None:
             out["sampler_cosampled_windows_per_s_per_gpu"] = round(members * (Ls - w + 1) * nst / dts, 1)
+        # north_star's second half, "ensemble sampling shards members embarrassingly" (exp/downscaling.py:96-99,248-250): every rank
+        # has just sampled ITS `members` members with no collective on the data path; the job's rate is all members over the slowest rank
+        if world > 1:
+            dist.barrier()
+            tm = torch.tensor([dts], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dts_job = float(tm.item())
+        else:
+            dts_job = dts
+        if out is not None:
+            out["sampler_member_sharded"] = dict(
+                note="BASELINE configs[3] shape: members sharded by rank, %d co-sampled members per GPU, L = %d, %d sampler steps, no collective; "
+                     "whole-job window-forwards/s = all ranks' windows over the slowest rank's time" % (members, Ls, nst),
+                n_gpus=world, members_total=members * world, scaling="weak",
+                window_forwards_per_s=round(world * members * (Ls - w + 1) * nst / dts_job, 1),
+                members_per_hour_at_256_steps=round(world * members * 3600.0 / (256 * dts_job / nst), 1))
 
     # ---- BASELINE configs[4] (outside the headline region): deep variant, 80 ch x 256x256, fp16 MFMA, hipGraph-replayed sampler step
     if extras and a.size == 128 and world == 1:

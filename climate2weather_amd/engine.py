@@ -219,6 +219,7 @@ class Engine:
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
         self._wg_stream = None  # second HIP stream for the weight-gradient launches (see _wg)
+        self.prefetch_dgrad = os.environ.get("C2W_NO_DG_PREFETCH") is None  # A/B knob, read once (here)
         self._dg_ready = None  # event behind input-gradient operands that were rebuilt on the gradient stream (prefetch_backward_operands)
         # C2W_WGRAD_STREAM=0 (read once, here; or set the attribute): weight gradients on the caller's stream, every kernel alone on the
         # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
@@ -458,7 +459,7 @@ class Engine:
         asked for) NOW, on the gradient stream, behind everything enqueued so far on the current stream (= the optimizer's update):
         0.18 ms of HBM-bound passes that then run next to the following forward's matrix-core launches instead of in front of the
         backward.  ``backward`` waits for them (``_dg_ready``); without a gradient stream nothing happens and backward builds them itself."""
-        side = self.grad_stream()
+        side = self.grad_stream() if self.prefetch_dgrad else None
         if side is None:
             return
         self.refresh_version()

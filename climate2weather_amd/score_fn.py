@@ -164,12 +164,19 @@ class _WindowScore(AbstractScoreFunction):
         x = x.unflatten(1, (2 * k + 1, -1))
         return torch.cat((x[0, :k], x[:, k], x[-1, -k:]), dim=0)
 
-    def score_fn(self, x, t):
+    def score_fn(self, x, t, ranges=None, out=None):
         """eps(x, t) over the whole trajectory x: (L, F, H, W) -- or over M co-sampled ensemble members (M, L, F, H, W):
         the windows of all members form one list that is fed to the network ``batch_size`` at a time, so short
         trajectories (37 windows at L = 49) still fill the chip (an extension: the reference samples members one by one,
-        exp/downscaling.py:248-265)."""
+        exp/downscaling.py:248-265).
+        ``ranges`` (one trajectory only): [(first window, count)] -- evaluate only these windows, writing their kept frames into
+        ``out`` (an eps buffer of x's shape from an earlier call); the time-sharded sampler runs the windows that need no halo
+        while the halo frames are still in flight (sharded.py)."""
+        if ranges is not None and (x.dim() != 4 or self.use_graphs):
+            raise ValueError("window ranges apply to one eagerly evaluated trajectory")
         if not _engine_ready(self.unet) or torch.is_grad_enabled() and x.requires_grad or _wrapped(x):
+            if ranges is not None:
+                raise ValueError("window ranges need the engine path")
             if x.dim() == 5:
                 return torch.stack([self._score_generic(xm, t) for xm in x], 0)
             return self._score_generic(x, t)  # differentiable / foreign-network path: same math through the module call
@@ -193,14 +200,19 @@ class _WindowScore(AbstractScoreFunction):
             bs = -(-total // -(-total // bs))
         if self.use_graphs and xd.is_cuda and src_dev == self.device and xd.dim() == 4:
             return self._score_graphed(xd, t, eng, dt, lay, k, w, nwin, bs)
-        eps = torch.empty_like(xd)
+        eps = torch.empty_like(xd) if out is None else out
         xs, es = xd.view(M, L, F, H, W), eps.view(M, L, F, H, W)
         td = torch.as_tensor(t).to(self.device)
         HW = H * W
         # Window batches are independent: with more than one they alternate between HIP streams, so that one batch's low-resolution
         # levels (8x8: one workgroup per CU), HBM-bound passes and last rounds of workgroups overlap the other's full-chip
         # convolutions.  Everything the batches share is read-only and prepared on the caller's stream first.
-        batches = [(g0, min(bs, total - g0)) for g0 in range(0, total, bs)]
+        if ranges is None:
+            batches = [(g0, min(bs, total - g0)) for g0 in range(0, total, bs)]
+        else:
+            batches = [(g0, min(bs, a + cnt - g0)) for a, cnt in ranges if cnt > 0 for g0 in range(a, a + cnt, bs)]
+            if any(a < 0 or a + cnt > nwin for a, cnt in ranges):
+                raise ValueError(f"window range outside [0, {nwin})")
         streams = self._side_streams(len(batches)) if xd.is_cuda else []
         if streams:
             eng.prepare_forward(dt)

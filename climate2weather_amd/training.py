@@ -36,7 +36,8 @@ class Trainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-3, ema_rates: Sequence[float] = (0.9999,),
                  precision: str = "bf16", batch_size: Optional[int] = None, loss_scaling: float = 1.0,
                  process_group=None, bucket_mb: float = 25.0, init_scale: float = 65536.0, growth_factor: float = 2.0,
-                 backoff_factor: float = 0.5, growth_interval: int = 2000, fused_noise: bool = True, seed: Optional[int] = None):
+                 backoff_factor: float = 0.5, growth_interval: int = 2000, fused_noise: bool = True, seed: Optional[int] = None,
+                 allreduce_dtype: Optional[str] = None):
         self.net = net
         self.pipeline = pipeline or SDAPipeline()
         self.lr, self.lr_fn = lr, lr_fn
@@ -92,6 +93,14 @@ class Trainer:
             start = max(0, end - per)
             self.buckets.append((start, end))
             end = start
+        # Wire format of the gradient all-reduce: None / "fp32" = the flat fp32 gradients themselves (288 MB per step, what DDP moves
+        # for the reference); "bf16" (or C2W_ALLREDUCE_DTYPE=bf16) = each finished bucket is cast to bfloat16, summed over the ranks
+        # in bfloat16 and cast back: 144 MB on the xGMI links, gradients carry bf16's 8 mantissa bits across the sum (the
+        # compression DDP's bf16_compress_hook applies) while weights, moments and the local gradients stay fp32.
+        allreduce_dtype = os.environ.get("C2W_ALLREDUCE_DTYPE", allreduce_dtype) or "fp32"
+        if allreduce_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"allreduce_dtype must be fp32 or bf16, got {allreduce_dtype!r}")
+        self.wire = torch.empty(n, dtype=torch.bfloat16, device=dev) if (allreduce_dtype == "bf16" and self.sync_grads) else None
         self._works: list = []
         self._next_bucket = 0
         self._chase = None  # (lr, step) while the optimizer update chases the backward of the current round
@@ -119,8 +128,15 @@ class Trainer:
             side = self.eng.grad_stream()
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 work = None
-                if self.sync_grads:
+                if self.sync_grads and self.wire is None:
                     work = dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                elif self.sync_grads:  # bf16 on the wire: cast, sum, cast back -- all ordered on this (the gradient) stream
+                    wb = self.wire[s:e]
+                    wb.copy_(self.eng.flat_grad[s:e])
+                    work = dist.all_reduce(wb, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    work.wait()  # stream-side wait (RCCL); the copy back must see the reduced values
+                    self.eng.flat_grad[s:e].copy_(wb)
+                    work = None
                 if self._chase is not None:
                     if work is not None:
                         work.wait()  # the gradient stream waits for the collective, not the host

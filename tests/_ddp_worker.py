@@ -91,6 +91,46 @@ def run_chase(rank: int, world: int, port: int, golden_dir: str, out_dir: str, b
     dist.destroy_process_group()
 
 
+def run_wire(rank: int, world: int, port: int, golden_dir: str, out_dir: str, backend: str = "gloo"):
+    """The gradient all-reduce with bfloat16 on the wire (Trainer(allreduce_dtype="bf16"): every finished bucket cast, summed over the
+    ranks in bf16, cast back) next to the fp32 wire, same weights and batches, several buckets: the summed gradients agree to bf16's
+    resolution, the ranks stay in lock step, the loss is untouched (it is computed before any gradient moves)."""
+    dev = _init(rank, world, port, backend)
+    from climate2weather_amd.score import ScoreUNet
+    from climate2weather_amd.training import Trainer
+
+    g = np.load(os.path.join(golden_dir, "tiny_net.npz"))
+    if world == 1:
+        os.environ["C2W_FORCE_DIST"] = "1"
+    x, t, eps = (torch.from_numpy(g[k]).to(dev) for k in ("x", "t", "eps"))
+    per = x.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    res = {}
+    for wire in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
+                        attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev)
+        tr = Trainer(net, lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=0.05, allreduce_dtype=wire)
+        assert tr.sync_grads and len(tr.buckets) > 4 and (tr.wire is not None) == (wire == "bf16")
+        n_ar, dts = [0], set()
+        orig = dist.all_reduce
+
+        def counting(tensor, *a, **k):
+            n_ar[0] += 1
+            dts.add(tensor.dtype)
+            return orig(tensor, *a, **k)
+        dist.all_reduce = counting
+        try:
+            loss = tr.step(x[sl].contiguous(), t=t[sl].reshape(-1), eps=eps[sl].contiguous())
+        finally:
+            dist.all_reduce = orig
+        res[wire] = dict(loss=float(loss), grad=tr.eng.flat_grad.detach().cpu().clone(), flat=tr.eng.flat.detach().cpu().clone(),
+                         all_reduces=n_ar[0], dtypes=sorted(str(d) for d in dts), nb=len(tr.buckets))
+    torch.save(res, os.path.join(out_dir, f"wire{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def run_full_size(rank: int, world: int, port: int, out_dir: str, steps: int = 3, batch: int = 16):
     """The bench's own network (default configs/sda_unet.yml, C = 65, 128x128) in bf16 through a real RCCL communicator: every one of
     the 25-MB buckets of the 288-MB gradient buffer is all-reduced from the gradient stream while wgrad_patch_kernel / conv_patch

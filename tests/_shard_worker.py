@@ -39,6 +39,10 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, backend
         x = sample_time_sharded(pipe, sf, noise[lo:hi], steps=4, corrections=corrections, tau=0.5, z_draws=zs, gather=True)
         out[name] = x.cpu().clone()
         out[name + ".bounds"] = sf.bounds
+        if name == "cond_c0":  # the same run with the halo exchange waited for BEFORE any window runs (no overlap): same trajectory
+            sf.overlap_halo = False
+            x2 = sample_time_sharded(pipe, sf, noise[lo:hi], steps=4, corrections=corrections, tau=0.5, z_draws=zs, gather=True)
+            out[name + ".no_overlap"] = x2.cpu().clone()
     torch.save(out, os.path.join(out_dir, f"shard{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
