@@ -101,6 +101,8 @@ class TimeShardedScoreFunction(BatchedScoreFunction):
         if x_own.shape[0] != self.e - self.s:
             raise ValueError(f"rank {self.rank} owns frames [{self.s}, {self.e}) but got {x_own.shape[0]}")
         x_own = x_own.to(device=self.device, dtype=torch.float32).contiguous()
+        if self._guide is not None and self._guide["exact"]:
+            return self._call_exact(x_own, t)
         k, n = self.markov_order, x_own.shape[0]
         ext, kl, works = self.post_halo_exchange(x_own)
         nwin = ext.shape[0] - 2 * k
@@ -125,12 +127,59 @@ class TimeShardedScoreFunction(BatchedScoreFunction):
             self._apply_guidance(x_own, eps, t)
         return eps
 
+    def _call_exact(self, x_own, t):
+        """``exact_grad=True`` (the API default, src/thor/score.py:44): eps - sigma dlog p/dx with the network inside the derivative
+        (src/thor/score.py:28-35,48-57).  log p is a sum over observed frames, each rank holds the terms of ITS observed frames; the
+        estimate x0 of an owned frame reads the k frames either side of it, so a rank's terms also have a gradient with respect to its
+        HALO frames -- which belong to the neighbours.  Forward halo exchange, local reverse pass over own + halo frames, then the
+        reverse exchange: the gradient of my halo copies goes to their owners, theirs of my boundary frames comes back and is added."""
+        g = self._guide
+        k, n = self.markov_order, x_own.shape[0]
+        ext, kl = self.exchange_halos(x_own)
+        tt = torch.as_tensor(t).to(self.device)
+        mu, sigma = self.noise_process.mu(tt), self.noise_process.sigma(tt)
+        with torch.enable_grad():
+            xg = ext.detach().requires_grad_(True)
+            eps_ext = self.score_fn(xg, tt)  # differentiable route: unfold -> module (one autograd node per window batch) -> fold
+            eps_own = eps_ext[kl:kl + n]
+            if g["nobs"] > 0:
+                x0 = (xg[kl:kl + n] - sigma * eps_own) / mu
+                err = g["y"] - g["A"]._pool(x0[g["off"]:: g["A"].t_step][: g["nobs"]])
+                F = x_own.shape[1]
+                sd = g["std"].reshape(1, -1, 1, 1)
+                gm = g["gamma"].reshape(1, F, 1, 1) if isinstance(g["gamma"], torch.Tensor) else g["gamma"]
+                logp = -(err ** 2 / (sd ** 2 + gm * (sigma / mu) ** 2)).sum() / 2
+                (J_ext,) = torch.autograd.grad(logp, xg)
+            else:  # no observed frame here: this rank still takes part in the exchange below
+                J_ext = torch.zeros_like(ext)
+        J = J_ext[kl:kl + n].clone()
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank + 1 < self.world else None
+        p2p, rl, rr = [], None, None
+        if left is not None:
+            rl = torch.empty_like(J[:k])
+            p2p += [dist.P2POp(dist.isend, J_ext[:kl].contiguous(), self._global(left), group=self.pg),
+                    dist.P2POp(dist.irecv, rl, self._global(left), group=self.pg)]
+        if right is not None:
+            rr = torch.empty_like(J[n - k:])
+            p2p += [dist.P2POp(dist.isend, J_ext[kl + n:].contiguous(), self._global(right), group=self.pg),
+                    dist.P2POp(dist.irecv, rr, self._global(right), group=self.pg)]
+        if p2p:
+            for w in dist.batch_isend_irecv(p2p):
+                w.wait()
+        if rl is not None:
+            J[:k] += rl
+        if rr is not None:
+            J[n - k:] += rr
+        return (eps_own.detach() - sigma * J).contiguous()
+
     def condition_on(self, *, A, y, std, gamma=1e-2, exact_grad=False):
         """Same keywords as ``src/thor/score.py:44-60``; ``y`` is the GLOBAL observation ``A(x)`` of the whole trajectory.
-        Only the frame-local operator of the reference's experiments and ``exact_grad=False`` shard over time: the exact
-        gradient couples frames through the network and would need a gradient halo exchange."""
-        if not isinstance(A, PoolStrideOperator) or exact_grad:
-            raise NotImplementedError("time-sharded guidance supports A = PoolStrideOperator with exact_grad=False")
+        The frame-local operator of the reference's experiments shards over time; ``exact_grad=True`` adds a reverse halo exchange of
+        the gradient (``_call_exact``).  An arbitrary callable ``A`` over the whole trajectory cannot be split and is refused.
+        NOTE the default here is ``exact_grad=False`` (what every shipped experiment config sets), the reference API's is True."""
+        if not isinstance(A, PoolStrideOperator):
+            raise NotImplementedError("time-sharded guidance needs the frame-local operator A = PoolStrideOperator")
         if self._guide is not None:
             print("Warning: Overwriting old conditioning")
         t_step = A.t_step
@@ -146,7 +195,7 @@ class TimeShardedScoreFunction(BatchedScoreFunction):
         if gam is None:
             raise NotImplementedError("time-sharded guidance takes a scalar gamma or one value per variable, shape (1, F, 1, 1)")
         gam = float(gam) if gam.numel() == 1 else gam.to(self.device).contiguous()
-        self._guide = dict(A=A, y=y_loc, std=std, gamma=gam, off=first - self.s, nobs=nobs)
+        self._guide = dict(A=A, y=y_loc, std=std, gamma=gam, off=first - self.s, nobs=nobs, exact=bool(exact_grad))
         return self
 
     @property

@@ -26,14 +26,15 @@ def run(rank: int, world: int, port: int, golden_dir: str, out_dir: str, backend
     net.precision = "fp32"
     pipe = SDAPipeline()
     out = {}
-    for name, corrections, cond in [("uncond_c0", 0, False), ("uncond_c1", 1, False), ("cond_c0", 0, True), ("cond_c0_gvec", 0, True)]:
+    for name, corrections, cond in [("uncond_c0", 0, False), ("uncond_c1", 1, False), ("cond_c0", 0, True), ("cond_c0_gvec", 0, True),
+                                    ("cond_c1_exact", 1, True)]:  # exact gradient: reverse halo exchange of dlog p/dx
         noise = torch.from_numpy(s[name + ".noise"])
         sf = TimeShardedScoreFunction(net, markov_order=1, length=noise.shape[0], batch_size=3, device=dev,
                                       noise_process=pipe)
         if cond:
             sf.condition_on(A=PoolStrideOperator(8, 2), y=torch.from_numpy(s["y_obs"]), std=torch.from_numpy(s["std"]),
                             gamma=torch.from_numpy(sg["gamma"]) if name.endswith("_gvec") else float(s["gamma"]),  # (1, F, 1, 1): exp/downscaling.py:228-233
-                            exact_grad=False)
+                            exact_grad=name.endswith("_exact"))
         lo, hi = sf.bounds[rank]
         zs = [torch.from_numpy(z)[lo:hi] for z in s[name + ".z"]] if corrections else None
         x = sample_time_sharded(pipe, sf, noise[lo:hi], steps=4, corrections=corrections, tau=0.5, z_draws=zs, gather=True)

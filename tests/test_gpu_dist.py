@@ -129,7 +129,7 @@ def test_time_sharded_sampler_over_rccl_two_ranks(golden_dir, tmp_path):
     r0, r1 = (torch.load(tmp_path / f"shard{r}.pt", weights_only=False) for r in (0, 1))
     assert r0["uncond_c0.bounds"] == [(0, 5), (5, 9)]
     sg = _golden(golden_dir, "sampler_gamma.npz")  # per-variable gamma as exp/downscaling.py:228-233 builds it
-    for name in ("uncond_c0", "uncond_c1", "cond_c0", "cond_c0_gvec"):
+    for name in ("uncond_c0", "uncond_c1", "cond_c0", "cond_c0_gvec", "cond_c1_exact"):
         ref = torch.from_numpy(sg[name + ".x"] if name.endswith("_gvec") else s[name + ".x"])
         assert torch.equal(r0[name], r1[name]), name
         if name + ".no_overlap" in r0:  # interior windows evaluated while the halos were in flight == halos first

@@ -392,7 +392,7 @@ def test_time_sharded_sampler_two_ranks_equals_reference_trajectory(golden_dir, 
     r0, r1 = (torch.load(tmp_path / f"shard{r}.pt", weights_only=False) for r in (0, 1))
     assert r0["uncond_c0.bounds"] == [(0, 5), (5, 9)]
     sg = _golden(golden_dir, "sampler_gamma.npz")  # per-variable gamma as exp/downscaling.py:228-233 builds it
-    for name in ("uncond_c0", "uncond_c1", "cond_c0", "cond_c0_gvec"):
+    for name in ("uncond_c0", "uncond_c1", "cond_c0", "cond_c0_gvec", "cond_c1_exact"):
         ref = torch.from_numpy(sg[name + ".x"] if name.endswith("_gvec") else s[name + ".x"])
         assert torch.equal(r0[name], r1[name]), name  # gather=True: every rank holds the whole trajectory
         assert (r0[name] - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), name
