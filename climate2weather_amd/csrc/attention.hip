@@ -14,6 +14,8 @@ int c2w_attention_mfma_forward(const void* qkv, void* o, float* lse, int B, int 
 int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* lse, void* dqkv, int B, int C, int dtype, hipStream_t st);
 bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype);
 int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, hipStream_t st);
+int c2w_attention_mfma_blocks_backward(const void* qkv, const void* d_o, const float* lse, const float* delta, void* dqkv, int B, int Tn, int C,
+                                       int dtype, hipStream_t st);
 
 namespace {
 
@@ -251,6 +253,13 @@ extern "C" int c2w_attention_backward(const void* qkv, const void* o, const void
     const int P = dtype == C2W_DTYPE_F32 ? 4 : 8;
     if (!qkv || !o || !d_o || !lse || !delta_ws || !dqkv || B <= 0 || Tn <= 0 || C % P) return C2W_ERR_BAD_SHAPE;
     if (c2w_attention_mfma_eligible(B, Tn, C, dtype)) return c2w_attention_mfma_backward(qkv, d_o, lse, dqkv, B, C, dtype, (hipStream_t)stream);
+    if (c2w_attention_mfma_blocks_eligible(B, Tn, C, dtype)) {  // T = 64 nb: delta over the whole row first, then the two block kernels
+        const long long nrows = (long long)B * Tn;
+        const int rg = (int)((nrows + 15) / 16 < 4096 ? (nrows + 15) / 16 : 4096);
+        if (dtype == C2W_DTYPE_F16) rowdot_kernel<f16_t><<<rg, 256, 0, (hipStream_t)stream>>>((const f16_t*)d_o, (const f16_t*)o, delta_ws, nrows, C);
+        else rowdot_kernel<bf16_t><<<rg, 256, 0, (hipStream_t)stream>>>((const bf16_t*)d_o, (const bf16_t*)o, delta_ws, nrows, C);
+        return c2w_attention_mfma_blocks_backward(qkv, d_o, lse, delta_ws, dqkv, B, Tn, C, dtype, (hipStream_t)stream);
+    }
     const int lds = (TR * C + 2 * TR * Tn) * 4;
     if (lds > 160 * 1024) return C2W_ERR_UNSUPPORTED;
     dim3 grid((Tn + TR - 1) / TR, B);

@@ -318,6 +318,150 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_blocks_kernel(const bf16
     }
 }
 
+
+// ---- backward for T = 64 * nb tokens (round 4; the 256^2 variant's attention backward ran on the fp32 VALU kernels: 6.8 % of its
+// training step).  Flash-style in 64 x 64 blocks, two kernels, no atomics, bit-reproducible:
+//   attn_mfma_bwd_kv_blocks_kernel   one workgroup per (image, KEY block j): walks the query blocks i, recomputes S_ij and dP_ij,
+//                                    dv_j += P_ij^T dO_i,  dk_j += dS_ij^T q_i   (accumulators in registers: 16 rows x C/2 per wave)
+//   attn_mfma_bwd_q_blocks_kernel    one workgroup per (image, QUERY block i): walks the key blocks j, dq_i += dS_ij k_j
+// with P_ij = exp(S_ij s^2 - lse_i), dS_ij = P_ij (dP_ij - delta_i) s^2 and delta_i = sum_c dO_i O_i over the WHOLE row (rowdot_kernel,
+// attention.hip) -- the T = 64 kernel could take it from its one block.  Same wave roles as there: wave (w, half) works on the 16-row
+// strip w; half 0 computes S, half 1 dP, side by side; each takes half of the column tiles of the output strips.
+constexpr int MAXHCT = 16;  // column tiles of 16 per wave half: C <= 512
+
+template <typename T>
+__device__ __forceinline__ void strip_acc_lds(f32x4_t (&acc)[MAXHCT], const bf16x8_t (&a)[2], const char* M, int pitch, int ct0, int nct, int li,
+                                              int lg) {
+#pragma unroll
+    for (int c = 0; c < MAXHCT; ++c) {
+        if (c < nct) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc[c] = mfma16s<T>(a[ks], tr_frag(M, pitch, 32 * ks, 16 * (ct0 + c), li, lg), acc[c]);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void strip_store(bf16_t* out, int ldo, const f32x4_t (&acc)[MAXHCT], int ct0, int nct, int w, int li, int lg) {
+#pragma unroll
+    for (int c = 0; c < MAXHCT; ++c) {
+        if (c < nct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(16 * w + 4 * lg + r) * ldo + 16 * (ct0 + c) + li] = f32_to_bits16<T>(acc[c][r]);
+        }
+    }
+}
+
+// P and dS of one 64 x 64 block into LDS (half 0), from S (own accumulators) and dP (from the strip's other wave, through X)
+template <typename T, bool WANT_P>
+__device__ __forceinline__ void block_p_ds(char* Pl, char* Sl, const f32x4_t (&s)[4], const f32x4_t (&dp)[4], const float* lse_i, const float* del_i,
+                                           float scale2, int w, int li, int lg) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + 4 * lg + r;
+        const float l = lse_i[row], delta = del_i[row];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float p = __expf(s[n][r] * scale2 - l);
+            if (WANT_P) *(bf16_t*)(Pl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(p);
+            *(bf16_t*)(Sl + row * PP + (16 * n + li) * 2) = f32_to_bits16<T>(p * (dp[n][r] - delta) * scale2);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTA) void attn_mfma_bwd_kv_blocks_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                      bf16_t* __restrict__ dqkv, int Tn, int C, float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VP = C * 2 + 16;
+    char* const B0 = smem;                 // q_i
+    char* const B1 = smem + T64 * VP;      // dO_i
+    char* const Pl = smem + 2 * T64 * VP;  // P_ij  [q][key]
+    char* const Sl = Pl + T64 * PP;        // dS_ij [q][key]
+    char* const X = Pl;                    // dP on its way to the strip's other wave (before P / dS exist)
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, half = w8 >> 2, li = lane & 15, lg = lane >> 4;
+    const int ld = 3 * C, nb = Tn / T64, j = blockIdx.x;
+    const bf16_t* base = qkv + (size_t)blockIdx.y * Tn * ld;
+    const bf16_t* dob = d_o + (size_t)blockIdx.y * Tn * C;
+    const bf16_t* kj = base + (size_t)j * T64 * ld + C;
+    const bf16_t* vj = base + (size_t)j * T64 * ld + 2 * C;
+    const int nct = C / 16, ctm = nct / 2, ct0 = half ? ctm : 0, nc = half ? nct - ctm : ctm;
+    f32x4_t dk[MAXHCT], dv[MAXHCT];
+#pragma unroll
+    for (int c = 0; c < MAXHCT; ++c) dk[c] = dv[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nb; ++i) {
+        const bf16_t* qi = base + (size_t)i * T64 * ld;
+        const bf16_t* doi = dob + (size_t)i * T64 * C;
+        __syncthreads();  // every wave is done with the previous block's q, dO, P, dS
+        stage_rows(B0, VP, qi, ld, C);
+        stage_rows(B1, VP, doi, C, C);
+        f32x4_t s[4] = {}, dp[4];
+        if (!half) strip_abt<T>(s, qi, ld, kj, ld, 0, C / 32, w, li, lg);
+        else strip_abt<T>(s, doi, C, vj, ld, 0, C / 32, w, li, lg);
+        if (half) strip_to_lds(X, w, s, li, lg);
+        __syncthreads();
+        if (!half) strip_from_lds(X, w, dp, li, lg);
+        __syncthreads();  // X is read: P and dS may take its place
+        if (!half) block_p_ds<T, true>(Pl, Sl, s, dp, lse + (size_t)blockIdx.y * Tn + i * T64, delta + (size_t)blockIdx.y * Tn + i * T64, scale2, w, li, lg);
+        __syncthreads();
+        bf16x8_t a[2];
+        // dv strip (key rows 16 w ..): P^T . dO_i
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Pl, PP, 32 * ks, 16 * w, li, lg);
+        strip_acc_lds<T>(dv, a, B1, VP, ct0, nc, li, lg);
+        // dk strip: dS^T . q_i
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[ks] = tr_frag(Sl, PP, 32 * ks, 16 * w, li, lg);
+        strip_acc_lds<T>(dk, a, B0, VP, ct0, nc, li, lg);
+    }
+    bf16_t* dbase = dqkv + ((size_t)blockIdx.y * Tn + (size_t)j * T64) * ld;
+    strip_store<T>(dbase + C, ld, dk, ct0, nc, w, li, lg);
+    strip_store<T>(dbase + 2 * C, ld, dv, ct0, nc, w, li, lg);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTA) void attn_mfma_bwd_q_blocks_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                     bf16_t* __restrict__ dqkv, int Tn, int C, float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VP = C * 2 + 16;
+    char* const B0 = smem;             // k_j
+    char* const Pl = smem + T64 * VP;  // (unused P slot: keeps the X overlay's 16 KiB inside the buffer)
+    char* const Sl = Pl + T64 * PP;    // dS_ij [q][key]
+    char* const X = Pl;
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, half = w8 >> 2, li = lane & 15, lg = lane >> 4;
+    const int ld = 3 * C, nb = Tn / T64, i = blockIdx.x;
+    const bf16_t* base = qkv + (size_t)blockIdx.y * Tn * ld;
+    const bf16_t* qi = base + (size_t)i * T64 * ld;
+    const bf16_t* doi = d_o + ((size_t)blockIdx.y * Tn + (size_t)i * T64) * C;
+    const float* lse_i = lse + (size_t)blockIdx.y * Tn + i * T64;
+    const float* del_i = delta + (size_t)blockIdx.y * Tn + i * T64;
+    const int nct = C / 16, ctm = nct / 2, ct0 = half ? ctm : 0, nc = half ? nct - ctm : ctm;
+    f32x4_t dq[MAXHCT];
+#pragma unroll
+    for (int c = 0; c < MAXHCT; ++c) dq[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nb; ++j) {
+        const bf16_t* kj = base + (size_t)j * T64 * ld + C;
+        const bf16_t* vj = base + (size_t)j * T64 * ld + 2 * C;
+        __syncthreads();  // every wave is done with the previous k block and dS
+        stage_rows(B0, VP, kj, ld, C);
+        f32x4_t s[4] = {}, dp[4];
+        if (!half) strip_abt<T>(s, qi, ld, kj, ld, 0, C / 32, w, li, lg);
+        else strip_abt<T>(s, doi, C, vj, ld, 0, C / 32, w, li, lg);
+        if (half) strip_to_lds(X, w, s, li, lg);
+        __syncthreads();
+        if (!half) strip_from_lds(X, w, dp, li, lg);
+        __syncthreads();
+        if (!half) block_p_ds<T, false>(Pl, Sl, s, dp, lse_i, del_i, scale2, w, li, lg);
+        __syncthreads();
+        bf16x8_t a[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[ks] = *(const bf16x8_t*)(Sl + (16 * w + li) * PP + (32 * ks + 8 * lg) * 2);
+        strip_acc_lds<T>(dq, a, B0, VP, ct0, nc, li, lg);
+    }
+    strip_store<T>(dqkv + ((size_t)blockIdx.y * Tn + (size_t)i * T64) * ld, ld, dq, ct0, nc, w, li, lg);
+}
+
 }  // namespace
 
 static bool is16(int dtype) { return dtype == C2W_DTYPE_BF16 || dtype == C2W_DTYPE_F16; }
@@ -370,11 +514,37 @@ int c2w_attention_mfma_backward(const void* qkv, const void* d_o, const float* l
     return dtype == C2W_DTYPE_F16 ? bwd_launch<f16_t>(qkv, d_o, lse, dqkv, B, C, st) : bwd_launch<bf16_t>(qkv, d_o, lse, dqkv, B, C, st);
 }
 
-// forward only: T a multiple of 64 beyond 64 (the backward of those shapes stays on the fp32 VALU kernels)
+// T a multiple of 64 beyond 64: forward with the online softmax over key blocks, backward in 64 x 64 blocks (two kernels)
 bool c2w_attention_mfma_blocks_eligible(int B, int Tn, int C, int dtype) {
     return is16(dtype) && Tn > T64 && Tn % T64 == 0 && Tn <= 4096 && C % 32 == 0 && C <= 512 && B > 0 && !c2w_knobs().attn_valu;
 }
 
 int c2w_attention_mfma_blocks_forward(const void* qkv, void* o, float* lse, int B, int Tn, int C, int dtype, hipStream_t st) {
     return dtype == C2W_DTYPE_F16 ? blocks_launch<f16_t>(qkv, o, lse, B, Tn, C, st) : blocks_launch<bf16_t>(qkv, o, lse, B, Tn, C, st);
+}
+
+namespace {
+template <typename T>
+int blocks_bwd_launch(const void* qkv, const void* d_o, const float* lse, const float* delta, void* dqkv, int B, int Tn, int C, hipStream_t st) {
+    const int VP = C * 2 + 16;
+    const int lds_kv = 2 * T64 * VP + 2 * T64 * PP, lds_q = T64 * VP + 2 * T64 * PP;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_bwd_kv_blocks_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_mfma_bwd_q_blocks_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const float scale2 = 1.0f / sqrtf((float)C);
+    const dim3 grid(Tn / T64, B);
+    attn_mfma_bwd_kv_blocks_kernel<T><<<grid, NTA, lds_kv, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta, (bf16_t*)dqkv, Tn, C, scale2);
+    attn_mfma_bwd_q_blocks_kernel<T><<<grid, NTA, lds_q, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta, (bf16_t*)dqkv, Tn, C, scale2);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+// backward of the T = 64 nb shapes: delta[row] = sum_c dO O must have been computed (attention.hip: rowdot_kernel) into `delta`
+int c2w_attention_mfma_blocks_backward(const void* qkv, const void* d_o, const float* lse, const float* delta, void* dqkv, int B, int Tn, int C,
+                                       int dtype, hipStream_t st) {
+    return dtype == C2W_DTYPE_F16 ? blocks_bwd_launch<f16_t>(qkv, d_o, lse, delta, dqkv, B, Tn, C, st)
+                                  : blocks_bwd_launch<bf16_t>(qkv, d_o, lse, delta, dqkv, B, Tn, C, st);
 }

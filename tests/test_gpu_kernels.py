@@ -567,7 +567,7 @@ def test_grad_scaler_and_fp16_shadow():
 
 
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
-@pytest.mark.parametrize("shape", [(2, 64, 512), (3, 16, 64), (1, 256, 128), (2, 4, 64), (5, 64, 128), (3, 64, 96), (2, 256, 512), (1, 192, 64)])  # bf16: T=64 and T=64n (online softmax over key blocks) on the matrix cores
+@pytest.mark.parametrize("shape", [(2, 64, 512), (3, 16, 64), (1, 256, 128), (2, 4, 64), (5, 64, 128), (3, 64, 96), (2, 256, 512), (1, 192, 64), (3, 128, 512), (2, 512, 256)])  # 16-bit: T=64 and T=64n (forward: online softmax over key blocks; backward: 64x64 blocks, two kernels) on the matrix cores
 def test_attention(shape, dt):
     B, T, C = shape
     d = dev()
