@@ -40,27 +40,37 @@ class InfiniteSampler(torch.utils.data.Sampler):
             self._perm[epoch] = perm
         return perm
 
-    def positions(self, n: int):
-        """Advance the cursor by n items; -> [(epoch, first offset inside the epoch, count)] runs of constant epoch, offsets stepping
-        by ``self.stride`` inside a run."""
-        p, runs = self.cursor, []
-        left = n
+    def _runs(self, p: int, n: int):
+        """n items from position p on: ([(epoch, first offset inside the epoch, count)] runs of constant epoch, offsets stepping by
+        ``self.stride`` inside a run; position after them)."""
+        runs, left = [], n
         while left > 0:
             e, off = divmod(p, self.dataset_size)
             cnt = min(left, (self.dataset_size - off + self.stride - 1) // self.stride)
             runs.append((e, off, cnt))
             p += cnt * self.stride
             left -= cnt
-        self.cursor = p
+        return runs, p
+
+    def positions(self, n: int):
+        """Advance the cursor by n items and return their runs (see _runs)."""
+        runs, self.cursor = self._runs(self.cursor, n)
         return runs
 
-    def take(self, n: int) -> np.ndarray:
-        parts = [self.permutation(e)[off: off + cnt * self.stride: self.stride] for e, off, cnt in self.positions(n)]
+    def _gather(self, runs) -> np.ndarray:
+        parts = [self.permutation(e)[off: off + cnt * self.stride: self.stride] for e, off, cnt in runs]
         return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
+    def take(self, n: int) -> np.ndarray:
+        return self._gather(self.positions(n))
+
     def __iter__(self) -> Iterator[int]:
+        """Every iterator walks the stream from ``start_idx`` on its own position, like the reference's generator (dataset.py:28-40);
+        the object's cursor (take / positions) is not touched."""
+        p = self.start_idx
         while True:
-            for i in self.take(256).tolist():
+            runs, p = self._runs(p, 256)
+            for i in self._gather(runs).tolist():
                 yield i
 
 

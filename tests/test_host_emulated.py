@@ -475,6 +475,8 @@ def test_cursor_sampler_is_the_reference_index_stream(N, rank, R, seed, start):
     assert got == want
     it = iter(InfiniteSampler(_D(), rank, R, True, seed, start))
     assert [next(it) for _ in range(200)] == want
+    it2 = iter(s)  # a fresh iterator starts over (dataset.py:28: idx = self.start_idx), whatever take() has consumed
+    assert [next(it2) for _ in range(50)] == want[:50] and s.take(1).tolist() == oh.infinite_order(N, rank, R, seed, start, 201)[200:]
     feed = DeviceWindowFeed(_D(), torch.device("cpu"), rank=rank, num_replicas=R, seed=seed, start_idx=start)
     got = []
     for k in (5, 1, 30, 64):
