@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--sample-steps", type=int, default=2, help="sampler steps timed after the headline run (0 = skip)")
     p.add_argument("--kernel-steps", type=int, default=2, help="extra steps with every implicit-GEMM launch timed (by_kernel; 0 = skip)")
     p.add_argument("--no-extras", action="store_true", help="skip by_kernel, the deep-variant leg and the sampler legs")
+    p.add_argument("--light-extras", action="store_true",
+                   help="only the extras every rank of a multi-GPU job runs (vendor GEMM, by_kernel, sampler legs incl. the member-sharded one)")
     return p.parse_args()
 
 
@@ -562,7 +564,7 @@ def run_rank(a):
             out["sampler_cosampled_windows_per_s_per_gpu"] = round(members * (Ls - w + 1) * nst / dts, 1)
         # north_star's second half, "ensemble sampling shards members embarrassingly" (exp/downscaling.py:96-99,248-250): every rank
         # has just sampled ITS `members` members with no collective on the data path; the job's rate is all members over the slowest rank
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             tm = torch.tensor([dts], device=dev, dtype=torch.float64)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -578,7 +580,7 @@ def run_rank(a):
                 members_per_hour_at_256_steps=round(world * members * 3600.0 / (256 * dts_job / nst), 1))
 
     # ---- BASELINE configs[4] (outside the headline region): deep variant, 80 ch x 256x256, fp16 MFMA, hipGraph-replayed sampler step
-    if extras and a.size == 128 and world == 1:
+    if extras and a.size == 128 and world == 1 and not a.light_extras:
         timer.uninstall()
         del trainer, feed, ds, timer
         _empty_cache()

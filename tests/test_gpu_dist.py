@@ -157,6 +157,26 @@ def test_bench_launcher_spawns_one_rank_per_gpu(tmp_path):
     assert rec["world_size_rccl"] == n and rec["value"] > 0
 
 
+def test_bench_multi_rank_extras_run_through_the_communicator(tmp_path):
+    """The extras every rank of `bench.py --gpus N` runs -- by_kernel steps (collectives inside), the sampler legs and the member-sharded
+    sampler record with its barrier + MAX all-reduce -- through a real RCCL communicator (one rank per visible GPU, at least one)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 2 if NGPU >= 2 else 1
+    env = dict(os.environ, C2W_FORCE_DIST="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--sample-steps", "1", "--kernel-steps", "1", "--light-extras"],
+                         capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    sm = rec["sampler_member_sharded"]
+    assert sm["n_gpus"] == n and sm["members_total"] == 8 * n and sm["window_forwards_per_s"] > 0
+    assert rec["by_kernel"]["serialised_step_ms"] > 0 and "module_api" not in rec and "deep_variant" not in rec
+
+
 def test_bench_launcher_counts_gpus_without_hip_and_refuses_more_ranks_than_gpus():
     """bench.visible_gpus() reads the KFD topology of THIS box (no HIP call); asking for one rank more than there are GPUs is
     refused (rc 2) before any child starts -- or, where the topology is unreadable, fails in the rank that finds no device."""
