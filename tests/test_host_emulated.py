@@ -216,7 +216,7 @@ def _check_wire(outs):
     for r in outs:
         f, b = r["fp32"], r["bf16"]
         assert f["dtypes"] == ["torch.float32"] and b["dtypes"] == ["torch.bfloat16"] and b["all_reduces"] == f["all_reduces"] == f["nb"] > 4
-        assert f["loss"] == b["loss"]
+        assert abs(f["loss"] - b["loss"]) <= 1e-6 * abs(f["loss"])  # computed before any gradient moves (GPU: fp32 atomics in the loss sum)
         gf, gb = f["grad"], b["grad"]
         n = gf.numel() // 4096 * 4096
         blocks_f, blocks_b = gf[:n].view(-1, 4096), gb[:n].view(-1, 4096)
