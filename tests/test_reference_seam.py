@@ -131,3 +131,68 @@ def test_member_random_stream_is_the_reference_drivers(monkeypatch):
         sid, xm = mine[i]
         assert sid == rank * per + i
         assert (xm - x).abs().max().item() <= 3e-4 * x.abs().max().item()
+
+
+def test_the_training_loop_with_five_strings_changed_follows_the_reference(monkeypatch):
+    """training_loop.py:85-131,369-391 executed twice from the same seed: once with the reference's own classes (model.score.ScoreUNet
+    over the zuko shim, torch.optim.AdamW, thor.pipelines.SDAPipeline, thor.ema.StandardEMA, thor.lr) and once with the five class_name /
+    func_name strings of train.py:164-193 pointing at this package -- everything resolved by name through construct_class_by_name the
+    way the loop does it.  Same draws (CPU tensors take the reference's loss arithmetic), so after three optimizer steps the losses,
+    the 228-key state_dict, the EMA copy and the optimizer's state_dict must agree."""
+    import sys
+    emu_ops.install(monkeypatch, c2w_ops)
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_shim")
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.syspath_prepend(shim)
+    for name, path in (("thor_pipelines_ref", f"{REF}/src/thor/pipelines.py"), ("thor_ema_ref", f"{REF}/src/thor/ema.py"), ("thor_lr_ref", f"{REF}/src/thor/lr.py")):
+        sys.modules[name] = _load(name, path)
+    from climate2weather_amd import util as c2w_util
+
+    def run(strings):
+        net_kw = c2w_util.EasyDict(class_name=strings["net"], channels=6, spatial=2, activation=torch.nn.SiLU, **TINY)
+        opt_kw = c2w_util.EasyDict(class_name=strings["opt"], lr=1e-3, weight_decay=1e-3, betas=[0.9, 0.999])  # train.py:175-180
+        pipe_kw = c2w_util.EasyDict(class_name=strings["pipe"])
+        ema_kw = c2w_util.EasyDict(class_name=strings["ema"])
+        lr_kw = c2w_util.EasyDict(func_name=strings["lr"], ref_lr=1e-3, total_ndata=40)
+        torch.manual_seed(42)
+        net = c2w_util.construct_class_by_name(**net_kw)  # training_loop.py:88-89
+        net.train()
+        pipeline = c2w_util.construct_class_by_name(**pipe_kw)
+        optimizer = c2w_util.construct_class_by_name(params=net.parameters(), **opt_kw)  # training_loop.py:119-121
+        ema = c2w_util.construct_class_by_name(net=net, **ema_kw)
+        state = c2w_util.EasyDict(cur_ndata=0)
+        batch_size, losses = 2, []
+        g = torch.Generator().manual_seed(7)
+        for _ in range(3):  # training_loop.py:369-391
+            optimizer.zero_grad()
+            data = torch.randn(batch_size, 6, 16, 16, generator=g) * 0.5 + 0.5
+            loss = pipeline.loss(net=net, x=data).mean().mul(1.0)
+            loss.backward()
+            lr = c2w_util.call_func_by_name(cur_ndata=state.cur_ndata, **lr_kw)
+            for grp in optimizer.param_groups:
+                grp["lr"] = lr
+            optimizer.step()
+            losses.append(loss.detach().item())
+            state.cur_ndata += batch_size
+            ema.update(cur_ndata=state.cur_ndata, batch_size=batch_size)
+        return losses, net.state_dict(), ema.emas[0].state_dict(), optimizer.state_dict()
+
+    ref = run(dict(net="model.score.ScoreUNet", opt="torch.optim.AdamW", pipe="thor_pipelines_ref.SDAPipeline", ema="thor_ema_ref.StandardEMA",
+                   lr="thor_lr_ref.linear_learning_rate_schedule"))
+    mine = run(dict(net="climate2weather_amd.score.ScoreUNet", opt="climate2weather_amd.optim.AdamW", pipe="climate2weather_amd.pipelines.SDAPipeline",
+                    ema="climate2weather_amd.ema.StandardEMA", lr="climate2weather_amd.lr.linear_learning_rate_schedule"))
+    assert np.allclose(ref[0], mine[0], rtol=2e-5), (ref[0], mine[0])
+    keys = [k for k in ref[1] if not k.endswith(".eps")]  # zuko's LayerNorm registers eps as a buffer
+    assert keys == list(mine[1].keys()) and len(keys) == len(list(mine[1]))
+    # Two independent differentiations (torch autograd over the reference's modules / this package's hand-written backward) agree to
+    # fp32 round-off; Adam turns the round-off of a vanishing gradient (the attention key bias has none at all; single entries
+    # elsewhere) into a full step of lr = 1e-3 per iteration.  So: essentially every entry equal, none further apart than the three steps.
+    for k in keys:
+        for a, b in ((ref[1][k], mine[1][k]), (ref[2][k], mine[2][k])):
+            d = (a - b).abs()
+            assert d.max().item() <= 3 * 1e-3 * 1.05, (k, d.max().item())
+            if not k.endswith("qkv.bias"):
+                assert d.mean().item() <= 2e-6 and (d > 1e-5).float().mean().item() <= 0.02, (k, d.mean().item())
+    so_r, so_m = ref[3], mine[3]
+    assert so_r["state"].keys() == so_m["state"].keys() and all(float(so_m["state"][i]["step"]) == 3.0 for i in so_m["state"])
+    assert so_r["param_groups"][0]["lr"] == so_m["param_groups"][0]["lr"]
