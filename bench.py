@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--sample-steps", type=int, default=2, help="sampler steps timed after the headline run (0 = skip)")
     p.add_argument("--kernel-steps", type=int, default=2, help="extra steps with every implicit-GEMM launch timed (by_kernel; 0 = skip)")
     p.add_argument("--no-extras", action="store_true", help="skip by_kernel, the deep-variant leg and the sampler legs")
+    p.add_argument("--module-api-child", type=float, default=None, metavar="TRAINER_WINDOWS_PER_S",
+                   help="internal: run only the module_api legs (bench.py starts itself with this for a fresh process) and print their JSON")
     p.add_argument("--light-extras", action="store_true",
                    help="only the extras every rank of a multi-GPU job runs (vendor GEMM, by_kernel, sampler legs incl. the member-sharded one)")
     return p.parse_args()
@@ -356,11 +358,13 @@ def cpu_baseline(C, size, cfg):
 
 
 def _empty_cache():
-    """Between legs the allocator KEEPS its cached blocks (288 GB of HBM hold every leg's working set side by side): a leg that starts
-    on freshly re-allocated memory -- empty_cache() hands 100+ GB back to the driver, the next leg's hipMallocs get it back in
-    fragments -- measured 2 % slower than the same leg on recycled blocks (round 4, same box, same process: module-API legs 0.952 /
-    0.928 of the headline after empty_cache() against 0.976 / 0.947 without).  C2W_BENCH_EMPTY_CACHE=1 restores the old behaviour."""
-    if os.environ.get("C2W_BENCH_EMPTY_CACHE") == "1":
+    """Between the extra legs of this process the allocator's cached blocks go back to the driver (C2W_BENCH_KEEP_CACHE=1: keep them).
+    Either way a leg that runs late in a long-lived process is 2-6 % slower than the same leg in a process of its own (round 4:
+    module-API legs 0.93-0.95 of the headline after empty_cache(), 0.915-0.976 on a kept cache depending on what ran before,
+    0.97 / 0.94 in a fresh process; the first conditioned-sampler leg 5.7 k -> 2.2 k window-forwards/s on a kept cache) -- memory handed
+    back and re-obtained comes in fragments.  The legs that are compared WITH the headline (module_api) therefore run in a child
+    process, like the headline's own ranks."""
+    if os.environ.get("C2W_BENCH_KEEP_CACHE") != "1":
         torch.cuda.empty_cache()
 
 
@@ -588,7 +592,7 @@ def run_rank(a):
         out["deep_variant"] = deep_variant(dev)
         gc.collect()
         _empty_cache()
-        out["module_api"] = module_api(dev, a, out["value"])
+        out["module_api"] = module_api_child(a, out["value"])
         gc.collect()
         _empty_cache()
         out["sampler_configs3"] = sampler_configs3(dev, a.precision if a.precision != "fp32" else "bf16")
@@ -694,6 +698,24 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         del tr, net, feed, ds
         _empty_cache()
     return res
+
+
+def module_api_child(a, trainer_windows_per_s):
+    """module_api() in a process of its own (this one stays alive and idle meanwhile, its cached memory returned): the same
+    conditions the headline number was taken under.  The child is this file with --module-api-child; it prints one JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--module-api-child", str(trainer_windows_per_s), "--steps", str(a.steps), "--warmup", str(a.warmup),
+           "--batch", str(a.batch), "--vars", str(a.vars), "--markov-order", str(a.markov_order), "--size", str(a.size)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return dict(error="module-api child failed", returncode=r.returncode, stderr_tail=r.stderr[-600:])
+        res = json.loads(lines[-1])
+        res["process"] = "child process of bench.py (fresh allocator, like the headline's own ranks)"
+        return res
+    except subprocess.TimeoutExpired:
+        return dict(error="module-api child timed out")
 
 
 def deep_variant(dev, B=32):
@@ -840,6 +862,10 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
 
 def main():
     a = parse()
+    if a.module_api_child is not None:
+        torch.cuda.set_device(0)
+        print(json.dumps(module_api(torch.device("cuda", 0), a, a.module_api_child)), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch(a))
     run_rank(a)
