@@ -86,6 +86,9 @@ class Layout:
         self._off = 0
         # Flat order = reverse of the order in which backward finalises gradients (time MLP last, output conv first), so
         # the finished part of the gradient buffer is always a growing suffix -> bucketed all-reduce can chase it.
+        self.forcing_dim = net.map_forcing.in_features if getattr(net, "map_forcing", None) is not None else 0
+        if self.forcing_dim:  # model/score.py:49-51; its gradient is final together with map_layer1's: same place in the flat order
+            self._add("map_forcing", self.E, self.forcing_dim, 1, kstride=_round_up(self.forcing_dim, 32), lin=True)
         self._add("map_layer0", self.E, self.noise_features, 1, lin=True)
         self._add("map_layer1", self.E, self.E, 1, lin=True)
         off = self._off
@@ -136,7 +139,7 @@ class Layout:
         dg = 0
         dgl = 0
         for rec in self.convs.values():
-            if rec.name == "map_layer0":
+            if rec.name in ("map_layer0", "map_forcing"):
                 continue
             size = _round_up(rec.cin * rec.taps * rec.dg_ld, ALIGN)
             if rec.lin:
@@ -578,7 +581,7 @@ class Engine:
         ops.conv(x, self._w(rec, DTYPE_F32), self._b(rec), y, g, DTYPE_F32, act=act)
         if tape is not None:
             def bw(gy: torch.Tensor) -> Optional[torch.Tensor]:
-                self._wg(x, gy, rec, g, DTYPE_F32)
+                self._wgrad(rec, x, gy, g, DTYPE_F32)  # (a padded operand -- map_forcing -- goes through its padded scratch)
                 if not need_dx:
                     tape.done(rec.w_off)
                     return None
@@ -610,7 +613,8 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, dt: int, tape: Optional[Tape] = None, noise: Optional[Tuple] = None,
-                want_dx: bool = False, nhwc_out: bool = False, x_nhwc: Optional[torch.Tensor] = None, shape=None):
+                want_dx: bool = False, nhwc_out: bool = False, x_nhwc: Optional[torch.Tensor] = None, shape=None,
+                forcing: Optional[torch.Tensor] = None):
         """eps_pred = ScoreUNet(x, t).  x: (B,C,H,W) fp32 on the GPU; t: numel 1 or B.
         noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion; eps may be an int
         seed instead of a tensor: the kernel regenerates the Philox stream of that seed (ops.philox_normal) and eps never exists.
@@ -647,7 +651,27 @@ class Engine:
         pe = torch.empty((Bt, lay.noise_features), dtype=torch.float32, device=dev)
         ops.timestep_embedding(tt, pe, Bt, lay.noise_features)
         emb = self._mlp_layer("map_layer0", pe, Bt, tape, need_dx=False)
-        emb = self._mlp_layer("map_layer1", emb, Bt, tape)
+        zf = None
+        if lay.forcing_dim:  # emb = silu(map_layer1(.) + map_forcing(forcing))  (model/score.py:64-67)
+            if forcing is None:
+                raise ValueError("forcing_dim > 0: the forcing vector is required")
+            rf = lay.convs["map_forcing"]
+            fr = forcing.reshape(-1, lay.forcing_dim).to(device=dev, dtype=torch.float32)
+            if fr.shape[0] not in (1, Bt) and not (Bt == 1 and fr.shape[0] == B):
+                raise ValueError(f"forcing has {fr.shape[0]} rows for {Bt} time values / {B} batch items")
+            if Bt == 1 and fr.shape[0] == B and B > 1:  # scalar t, per-item forcing: the embedding becomes per item
+                raise NotImplementedError("per-item forcing with a scalar t: pass t with one value per batch item")
+            fpad = torch.zeros((Bt, rf.kstride), dtype=torch.float32, device=dev)
+            fpad[:, : lay.forcing_dim] = fr if fr.shape[0] == Bt else fr.expand(Bt, -1)
+            zf = self._linear("map_forcing", fpad, Bt, ACT_NONE, None)  # not on the tape: its gradient is map_layer1's pre-activation gradient
+            g_f = self._geom(Bt, 1, 1, rf.kstride, 1, 1, rf.rows, rf.rows, rf.rows, CONV_1X1)
+
+            def forcing_bw(gz, rf=rf, fpad=fpad, g_f=g_f):
+                self._wgrad(rf, fpad, gz, g_f, DTYPE_F32)
+                tape.done(rf.w_off)
+        elif forcing is not None:
+            raise ValueError("forcing passed to a network built with forcing_dim == 0 (model/score.py:60)")
+        emb = self._mlp_layer("map_layer1", emb, Bt, tape, add=zf, add_bw=forcing_bw if zf is not None and tape is not None else None)
         m_all = self._linear("proj", emb, Bt, ACT_NONE, tape)
         if train:
             dm_all = torch.zeros_like(m_all)
@@ -909,11 +933,19 @@ class Engine:
         ops.nhwc_to_nchw(cur, y, B, lay.out_channels, H * W, lay.cout_pad, dt)
         return y
 
-    def _mlp_layer(self, name: str, x: torch.Tensor, rows: int, tape: Optional[Tape], need_dx: bool = True) -> torch.Tensor:
-        """silu(Linear(x)) of the time-embedding MLP (model/score.py:62-67); keeps the pre-activation when taping."""
-        if tape is None:
+    def _mlp_layer(self, name: str, x: torch.Tensor, rows: int, tape: Optional[Tape], need_dx: bool = True,
+                   add: Optional[torch.Tensor] = None, add_bw: Optional[Callable] = None) -> torch.Tensor:
+        """silu(Linear(x) [+ add]) of the time-embedding MLP (model/score.py:62-67; ``add`` = the forcing projection, :65-66); keeps the
+        pre-activation when taping."""
+        if tape is None and add is None:
             return self._linear(name, x, rows, ACT_SILU, None)
         z = self._linear(name, x, rows, ACT_NONE, None)
+        if add is not None:
+            z.add_(add)  # (rows, E) fp32: the one tensor-arithmetic line of the forward; its adjoint hands gz to both Linears unchanged
+        if tape is None:
+            h = torch.empty_like(z)
+            ops.silu(z, h, z.numel(), DTYPE_F32)
+            return h
         h = torch.empty_like(z)
         ops.silu(z, h, z.numel(), DTYPE_F32)
         rec = self.layout.convs[name]
@@ -922,6 +954,8 @@ class Engine:
         def bw(gh: torch.Tensor) -> Optional[torch.Tensor]:
             gz = torch.empty_like(z)
             ops.silu_backward(z, gh, gz, z.numel(), DTYPE_F32)
+            if add_bw is not None:  # z = Linear(x) + add: the same gz is the output gradient of whatever produced `add`
+                add_bw(gz)
             self._wg(x, gz, rec, g, DTYPE_F32)
             if not need_dx:
                 tape.done(rec.w_off)

@@ -35,12 +35,13 @@ class _TapeHolder:
     lives exactly as long as something references the holder or the context -- no global table, no finalizers (a context of
     a grad-disabled level can die between two ``setup_context`` calls of the same forward: seen under the reference's
     ``torch.func.jacrev(log_p)`` with ``exact_grad=False``)."""
-    __slots__ = ("tape", "loss", "loss_sum")
+    __slots__ = ("tape", "loss", "loss_sum", "forcing")
 
-    def __init__(self, loss=None):
+    def __init__(self, loss=None, forcing=None):
         self.tape = None
         self.loss = loss  # fused-loss request of SDAPipeline.loss: dict(eps=<int seed | (B,C,H,W) tensor>, eta=float), else None
         self.loss_sum = None
+        self.forcing = forcing  # (B or 1, forcing_dim) conditioning vector of model/score.py:65-66 (a constant of the node), or None
 
 
 class _ScoreUNetFn(torch.autograd.Function):
@@ -54,7 +55,7 @@ class _ScoreUNetFn(torch.autograd.Function):
         if holder.loss is not None:  # noise process + network + unreduced loss in one node (src/thor/pipelines.py:27-35)
             y, holder.loss_sum = _forward_loss(eng, x, t, dt, holder.loss, tape)
         else:
-            y = eng.forward(x, t, dt, tape=tape, want_dx=True)
+            y = eng.forward(x, t, dt, tape=tape, want_dx=True, forcing=holder.forcing)
         holder.tape = tape
         return y
 
@@ -197,9 +198,8 @@ class ScoreUNet(torch.nn.Module):
 
     def __init__(self, channels, embedding_dim, forcing_dim=0, **kwargs):
         super().__init__()
-        if forcing_dim > 0:
-            raise NotImplementedError("forcing is never passed by the reference's callers (SURVEY.md a2)")
-        self.map_forcing = None
+        # created FIRST, like the reference (model/score.py:49-51): the parameter creation order is the RNG order
+        self.map_forcing = torch.nn.Linear(forcing_dim, embedding_dim) if forcing_dim > 0 else None
         self.embedding_dim = embedding_dim
         self.noise_features = 32
         self.unet = UNet(channels, channels, embedding_dim, **kwargs)
@@ -268,7 +268,11 @@ class ScoreUNet(torch.nn.Module):
         return DTYPE_F16 if torch.get_autocast_dtype("cuda") == torch.float16 else DTYPE_BF16
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, forcing: Optional[torch.Tensor] = None) -> torch.Tensor:
-        assert forcing is None, "forcing_dim == 0"
+        assert (forcing is None) or (self.map_forcing is not None)  # model/score.py:60
+        if self.map_forcing is not None and forcing is None:
+            raise ValueError("this network was built with forcing_dim > 0: forward() needs the forcing vector (model/score.py:65-66)")
+        if forcing is not None and torch.is_grad_enabled() and forcing.requires_grad:
+            raise NotImplementedError("gradients with respect to the forcing vector are not provided (no caller of the reference asks for them)")
         eng = self._get_engine()
         dt = self.compute_dtype()
         params = eng._bound  # the Parameter objects in layout order (is_attached has just verified they are the module's)
@@ -287,9 +291,9 @@ class ScoreUNet(torch.nn.Module):
         shape = x.shape
         x4 = x.reshape(-1, *shape[-3:]) if x.dim() != 4 else x
         if needs_grad or _in_functorch_transform(x):
-            y = _ScoreUNetFn.apply(x4, t, self, dt, _TapeHolder(), *params)
+            y = _ScoreUNetFn.apply(x4, t, self, dt, _TapeHolder(forcing=forcing), *params)
         else:
-            y = eng.forward(x4, t, dt)
+            y = eng.forward(x4, t, dt, forcing=forcing)
         return y.reshape(shape).to(x.dtype)
 
     def _ordered_params(self, eng: Engine):

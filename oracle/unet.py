@@ -20,7 +20,7 @@ Each function cites the reference file:line it follows.
 from __future__ import annotations
 
 import math
-from typing import Dict, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -46,11 +46,13 @@ def channel_layer_norm(x: Tensor, dim: int = 1, eps: float = 1e-5, ln_unbiased: 
     return (x - mean) / (var + eps).sqrt()
 
 
-def time_mlp(sd: SD, t: Tensor, noise_features: int = 32) -> Tensor:
-    """model/score.py:61-67 (forcing_dim == 0 path)."""
+def time_mlp(sd: SD, t: Tensor, noise_features: int = 32, forcing: Optional[Tensor] = None) -> Tensor:
+    """model/score.py:61-67; with ``forcing`` the projection of model/score.py:49-51 is added before the second SiLU (:65-66)."""
     e = timestep_embedding(t.reshape(-1), noise_features)
     e = F.silu(F.linear(e, sd["map_layer0.weight"], sd["map_layer0.bias"]))
     e = F.linear(e, sd["map_layer1.weight"], sd["map_layer1.bias"])
+    if forcing is not None:
+        e = e + F.linear(forcing, sd["map_forcing.weight"], sd["map_forcing.bias"])
     return F.silu(e)
 
 
@@ -130,9 +132,10 @@ def score_unet_forward(
     attention_levels: Sequence[int] = (),
     act=F.silu,
     ln_unbiased: bool = True,
+    forcing: Optional[Tensor] = None,
 ) -> Tensor:
     """model/score.py:59-70."""
-    emb = time_mlp(sd, t)
+    emb = time_mlp(sd, t, forcing=forcing)
     return unet_forward(sd, x, emb, hidden_blocks, attention_levels, act, ln_unbiased).reshape(x.shape)
 
 
@@ -154,5 +157,4 @@ class OracleScoreUNet(torch.nn.Module):
         return dict(zip(self.keys, self.params))
 
     def forward(self, x: Tensor, t: Tensor, forcing=None) -> Tensor:
-        assert forcing is None
-        return score_unet_forward(self.sd(), x, t, self.hidden_blocks, self.attention_levels, self.act, self.ln_unbiased)
+        return score_unet_forward(self.sd(), x, t, self.hidden_blocks, self.attention_levels, self.act, self.ln_unbiased, forcing=forcing)

@@ -163,6 +163,34 @@ def tiny_net_relu():
     np.savez_compressed(os.path.join(HERE, "tiny_net_relu.npz"), **out)
 
 
+def tiny_net_forcing():
+    """model/score.py:49-51,65-66: the forcing projection (no caller in the reference passes forcing, the code path exists): the tiny
+    network with forcing_dim = 5 -- map_forcing is created FIRST, so the same seed gives other weights than tiny_net.npz; the tests
+    rebuild them from the seed (creation-order parity) and only fingerprints travel -- output, loss, the L2 norm of every gradient,
+    and the gradients of map_forcing / map_layer1 / one conv in full; plus a scalar-t call with one forcing row."""
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, forcing_dim=5, **TINY)
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn(2, 6, 16, 16, generator=g) * 0.5 + 0.5
+    t = torch.rand(2, generator=g)
+    eps = torch.randn(2, 6, 16, 16, generator=g)
+    forcing = torch.randn(2, 5, generator=g)
+    y = net(x, t, forcing=forcing)
+    loss = ((y - eps) ** 2).mean()
+    names = [k for k, _ in net.named_parameters()]
+    grads = dict(zip(names, torch.autograd.grad(loss, list(net.parameters()))))
+    out = {"x": x.numpy(), "t": t.numpy(), "eps": eps.numpy(), "forcing": forcing.numpy(), "y": y.detach().numpy(),
+           "loss": np.array(loss.item(), dtype=np.float64), "names": np.array(names),
+           "sd_abs_sum": np.array(sum(v.double().abs().sum().item() for v in net.state_dict().values())),
+           "grad_norm": np.array([grads[k].double().norm().item() for k in names])}
+    for k in ("map_forcing.weight", "map_forcing.bias", "map_layer1.weight", "map_layer0.bias", "unet.heads.0.weight"):
+        out["grad." + k] = grads[k].numpy()
+    with torch.no_grad():
+        out["y_scalar_t"] = net(x[:1], torch.tensor(0.3), forcing=forcing[:1]).numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_net_forcing.npz"), **out)
+    print("tiny_net_forcing: loss", loss.item(), "keys", list(net.state_dict().keys())[:2])
+
+
 def sampler(net):
     """Sampler trajectories on the tiny net: L=9, F=2, k=1, 32^2, 4 steps."""
     pipe = pipelines.SDAPipeline()
@@ -342,11 +370,14 @@ if __name__ == "__main__":
         tiny_net_relu()
     elif sys.argv[1:] == ["sampler_tensor_gamma"]:
         sampler_tensor_gamma()
+    elif sys.argv[1:] == ["tiny_net_forcing"]:
+        tiny_net_forcing()
     else:
         kats()
         ops()
         net = tiny_net()
         tiny_net_relu()
+        tiny_net_forcing()
         sampler(net)
         sampler_tensor_gamma()
         ema_kat()

@@ -265,6 +265,38 @@ def test_packed_weight_copies_keep_their_addresses_and_follow_the_weights(emu, g
     assert eng._pk[kf].data_ptr() == ptr0
 
 
+def test_forcing_projection_matches_the_reference(emu, golden_dir):
+    """forcing_dim > 0 (model/score.py:49-51,65-66): creation order (map_forcing first), forward with per-item and scalar t, loss and all
+    gradients against the imported reference's (tests/golden/tiny_net_forcing.npz); state_dict round trip; the argument checks."""
+    g = _golden(golden_dir, "tiny_net_forcing.npz")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, forcing_dim=5, **TINY)
+    assert list(net.state_dict().keys())[:2] == ["map_forcing.weight", "map_forcing.bias"] and len(net.state_dict()) == len(g["names"])
+    assert sum(v.double().abs().sum().item() for v in net.state_dict().values()) == pytest.approx(float(g["sd_abs_sum"]), rel=1e-12)
+    x, t, eps, forcing = (torch.from_numpy(g[k]) for k in ("x", "t", "eps", "forcing"))
+    y = net(x, t, forcing=forcing)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), atol=2e-5)
+    loss = ((y - eps) ** 2).mean()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    named = dict(net.named_parameters())
+    for n, ref in zip([str(v) for v in g["names"]], g["grad_norm"]):
+        assert named[n].grad.double().norm().item() == pytest.approx(float(ref), rel=5e-4, abs=1e-9), n
+    for n in ("map_forcing.weight", "map_forcing.bias", "map_layer1.weight", "map_layer0.bias", "unet.heads.0.weight"):
+        ref = torch.from_numpy(g["grad." + n])
+        assert torch.allclose(named[n].grad, ref, atol=1e-6 + 2e-4 * ref.abs().max().item()), n
+    with torch.no_grad():
+        assert torch.allclose(net(x[:1], torch.tensor(0.3), forcing=forcing[:1]), torch.from_numpy(g["y_scalar_t"]), atol=2e-5)
+        with pytest.raises(ValueError):
+            net(x, t)  # built with forcing_dim > 0: the vector is required
+        with pytest.raises(AssertionError):
+            _tiny()(x, t, forcing=forcing)  # model/score.py:60
+    other = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, forcing_dim=5, **TINY)
+    other.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        assert torch.equal(other(x, t, forcing=forcing), net(x, t, forcing=forcing))
+
+
 def test_fp16_snapshot_module_round_trip_runs(emu):
     """training_loop.py:254-265 pickles ``deepcopy(ema).cpu().eval().requires_grad_(False).to(torch.float16)`` and
     exp/downscaling.py:110-126 unpickles it and calls it: the half-precision module object itself must run (the engine keeps

@@ -62,6 +62,42 @@ def test_tiny_net_fp32_forward_and_grads_vs_golden(golden_dir):
     print("worst relative grad error", worst)
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_forcing_projection_vs_reference(golden_dir, precision, tol):
+    """forcing_dim > 0 (model/score.py:49-51,65-66) on the GPU: weights from the seed (map_forcing is created first), output, loss and
+    gradients against the imported reference's (tests/golden/tiny_net_forcing.npz); 5 forcing features ride a K chunk padded to 32."""
+    g = _golden(golden_dir, "tiny_net_forcing.npz")
+    cfg = dict(TINY, hidden_channels=[64, 128]) if precision != "fp32" else TINY
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, forcing_dim=5, **cfg).cuda()
+    net.precision = precision
+    x, t, eps, forcing = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "eps", "forcing"))
+    if precision == "fp32":
+        assert sum(v.double().abs().sum().item() for v in net.state_dict().values()) == pytest.approx(float(g["sd_abs_sum"]), rel=1e-12)
+        y = net(x, t, forcing=forcing)
+        assert _rel(y, torch.from_numpy(g["y"])) <= 1e-4
+        loss = ((y - eps) ** 2).mean()
+        assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-4)
+        loss.backward()
+        named = dict(net.named_parameters())
+        for n, ref in zip([str(v) for v in g["names"]], g["grad_norm"]):
+            assert named[n].grad.double().norm().item() == pytest.approx(float(ref), rel=5e-4, abs=1e-9), n
+        for n in ("map_forcing.weight", "map_forcing.bias", "map_layer1.weight", "map_layer0.bias", "unet.heads.0.weight"):
+            assert _rel(named[n].grad, torch.from_numpy(g["grad." + n])) <= tol, n
+        with torch.no_grad():
+            assert _rel(net(x[:1], torch.tensor(0.3), forcing=forcing[:1]), torch.from_numpy(g["y_scalar_t"])) <= 1e-4
+        return
+    # 16-bit: a wider tiny net (whole 64-channel K chunks) against the CPU oracle on the same weights
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    y = net(x, t, forcing=forcing)
+    yo = ou.score_unet_forward(sd, x.cpu(), t.cpu(), cfg["hidden_blocks"], cfg["attention_levels"], forcing=forcing.cpu())
+    assert _rel(y, yo.detach()) <= tol
+    ((y - eps) ** 2).mean().backward()
+    go = torch.autograd.grad(((yo - eps.cpu()) ** 2).mean(), [sd["map_forcing.weight"], sd["map_layer1.weight"]])
+    named = dict(net.named_parameters())
+    assert _rel(named["map_forcing.weight"].grad, go[0]) <= 2 * tol and _rel(named["map_layer1.weight"].grad, go[1]) <= 2 * tol
+
+
 def test_tiny_net_input_gradient_fp32(golden_dir):
     g = _golden(golden_dir, "tiny_net.npz")
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}

@@ -13,6 +13,7 @@ from oracle import host as oh
 from oracle import unet as ou
 
 TINY = dict(hidden_blocks=[1, 1], attention_levels=[1])
+TINY_CFG = dict(embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
 
 
 def _load(golden_dir, name):
@@ -110,6 +111,33 @@ def test_tiny_net_forward_loss_grads(golden_dir):
     with torch.no_grad():
         y32 = ou.score_unet_forward(sd, _t(g["x32"]), torch.tensor(0.3), **TINY)
     assert torch.allclose(y32, _t(g["y32"]), atol=1e-5)
+
+
+def test_forcing_projection_against_the_reference(golden_dir):
+    """model/score.py:49-51,65-66 (forcing_dim > 0): output, loss and gradients of the imported reference on the tiny network with a
+    5-wide forcing vector; the weights are rebuilt from the seed (map_forcing is created first: creation-order parity)."""
+    from climate2weather_amd.score import ScoreUNet
+    g = _load(golden_dir, "tiny_net_forcing.npz")
+    torch.manual_seed(3)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, forcing_dim=5, **{**TINY_CFG})
+    assert list(net.state_dict().keys())[:2] == ["map_forcing.weight", "map_forcing.bias"]
+    assert sum(v.double().abs().sum().item() for v in net.state_dict().values()) == pytest.approx(float(g["sd_abs_sum"]), rel=1e-12)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x, t, eps, forcing = (_t(g[k]) for k in ("x", "t", "eps", "forcing"))
+    y = ou.score_unet_forward(sd, x, t, forcing=forcing, **TINY)
+    assert torch.allclose(y, _t(g["y"]), atol=1e-5)
+    loss = ((y - eps) ** 2).mean()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    names = [str(n) for n in g["names"]]
+    grads = dict(zip(names, torch.autograd.grad(loss, [sd[n] for n in names])))
+    for n, ref in zip(names, g["grad_norm"]):
+        assert grads[n].double().norm().item() == pytest.approx(float(ref), rel=2e-4, abs=1e-9), n
+    for n in ("map_forcing.weight", "map_forcing.bias", "map_layer1.weight", "map_layer0.bias", "unet.heads.0.weight"):
+        ref = _t(g["grad." + n])
+        assert torch.allclose(grads[n], ref, atol=1e-6 + 1e-4 * ref.abs().max().item()), n
+    with torch.no_grad():
+        ys = ou.score_unet_forward(sd, x[:1], torch.tensor(0.3), forcing=forcing[:1], **TINY)
+    assert torch.allclose(ys, _t(g["y_scalar_t"]), atol=1e-5)
 
 
 def test_window_fold_unfold_and_sampler(golden_dir):
