@@ -210,3 +210,81 @@ def run_module_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: s
                os.path.join(out_dir, f"mod{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_five_strings_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
+    """The reference's configuration: the module wrapped in torch DDP (fabric.setup_module, training_loop.py:116), the loop of
+    training_loop.py:369-391, and all five seams pointing at this package -- in particular climate2weather_amd.optim.AdamW over the
+    DDP-averaged gradients and SDAPipeline.loss as one autograd node called THROUGH the DDP wrapper.  Three steps; rank r sees item r
+    of each global batch of 2.  Saved: losses, weights, whether the optimizer ran its flat path, and (rank 0) the same three steps in
+    ONE process on the whole batch with torch.optim.AdamW and the reference's loss arithmetic for comparison."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import emu_ops
+    from climate2weather_amd import ops as c2w_ops
+    for name in emu_ops.ALL:
+        if hasattr(c2w_ops, name):
+            setattr(c2w_ops, name, getattr(emu_ops, name))
+    c2w_ops.EMULATED = True
+    from climate2weather_amd.ema import StandardEMA
+    from climate2weather_amd.optim import AdamW
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score import ScoreUNet, _LossTensor
+
+    cfg = dict(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[32, 64], hidden_blocks=[1, 1],
+               attention_levels=[1], kernel_size=3, padding_mode="zeros")
+    gen = torch.Generator().manual_seed(11)
+    data = [torch.randn(world, 6, 16, 16, generator=gen) * 0.5 + 0.5 for _ in range(3)]
+    draws = [(torch.rand(world, 1, 1, 1, generator=gen), torch.randn(world, 6, 16, 16, generator=gen)) for _ in range(3)]
+
+    class Injected(SDAPipeline):  # the loop's own draws replaced by recorded ones, so that the ranks' items form one known batch
+        fused_loss = "eps"
+
+        def loss(self, net, x, forcing=None):
+            from climate2weather_amd.pipelines import _engine_module
+            core = _engine_module(net)
+            t, eps = self._next
+            core.__dict__["_loss_request"] = dict(eps=eps, eta=self.eta)
+            try:
+                return net(x, t)
+            finally:
+                core.__dict__.pop("_loss_request", None)
+
+    torch.manual_seed(3)
+    net = ScoreUNet(**cfg)
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    pipeline, optimizer, ema = Injected(), AdamW(params=net.parameters(), lr=1e-3, weight_decay=1e-3, betas=[0.9, 0.999]), StandardEMA(net=net)
+    losses, fused = [], []
+    for i in range(3):
+        optimizer.zero_grad()
+        pipeline._next = (draws[i][0][rank:rank + 1], draws[i][1][rank:rank + 1])
+        out = pipeline.loss(net=ddp, x=data[i][rank:rank + 1])
+        fused.append(isinstance(out, _LossTensor))
+        loss = out.mean().mul(1.0)
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.detach().item())
+        ema.update()
+    res = dict(losses=losses, sd={k: v.detach().clone() for k, v in net.state_dict().items()}, flat=bool(optimizer._flat), fused=fused,
+               ema={k: v.detach().clone() for k, v in ema.emas[0].state_dict().items()})
+    if rank == 0:  # single process, whole batch, torch's optimizer, the reference's tensor arithmetic
+        torch.manual_seed(3)
+        ref = ScoreUNet(**cfg)
+        opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=1e-3, betas=(0.9, 0.999))
+        plain = SDAPipeline()
+        ref_losses = []
+        for i in range(3):
+            opt.zero_grad()
+            t, eps = draws[i]
+            xt = plain.mu(t) * data[i] + plain.sigma(t) * eps
+            l = ((ref(xt, t) - eps) ** 2).mean()
+            l.backward()
+            opt.step()
+            ref_losses.append(l.item())
+        res["ref_losses"], res["ref_sd"] = ref_losses, {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    torch.save(res, os.path.join(out_dir, f"five{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -172,6 +172,15 @@ def test_bench_multi_rank_extras_run_through_the_communicator(tmp_path):
                          capture_output=True, text=True, env=env, timeout=1200)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    # the driver's contract for the one JSON line (metric / value / unit / ... / roofline / cpu_baseline keys present, value = whole job)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "step_ms"):
+        assert key in rec, key
+    assert rec["unit"] == "windows/s" and rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert rec["dtype"] == "bf16" and rec["data"] == "synthetic" and "workload" in rec["config"] and "model" not in rec["config"]
+    assert abs(rec["value"] - 8 * n * rec["steps"] / (rec["ms_per_step"] * rec["steps"] / 1e3)) <= 0.01 * rec["value"]
+    rf = rec["roofline"]
+    assert rf is None or (rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf)
     sm = rec["sampler_member_sharded"]
     assert sm["n_gpus"] == n and sm["members_total"] == 8 * n and sm["window_forwards_per_s"] > 0
     assert rec["by_kernel"]["serialised_step_ms"] > 0 and "module_api" not in rec and "deep_variant" not in rec
