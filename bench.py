@@ -607,7 +607,7 @@ def run_rank(a):
         dist.destroy_process_group()
 
 
-def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16"), item=True, lazy=False):
+def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16"), item=True, lazy=False):
     """What a maintainer gets who changes ONLY the five class_name / func_name strings of train.py:164-193 and
     leaves training_loop.py alone: the loop of training_loop.py:369-391, statement for statement -- optimizer.zero_grad(); data =
     next(dataset_iterator) (a dense (B,C,H,W) tensor); loss = pipeline.loss(net, data).mean().mul(loss_scaling) under autocast;
@@ -697,6 +697,12 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         res["trainer_" + prec] = r
         del tr, net, feed, ds
         _empty_cache()
+    # the like-for-like ratio: every leg over the fused bf16 Trainer timed in THIS process, minutes after the headline and on the
+    # same allocator state (vs_trainer compares with the headline line, taken in another process at another moment)
+    if "trainer_bf16" in res:
+        for k, v in res.items():
+            if isinstance(v, dict) and "windows_per_s" in v:
+                v["vs_trainer_same_process"] = round(v["windows_per_s"] / res["trainer_bf16"]["windows_per_s"], 4)
     return res
 
 
