@@ -680,8 +680,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         r.update(final_loss=round(float(state["losses"][-1]), 5), flat_optimizer_path=bool(optimizer._flat), optimizer_steps_taken=optimizer.steps_taken(),
                  loss_scale=scaler.get_scale() if scaler is not None else None)
         res[name] = r
-        del net, optimizer, ema, feed, ds, pipeline, step
-        _empty_cache()
+        del net, optimizer, ema, feed, ds, pipeline, step  # the allocator keeps its blocks: the next leg has the same working set
     # the fused Trainer in the reference's arithmetic type (loss scale, inf check and skipped steps on the device)
     for prec in ("fp16", "bf16"):
         if "trainer_" + prec not in legs:
@@ -696,7 +695,6 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale())
         res["trainer_" + prec] = r
         del tr, net, feed, ds
-        _empty_cache()
     # the like-for-like ratio: every leg over the fused bf16 Trainer timed in THIS process, minutes after the headline and on the
     # same allocator state (vs_trainer compares with the headline line, taken in another process at another moment)
     if "trainer_bf16" in res:
