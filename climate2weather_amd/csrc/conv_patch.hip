@@ -433,6 +433,40 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_ts2_kernel(const C2wConv
     conv_patch_ts2_class<T, CLS>(p, smem, L);
 }
 
+// All four classes in ONE launch (round 4): a workgroup still computes one class of one tile -- the class is picked per workgroup, so the
+// register allocation is the maximum over the four bodies, not their sum -- and the four classes of a tile sit next to each other
+// on the same XCD (blockIdx = 8 * (4 * tile-in-XCD + class slot) + XCD), so that they find the tile's dy patch and their common
+// residual lines in that XCD's L2.  Class slots in the order 3, 1, 2, 0 (most taps first).
+template <typename T>
+__global__ __launch_bounds__(H_NTHR, 2) void conv_patch_ts2_all_kernel(const C2wConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x, xcd = bid & 7, rest = bid >> 3, slot = rest & 3, j = rest >> 2;
+    const int ntile = ((p.Cout + 127) / 128) * p.B * (p.Hin >> 3) * (p.Win >> 4);
+    const int q = ntile >> 3, r = ntile & 7;  // tiles are dealt to the XCDs like the single-class launch deals its workgroups
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    if (j >= (xcd < r ? q + 1 : q)) return;  // (grid padded to a multiple of 8 tiles per class slot)
+    switch (slot) {
+        case 0: conv_patch_ts2_class<T, 3>(p, smem, L); break;
+        case 1: conv_patch_ts2_class<T, 1>(p, smem, L); break;
+        case 2: conv_patch_ts2_class<T, 2>(p, smem, L); break;
+        default: conv_patch_ts2_class<T, 0>(p, smem, L); break;
+    }
+}
+
+template <typename T>
+int launch_ts2_all(const C2wConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_ts2_all_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    const int nN = (a.Cout + 127) / 128;
+    const int nM = a.B * (a.Hin >> 3) * (a.Win >> 4);
+    const int ntile = nM * nN, per_xcd = (ntile + 7) / 8;
+    conv_patch_ts2_all_kernel<T><<<8 * 4 * per_xcd, H_NTHR, H_LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int CLS>
 int launch_ts2_class(const C2wConvArgs& a, hipStream_t st) {
     static bool attr = false;
@@ -448,6 +482,7 @@ int launch_ts2_class(const C2wConvArgs& a, hipStream_t st) {
 
 template <typename T>
 int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
+    if (c2w_knobs().ts2_one_launch) return launch_ts2_all<T>(a, st);
     int rc = launch_ts2_class<T, 3>(a, st);
     if (rc == 0) rc = launch_ts2_class<T, 1>(a, st);
     if (rc == 0) rc = launch_ts2_class<T, 2>(a, st);
