@@ -623,7 +623,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
     from climate2weather_amd.training import Trainer
     w = 2 * a.markov_order + 1
     C, B = a.vars * w, a.batch
-    steps, warm = max(a.steps, 5), max(a.warmup, 2)
+    steps, warm = max(a.steps, 5), max(a.warmup, 3)
     total_ndata = B * (steps + warm + 2) * 4
     res = dict(note="training_loop.py:369-391 with network / optimizer / pipeline / EMA / lr schedule resolved from this package's class names; B = %d, "
                     "C = %d, %dx%d; loss.item() every step as the reference does; vs_trainer = windows/s over the headline Trainer's" % (B, C, a.size, a.size),
@@ -736,15 +736,21 @@ def deep_variant(dev, B=32):
     net = ScoreUNet(channels=80, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
     tr = Trainer(net, SDAPipeline(), lr=1e-4, precision="fp16", ema_rates=[0.9999], seed=1)
     x = torch.randn(B, 80, 256, 256, device=dev) * 0.5 + 0.5
-    for _ in range(2):
+    # four warm-up steps: on freshly returned memory the allocator needs a few steps before every block the two streams hold in turn
+    # exists (seen twice in round 4 with two: 59 and 65 windows/s instead of 600+, every timed step waiting on hipMalloc)
+    for _ in range(4):
         tr.step(x)
     torch.cuda.synchronize()
-    n = 3
+    n = 4
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     t0 = time.perf_counter()
-    for _ in range(n):
+    marks[0].record()
+    for i in range(n):
         tr.step(x)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    res["train_step_ms"] = _step_stats([marks[i].elapsed_time(marks[i + 1]) for i in range(n)])
     res["train_windows_per_s"] = round(B / dt, 1)
     res["train_model_tflops"] = round(B / dt * (3 * GFLOP_FWD_DEEP - 7.9) / 1e3, 1)
     res["train_mfma_frac"] = round(res["train_model_tflops"] / MFMA_PEAK_TFLOPS, 4)
