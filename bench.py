@@ -623,7 +623,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
     from climate2weather_amd.training import Trainer
     w = 2 * a.markov_order + 1
     C, B = a.vars * w, a.batch
-    steps, warm = max(a.steps, 5), max(a.warmup, 3)
+    steps, warm = max(a.steps, 20), max(a.warmup, 3)  # 20 steps = 1 s per leg: the chip's clock wanders by +-3 % over half a second
     total_ndata = B * (steps + warm + 2) * 4
     res = dict(note="training_loop.py:369-391 with network / optimizer / pipeline / EMA / lr schedule resolved from this package's class names; B = %d, "
                     "C = %d, %dx%d; loss.item() every step as the reference does; vs_trainer = windows/s over the headline Trainer's" % (B, C, a.size, a.size),
