@@ -232,9 +232,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     for (int m = 0; m < MTW; ++m) accb[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment read offsets (register part; K step and slot are added as immediates / one add per tile)
-    uint32_t offA[MTW][2], offB[9][2];
+    uint32_t offA[MTW][2], offB[9][2], offX[3];
     if constexpr (BF) {
         const int qq = li >> 2, pp = li & 3;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {  // pixels b + 8 .. b + 11 of kernel row kh (C2W_WPV & 8)
+            const int pix = ((lg >> 1) + kh) * PPITCH + 8 * (lg & 1) + 8 + qq + (PAIR ? 2 * (lg & 1) : 0);
+            offX[kh] = (uint32_t)(pix * 128 + (((uint32_t)(nt * 2 + (pp >> 1)) ^ swzP(pix)) << 4) + 8 * (pp & 1));
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = 8 * lg + qq + 4 * h;  // + 32*ks
@@ -293,6 +298,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(base + o1), "n"(IMM));
                 }
             };
+            auto rd3 = [](tr_half* r, uint32_t a0, uint32_t a1, uint32_t a2, auto IMMc) {
+                constexpr int IMM = decltype(IMMc)::value;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[0]) : "v"(a0), "n"(IMM));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[1]) : "v"(a1), "n"(IMM));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r[2]) : "v"(a2), "n"(IMM));
+            };
             static_for<4>([&](auto KSc) {
                 constexpr int ks = decltype(KSc)::value;
                 if constexpr ((C2W_WPV & 2) == 0 && (C2W_EXP & 8) == 0) {
@@ -314,6 +325,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
                 tr_frag a[MTW], bq[PF + 1];
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) rd(a[m], sA, offA[m][0], offA[m][1], IC<ks * 32 * 256>{});
+                if constexpr ((C2W_WPV & 8) != 0) {
+                    // kw-shift reuse: the three taps of a kernel row read the same patch pixels shifted by one -- per kernel row ONE
+                    // 12-pixel run per lane (three transposing reads: pixels b..b+3, b+4..b+7, b+8..b+11) instead of three 8-pixel
+                    // runs (six reads); the kw = 1 fragment is a 16-bit funnel shift of it (v_alignbit_b32 x 4), kw = 2 a dword shift.
+                    tr_half R[2][3];
+                    rd3(R[0], sP + offB[0][0], sP + offB[0][1], sP + offX[0], IC<ks * 2 * PPITCH * 128>{});
+                    static_for<3>([&](auto KHc) {
+                        constexpr int kh = decltype(KHc)::value;
+                        if constexpr (kh < 2) rd3(R[(kh + 1) & 1], sP + offB[3 * (kh + 1)][0], sP + offB[3 * (kh + 1)][1], sP + offX[kh + 1], IC<ks * 2 * PPITCH * 128>{});
+                        if constexpr (kh < 2) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        const tr_half* r = R[kh & 1];
+                        tr_frag f0, f1, f2;
+                        f0.lo = r[0];
+                        f0.hi = r[1];
+                        f1.lo = (tr_half){(int)__builtin_amdgcn_alignbit(r[0][1], r[0][0], 16), (int)__builtin_amdgcn_alignbit(r[1][0], r[0][1], 16)};
+                        f1.hi = (tr_half){(int)__builtin_amdgcn_alignbit(r[1][1], r[1][0], 16), (int)__builtin_amdgcn_alignbit(r[2][0], r[1][1], 16)};
+                        f2.lo = (tr_half){r[0][1], r[1][0]};
+                        f2.hi = (tr_half){r[1][1], r[2][0]};
+                        const bf16x8_t b0 = f0.vec(), b1 = f1.vec(), b2 = f2.vec();
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m) acc[3 * kh + 0][m] = mfma16s<T>(a[m].vec(), b0, acc[3 * kh + 0][m]);
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m) acc[3 * kh + 1][m] = mfma16s<T>(a[m].vec(), b1, acc[3 * kh + 1][m]);
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m) acc[3 * kh + 2][m] = mfma16s<T>(a[m].vec(), b2, acc[3 * kh + 2][m]);
+                        if (kh == 2 && do_bias) {
+                            const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones16<T>());
+#pragma unroll
+                            for (int m = 0; m < MTW; ++m) accb[m] = mfma16s<T>(a[m].vec(), ones, accb[m]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    return;
+                }
                 static_for<PF>([&](auto Jc) {
                     constexpr int j = decltype(Jc)::value;
                     rd(bq[j], sP, offB[j][0], offB[j][1], IC<ks * 2 * PPITCH * 128>{});
