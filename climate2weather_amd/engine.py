@@ -227,6 +227,8 @@ class Engine:
         # C2W_WGRAD_STREAM=0 (read once, here; or set the attribute): weight gradients on the caller's stream, every kernel alone on the
         # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
+        self._wgrad_behind = os.environ.get("C2W_WGRAD_BEHIND") == "1"  # A/B knob: weight gradients one layer behind
+        self._wg_pending = None
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
         self.debug_trace: Optional[list] = None  # diagnostics: a list collects (name, output tensor[, operands of a conv]) of every conv / attention launch of a forward
         self.attach(net)
@@ -521,6 +523,15 @@ class Engine:
         if side is None:
             fn()
             return
+        if self._wgrad_behind:  # experiment knob: this launch is enqueued at the NEXT call, i.e. behind the input gradient issued in between
+            pending, self._wg_pending = self._wg_pending, (fn, tensors)
+            if pending is not None:
+                self._issue_on(side, *pending)
+            return
+        self._issue_on(side, fn, tensors)
+
+    @staticmethod
+    def _issue_on(side, fn, tensors) -> None:
         side.wait_stream(torch.cuda.current_stream())
         for t in tensors:
             t.record_stream(side)
@@ -531,6 +542,9 @@ class Engine:
         """Make the current stream wait for every gradient launch enqueued so far."""
         side = self.grad_stream()
         if side is not None:
+            if self._wg_pending is not None:
+                pending, self._wg_pending = self._wg_pending, None
+                self._issue_on(side, *pending)
             torch.cuda.current_stream().wait_stream(side)
 
     def workspace(self) -> Optional[torch.Tensor]:
