@@ -543,6 +543,7 @@ def run_rank(a):
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):  # stdout carries exactly one line: the JSON below
             sf = BatchedScoreFunction(net, markov_order=a.markov_order, batch_size=128, device=dev, noise_process=trainer.pipeline)
+            sf.window_batch_floor = 0  # these legs are quoted at exactly 128 windows per network call (sampler_configs3 prices the default)
         noise = torch.randn(L, a.vars, a.size, a.size, device=dev)
         with contextlib.redirect_stdout(io.StringIO()):
             trainer.pipeline.sample(sf, noise, steps=1, show_progressbar=False)
@@ -835,12 +836,13 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
     gamma = 0.0007196856730011522
     legs = []
 
-    def leg(L, nmem, c):
+    def leg(L, nmem, c, bsz=128, floor=0, into=None):
         shape = (L, F, H, H) if nmem == 1 else (nmem, L, F, H, H)
         g = torch.Generator(device=dev).manual_seed(L)
         truth = torch.randn((L, F, H, H), device=dev, generator=g) * 0.5 + 0.5
         with contextlib.redirect_stdout(io.StringIO()):
-            sf = BatchedScoreFunction(net, markov_order=k, batch_size=128, device=dev, noise_process=pipe)
+            sf = BatchedScoreFunction(net, markov_order=k, batch_size=bsz, device=dev, noise_process=pipe)
+            sf.window_batch_floor = floor
             sf.condition_on(A=A, y=A(truth), std=std, gamma=gamma, exact_grad=False)
             assert sf._fused_guidance is not None
             del truth
@@ -861,7 +863,9 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
         r = dict(L=L, members=nmem, corrections=c, timed_steps=n, windows_per_score_evaluation=nwin, sampler_steps_per_s=round(1 / d, 3),
                  ms_per_sampler_step=round(1e3 * d, 2), window_forwards_per_s=round(nwin * (1 + c) / d, 1),
                  members_per_hour_at_256_steps=round(nmem * 3600.0 / (256 * d), 2))
-        legs.append(r)
+        if bsz != 128 or floor != 0:
+            r.update(batch_size=bsz, window_batch_floor=floor)
+        (legs if into is None else into).append(r)
         if log is not None:
             log(r)
 
@@ -871,7 +875,16 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
     if members > 1:
         for c in corrections:
             leg(49, members, c)
-    return dict(config="F=4, k=6, 52 ch x 128x128, %s, window batch 128, conditioned on AvgPool2d(16) o x[::6] (s16_t6.yml std / gamma, exact_grad=False), "
+    # what the product default does with the reference's other shipped batch size (exp/configs: batch_size 32): score_fn.py::window_batch_floor
+    floor_legs = []
+    if 8737 in lengths:
+        from climate2weather_amd.score_fn import BatchedScoreFunction as _B
+        leg(8737, 1, 0, bsz=32, floor=0, into=floor_legs)
+        leg(8737, 1, 0, bsz=32, floor=_B.window_batch_floor, into=floor_legs)
+    return dict(window_batch_floor=dict(note="L = 8737, batch_size = 32 (the reference's other shipped value): exactly 32 windows per network call "
+                                             "(floor 0) against the product default (launches of at least `window_batch_floor` windows); the legs "
+                                             "below run exactly 128 windows per call", legs=floor_legs),
+                config="F=4, k=6, 52 ch x 128x128, %s, window batch 128, conditioned on AvgPool2d(16) o x[::6] (s16_t6.yml std / gamma, exact_grad=False), "
                        "%d timed sampler steps per leg after 1 warm-up step (legs shorter than 0.25 s are re-timed over up to 32 steps: `timed_steps`)" % (precision, steps), legs=legs)
 
 

@@ -153,6 +153,8 @@ class _WindowScore(AbstractScoreFunction):
         # window batches of one score evaluation alternate between this many HIP streams (1: the caller's stream only);
         # C2W_SCORE_STREAMS (read once, here) or the attribute
         self.num_streams = int(os.environ.get("C2W_SCORE_STREAMS", type(self).num_streams))
+        if "C2W_WINDOW_BATCH_FLOOR" in os.environ:
+            self.window_batch_floor = int(os.environ["C2W_WINDOW_BATCH_FLOOR"])
 
     # reference-compatible helpers (src/thor/score.py:68-88)
     def unfold(self, x):
@@ -195,7 +197,7 @@ class _WindowScore(AbstractScoreFunction):
         if lay.in_channels != w * F:
             raise ValueError(f"network expects {lay.in_channels} channels, window gives {w * F}")
         total = M * nwin
-        bs = self.batch_size or total
+        bs = min(max(self.batch_size or total, self._window_floor(H * W)), total)
         if xd.dim() == 5:  # co-sampled members: equal batches instead of full ones and a ragged tail (148 windows: 2 x 74, not 128 + 20)
             bs = -(-total // -(-total // bs))
         if self.use_graphs and xd.is_cuda and src_dev == self.device and xd.dim() == 4:
@@ -243,6 +245,18 @@ class _WindowScore(AbstractScoreFunction):
     # persistent eps buffer and a one-element time buffer that is overwritten before each replay.
     use_graphs = False
     num_streams = 4  # window batches of one score evaluation alternate between this many HIP streams (1: the caller's stream only)
+    # ``batch_size`` bounds activation memory in the reference (src/thor/score.py:156-185; the shipped configs say 32 and 128 for
+    # 40-80 GB devices).  On the engine path it is a LOWER bound: a launch sequence carries at least this many windows of 128x128
+    # pixels (fewer, in proportion, for larger fields), because the 16x16 and 8x8 levels of a 32-window batch leave three quarters
+    # of the CUs without a workgroup (L = 1037, one member: 7.8 k window-forwards/s at 32 windows per batch, 9.1 k at 128, 9.3 k at
+    # 256; profiles/r04_experiments.md section 15).  256 windows of bf16 activations are ~5 GB per stream.  The windows are
+    # independent, so the result is the same trajectory; 0 (attribute, or C2W_WINDOW_BATCH_FLOOR read at construction) restores
+    # exactly ``batch_size`` windows per network call.
+    window_batch_floor = 256
+
+    def _window_floor(self, pixels: int) -> int:
+        n = int(self.window_batch_floor)
+        return max(1, n * 128 * 128 // max(pixels, 1)) if n > 0 else 1
 
     def _side_streams(self, nbatches: int):
         n = min(int(self.num_streams), nbatches)

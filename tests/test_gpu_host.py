@@ -538,6 +538,40 @@ def test_window_batches_on_several_streams_equal_one_stream(monkeypatch):
     assert len(sf._side_streams(5)) == 4
 
 
+def test_window_batch_floor_gives_the_same_score_in_fewer_launch_sequences():
+    """score_fn.py::window_batch_floor (the product default; tests/conftest.py sets 0 for the rest of the suite): ``batch_size`` windows
+    per network call become AT LEAST the floor -- same eps to fp32 round-off (the launch size picks the kernels, hence the summation
+    order), one network call instead of six."""
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev).eval()
+    net.precision = "fp32"
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=2, device=dev, noise_process=SDAPipeline())
+    assert sf.window_batch_floor == 0 and type(sf).window_batch_floor == 256
+    x = torch.randn(14, 2, 64, 64, device=dev)  # 12 windows
+    t = torch.tensor(0.4)
+    eng = net._get_engine()
+    calls, real = [], eng.forward
+
+    def spy(*a, **kw):
+        calls.append(kw["shape"][0])
+        return real(*a, **kw)
+    eng.forward = spy
+    try:
+        with torch.no_grad():
+            exact = sf.score_fn(x, t).clone()
+            assert calls == [2] * 6
+            del calls[:]
+            sf.window_batch_floor = type(sf).window_batch_floor
+            one = sf.score_fn(x, t).clone()
+            assert calls == [12]  # 256 windows of 128x128 = 1024 windows of 64x64: the whole trajectory
+    finally:
+        del eng.forward
+    torch.cuda.synchronize()
+    assert (one - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()
+
+
 def test_ensemble_driver_on_device():
     """a14 on the GPU: members of one rank, conditioned with the experiment's operator, state resident in HBM, bf16 network."""
     from climate2weather_amd.sampling import run_ensemble

@@ -742,6 +742,39 @@ def test_co_sampled_members_equal_members_sampled_one_by_one(emu, cond):
         assert torch.allclose(both[m], alone, atol=1e-5, rtol=1e-5)
 
 
+def test_window_batch_floor_is_a_lower_bound_on_the_launch_size(emu, monkeypatch):
+    """score_fn.py::window_batch_floor: ``batch_size`` (src/thor/score.py:156-185, a memory bound) is a LOWER bound on the windows
+    per network call on the engine path -- scaled by the field size, never more than the trajectory has -- and 0 restores exactly
+    ``batch_size`` windows per call.  Same trajectory either way."""
+    net = _tiny().eval()
+    pipe = SDAPipeline()
+    noise = torch.randn(9, 2, 16, 16, generator=torch.Generator().manual_seed(4))  # 7 windows of 3 frames
+    eng = net._get_engine()
+    calls = []
+    real = eng.forward
+
+    def spy(*a, **kw):
+        calls.append(kw["shape"][0])
+        return real(*a, **kw)
+    monkeypatch.setattr(eng, "forward", spy)
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=2, device=torch.device("cpu"), noise_process=pipe)
+    assert sf.window_batch_floor == 0  # tests/conftest.py pins the suite to the reference's meaning
+    exact = sf.score_fn(noise, 0.5)
+    assert calls == [2, 2, 2, 1]
+    del calls[:]
+    sf.window_batch_floor = 256  # the product default: 256 windows of 128x128 = 16384 windows of 16x16 -> everything in one call
+    assert sf._window_floor(16 * 16) == 256 * 64 and sf._window_floor(128 * 128) == 256 and sf._window_floor(256 * 256) == 64
+    one = sf.score_fn(noise, 0.5)
+    assert calls == [7]
+    assert torch.allclose(one, exact, atol=1e-6, rtol=1e-6)
+    del calls[:]
+    monkeypatch.setattr(sf, "_window_floor", lambda pixels: 3)  # a floor between batch_size and the trajectory
+    three = sf.score_fn(noise, 0.5)
+    assert calls == [3, 3, 1]
+    assert torch.allclose(three, exact, atol=1e-6, rtol=1e-6)
+    assert type(sf).window_batch_floor == 256
+
+
 def test_module_under_torch_ddp_matches_golden_gradients(golden_dir, tmp_path):
     """INTEGRATION.md section 1, "nothing else changes": ScoreUNet wrapped in torch's DistributedDataParallel (what
     fabric.setup_module does, training_loop.py:116), autograd backward, torch.optim.AdamW.  Two gloo ranks, one item each:
