@@ -65,6 +65,7 @@ _PROTOS = {
     "c2w_sq_err_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_timestep_embedding": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],
+    "c2w_publish_scalar": [c_void_p, c_void_p, c_int, c_void_p],
     "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
     "c2w_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_weight_transpose_batched": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],

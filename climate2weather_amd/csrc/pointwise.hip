@@ -1012,6 +1012,21 @@ extern "C" int c2w_sq_err_noise(const void* y, unsigned long long seed, float* o
     return sq_err_launch(y, nullptr, seed, true, out, loss_sum, B, C, HW, ldc, dtype, stream);
 }
 
+// A device scalar made readable by the host without a stream synchronisation (training_loop.py:385 reads the loss back every step):
+// one thread copies the value into a slot of host memory (pinned, device-visible) and then stores the sequence number the host polls
+// for -- release at system scope, so the value is there when the number is.
+__global__ void publish_scalar_kernel(const float* __restrict__ src, int* slot, int seq) {
+    const float v = *src;
+    __hip_atomic_store(slot, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int c2w_publish_scalar(const float* src, int* host_slot, int seq, void* stream) {
+    if (!src || !host_slot) return C2W_ERR_BAD_ARG;
+    publish_scalar_kernel<<<1, 1, 0, (hipStream_t)stream>>>(src, host_slot, seq);
+    return (int)hipGetLastError();
+}
+
 extern "C" int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {
     if (!t || !out || n <= 0 || dim <= 0) return C2W_ERR_BAD_SHAPE;
     timestep_embedding_kernel<<<(n * dim + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, out, n, dim, max_period);

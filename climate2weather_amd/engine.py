@@ -229,6 +229,7 @@ class Engine:
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
         self._wgrad_behind = os.environ.get("C2W_WGRAD_BEHIND") == "1"  # A/B knob: weight gradients one layer behind
         self._wg_pending = None
+        self._pub = None  # [pinned (64, 2) int32 ring, its numpy view, publications so far] (publish / published)
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
         self.debug_trace: Optional[list] = None  # diagnostics: a list collects (name, output tensor[, operands of a conv]) of every conv / attention launch of a forward
         self.attach(net)
@@ -512,8 +513,41 @@ class Engine:
         if self.flat is None or not self.flat.is_cuda or not self.use_grad_stream:
             return None
         if self._wg_stream is None or self._wg_stream.device != self.flat.device:
-            self._wg_stream = torch.cuda.Stream(device=self.flat.device)
+            from .streams import independent_stream
+            self._wg_stream = independent_stream(self.flat.device)  # on another hardware queue than the caller's stream (streams.py)
         return self._wg_stream
+
+    def publish(self, scalar: torch.Tensor):
+        """Enqueue, behind the launch that produced the fp32 device scalar ``scalar``, its copy into a slot of pinned host memory
+        (ops.publish_scalar); returns (slot, sequence number) for ``published``.  A ring of 64 slots: a reader that comes more than
+        64 publications late finds a newer number in its slot and falls back to an ordinary read."""
+        if self._pub is None:
+            buf = torch.zeros((64, 2), dtype=torch.int32).pin_memory()
+            self._pub = [buf, buf.numpy(), 0]
+        buf, _, n = self._pub
+        n += 1
+        self._pub[2] = n
+        slot = n % 64
+        ops.publish_scalar(scalar, buf.data_ptr() + 8 * slot, n)
+        return slot, n
+
+    def published(self, slot: int, seq: int, timeout_s: float = 20.0):
+        """The value of publication ``seq`` as a Python float once the device has written it (polling host memory: no stream is
+        synchronised), or None if the slot has been reused or nothing arrived in ``timeout_s``."""
+        import time
+        arr = self._pub[1]
+        t0 = None
+        while True:
+            got = int(arr[slot, 1])
+            if got == seq:
+                return float(arr[slot, 0:1].view("float32")[0])
+            if got > seq:
+                return None
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > timeout_s:
+                return None
+            time.sleep(0)
 
     def _on_grad_stream(self, fn, *tensors) -> None:
         """Run ``fn`` (launches that read ``tensors`` and write gradient memory) on the gradient stream, behind everything

@@ -259,6 +259,11 @@ def mu_sigma(t, musig, n, eta):
     check(_lib.load().c2w_mu_sigma(_p(t), _p(musig), n, eta, _stream()), "c2w_mu_sigma")
 
 
+def publish_scalar(src, host_slot_ptr: int, seq: int):
+    """src: 0-d / 1-element fp32 device tensor; host_slot_ptr: address of two ints of pinned host memory (value bits, sequence number)."""
+    check(_lib.load().c2w_publish_scalar(_p(src), ctypes.c_void_p(host_slot_ptr), int(seq), _stream()), "c2w_publish_scalar")
+
+
 def cast_f32(src, dst, n, dtype):
     check(_lib.load().c2w_cast_f32(_p(src), _p(dst), n, dtype, _stream()), "c2w_cast_f32")
 

@@ -11,6 +11,8 @@ own arithmetic type; the default / bfloat16 -> bf16).  ``net.precision = "fp32" 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -184,9 +186,61 @@ class _LossTensor(torch.Tensor):
         if func in (torch.Tensor.mean, torch.mean) and len(args) == 1 and not kwargs and isinstance(args[0], _LossTensor):
             ls = getattr(args[0], "_c2w_loss_sum", None)
             if ls is not None:
-                return _MeanOfLoss.apply(args[0].as_subclass(torch.Tensor), ls)
+                return _as_loss_scalar(_MeanOfLoss.apply(args[0].as_subclass(torch.Tensor), ls), getattr(args[0], "_c2w_engine", None))
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)
+
+
+class _LossScalar(torch.Tensor):
+    """The mean of the fused loss and what the reference's loop derives from it before reading it back (training_loop.py:377,385:
+    ``.mean().mul(loss_scaling)`` ... ``loss.detach().item()`` after ``optimizer.step()``).  ``item()`` on a plain tensor waits for
+    everything enqueued on the stream -- the backward pass and the optimizer step, for a value that was final at the end of the
+    forward -- and the chip then idles while the host prepares the next step (1.1 ms of a 49-ms step, profiles/r04_experiments.md
+    section 1).  Here the value is PUBLISHED when it is produced: a one-thread launch behind its producer copies it into pinned host
+    memory with a sequence number (Engine.publish), and ``item()`` / ``float()`` poll that memory -- the same bits, no stream
+    synchronised, no second stream involved.  ``mul`` / ``div`` by a number stay in the class (published again), ``detach`` keeps
+    its source's publication; every other operation sees, and returns, an ordinary tensor."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _SCALAR_READ and len(args) == 1 and not kwargs and isinstance(args[0], _LossScalar):
+            v = _read_published(args[0])
+            if v is not None:
+                return v
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        if type(out) is torch.Tensor and out.dim() == 0 and out.is_cuda and args and isinstance(args[0], _LossScalar):
+            src = args[0]
+            eng = getattr(src, "_c2w_engine", None)
+            if func in _SCALAR_ALIAS:  # no launch: the same value
+                return _as_loss_scalar(out, eng, getattr(src, "_c2w_pub", None))
+            if func in _SCALAR_KEEP and not any(isinstance(a, torch.Tensor) for a in args[1:]) and not kwargs:
+                return _as_loss_scalar(out, eng)
+        return out
+
+
+_SCALAR_READ = (torch.Tensor.item, torch.Tensor.__float__)
+_SCALAR_ALIAS = (torch.Tensor.detach, torch.detach)
+_SCALAR_KEEP = (torch.Tensor.mul, torch.mul, torch.Tensor.__mul__, torch.Tensor.__rmul__, torch.Tensor.div, torch.div, torch.Tensor.__truediv__)
+
+
+def _as_loss_scalar(t: torch.Tensor, eng, pub=None) -> torch.Tensor:
+    if eng is None or not t.is_cuda or t.dim() != 0 or t.dtype != torch.float32 or os.environ.get("C2W_NO_EARLY_ITEM") == "1":  # the knob: A/B only
+        return t
+    if pub is None:  # produced by a launch just enqueued on the current stream: publish behind it
+        pub = eng.publish(t.detach())
+    s = t.as_subclass(_LossScalar)
+    s._c2w_pub = pub
+    s._c2w_engine = eng
+    return s
+
+
+def _read_published(s: "_LossScalar"):
+    pub, eng = getattr(s, "_c2w_pub", None), getattr(s, "_c2w_engine", None)
+    if pub is None or eng is None:
+        return None
+    return eng.published(*pub)
 
 
 class ScoreUNet(torch.nn.Module):
@@ -286,6 +340,7 @@ class ScoreUNet(torch.nn.Module):
                 out, ls = _forward_loss(eng, x, t, dt, req, None)
             out = out.as_subclass(_LossTensor)
             out._c2w_loss_sum = ls
+            out._c2w_engine = eng
             return out
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         shape = x.shape

@@ -1,0 +1,63 @@
+"""HIP streams that really run next to each other.
+
+A HIP stream is bound to one of a few hardware queues when it is created (four per process and priority level on this stack,
+handed out in rotation), and two streams on one queue execute in order: the third, seventh, eleventh ... normal-priority stream
+a process creates shares the default stream's queue (tools/probes/early_item_probe.py: a 4-byte copy on such a stream returns
+after the 43-ms kernel on the default stream, on every other one after 0.3 ms).  The engine's gradient stream is usually the first
+stream of its process and lands elsewhere by luck; a process that has created streams before (a DDP communicator's pool, a
+sampler's window-batch streams, a test suite) may not be so lucky and would lose the whole two-stream backward without a sign.
+``independent_stream`` asks the hardware instead of the creation order.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+_PROBE_CYCLES = 4_000_000  # ~1.7 ms of torch.cuda._sleep on the stream that must NOT hold the candidate up
+
+
+def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None) -> bool:
+    """True if a launch on ``side`` completes while a kernel enqueued earlier on ``main`` (default: the current stream) is still
+    running, i.e. the two streams are on different hardware queues.  Costs one ~1.7-ms spin kernel on ``main``."""
+    main = main or torch.cuda.current_stream(side.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=side.device)
+    main.synchronize()
+    with torch.cuda.stream(main):
+        torch.cuda._sleep(_PROBE_CYCLES)
+    with torch.cuda.stream(side):
+        flag.fill_(1)
+    side.synchronize()
+    ok = not main.query()
+    flag.record_stream(side)
+    return ok
+
+
+def independent_stream(device, avoid=(), tries: int = 8, priority: int = 0) -> "torch.cuda.Stream":
+    """A new stream on ``device`` that shares a hardware queue neither with the current stream nor with any stream in ``avoid``
+    (the engine's gradient stream when the loss read-back stream is made, and the other way round): candidates are created one
+    after the other (each takes the next queue in the rotation) until one overtakes a kernel on each of them.  During a graph
+    capture, or if no candidate qualifies, the last one created is returned as it is.
+    Normal priority on purpose: with one high-priority stream in the process, the THIRD engine created in it ran its two-stream
+    backward at 56 instead of 47 ms/step although this probe had cleared its gradient stream (profiles/r04_experiments.md section 16)."""
+    device = torch.device(device)
+    with torch.cuda.device(device):
+        if os.environ.get("C2W_PLAIN_STREAMS") == "1" or torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream(device=device, priority=priority)
+        others, seen = [], set()
+        for st in [torch.cuda.current_stream(device)] + [a for a in avoid if a is not None]:
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                others.append(st)
+        rejected = []  # kept alive until the end: a destroyed stream's queue slot would be handed to the next candidate again
+        s, ok = None, False
+        for _ in range(max(1, tries)):
+            s = torch.cuda.Stream(device=device, priority=priority)
+            ok = all(overtakes(s, o) for o in others)
+            if ok:
+                break
+            rejected.append(s)
+        if os.environ.get("C2W_STREAM_DEBUG") == "1":
+            print("independent_stream: %d rejected, %d to avoid, verdict %s" % (len(rejected), len(others), ok), flush=True)
+        return s

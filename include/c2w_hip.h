@@ -187,6 +187,10 @@ int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, void* dy, fl
 int c2w_sq_err(const void* y, const float* eps, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype, void* stream);
 int c2w_sq_err_noise(const void* y, unsigned long long seed, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype,
                      void* stream);
+/* training_loop.py:385 (`loss.detach().item()` after optimizer.step()): the fp32 device scalar `src` is copied into host_slot[0]
+ * (its bits) and host_slot[1] = seq is stored after it, release at system scope.  host_slot: two ints of pinned, device-visible host
+ * memory; the host polls host_slot[1] for `seq` instead of synchronising the stream the value was produced on. */
+int c2w_publish_scalar(const float* src, int* host_slot, int seq, void* stream);
 /* model/score.py:14-34 */
 int c2w_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream);
 /* src/thor/pipelines.py:13-20: musig[i] = {mu(t_i), sigma(t_i)} */

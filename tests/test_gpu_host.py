@@ -538,6 +538,33 @@ def test_window_batches_on_several_streams_equal_one_stream(monkeypatch):
     assert len(sf._side_streams(5)) == 4
 
 
+def test_independent_stream_is_on_another_hardware_queue():
+    """streams.py: HIP hands hardware queues to new streams in rotation and two streams on one queue run in order -- after a few
+    streams exist, a freshly created one may sit on the caller's queue and the two-stream backward would silently serialise.
+    ``independent_stream`` returns one that overtakes a running kernel on the current stream, wherever the rotation stands."""
+    from climate2weather_amd.streams import independent_stream, overtakes
+    dev = torch.device("cuda", 0)
+    plain = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    verdicts = [overtakes(s) for s in plain]
+    torch.cuda.synchronize()
+    for shift in range(4):  # whatever slot of the rotation comes next
+        keep = [torch.cuda.Stream(device=dev) for _ in range(shift)]
+        s = independent_stream(dev)
+        assert overtakes(s), (shift, verdicts)
+        del keep
+    torch.cuda.synchronize()
+    if all(verdicts):
+        pytest.skip("no plain stream shared the default stream's queue on this runtime: the premise could not be shown (the helper still works)")
+    assert 1 <= verdicts.count(False) <= 6, verdicts  # one slot of the rotation, not a broken probe
+    # the engine's gradient stream is such a stream
+    torch.manual_seed(0)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev)
+    eng = net._get_engine()
+    assert overtakes(eng.grad_stream())
+    torch.cuda.synchronize()
+
+
 def test_window_batch_floor_gives_the_same_score_in_fewer_launch_sequences():
     """score_fn.py::window_batch_floor (the product default; tests/conftest.py sets 0 for the rest of the suite): ``batch_size`` windows
     per network call become AT LEAST the floor -- same eps to fp32 round-off (the launch size picks the kernels, hence the summation

@@ -170,6 +170,39 @@ def test_fp16_autocast_with_torch_grad_scaler():
     assert float(oa.state_dict()["state"][0]["step"]) == 4.0
 
 
+def test_loss_item_does_not_drain_the_stream():
+    """training_loop.py:385 reads ``loss.detach().item()`` AFTER optimizer.step(): on a plain tensor that waits for the backward pass
+    and the update although the value was final at the end of the forward.  score.py::_LossScalar answers item() / float() from a
+    pinned host memory the value was published into behind its own producer (Engine.publish): the same bits, while a second of later
+    work is still running."""
+    import time
+    from climate2weather_amd.score import _LossScalar
+    pipe = SDAPipeline()
+    net = _tiny(precision="auto")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = pipe.loss(net=net, x=_batch(0, DEV)).mean().mul(0.5)
+    assert isinstance(loss, _LossScalar) and isinstance(loss.detach(), _LossScalar) and loss.requires_grad
+    loss.backward()
+    assert all(p.grad is not None for p in net.parameters())
+    want = loss.detach().as_subclass(torch.Tensor).item()  # the ordinary, draining read
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2.0e9))  # ~1 s of later work on the stream (the loop's backward + optimizer step)
+    t0 = time.perf_counter()
+    got = loss.detach().item()
+    took = time.perf_counter() - t0
+    assert not torch.cuda.current_stream().query(), "the sleep kernel finished before item() returned: nothing was shown"
+    assert got == want and float(loss) == want and took < 0.5, (got, want, took)
+    torch.cuda.synchronize()
+    # anything else is an ordinary tensor operation with an ordinary result
+    assert type(loss + 1.0) is torch.Tensor and (loss + 1.0).item() == pytest.approx(want + 1.0, rel=1e-6)
+    assert type(loss.detach().cpu()) is torch.Tensor
+    # the unfused route hands back plain tensors
+    pipe.fused_loss = False
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        plain = pipe.loss(net=net, x=_batch(0, DEV)).mean()
+    assert type(plain) is torch.Tensor
+
+
 def test_full_size_network_one_reference_shaped_step():
     """The default network (configs/sda_unet.yml, C = 65, 128 x 128) through one iteration of the reference's loop with all five
     class_name seams pointing here, bf16 autocast, B = 4: flat path engaged, EMA moved, and the weights equal torch.optim.AdamW's on
