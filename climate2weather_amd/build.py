@@ -13,7 +13,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libc2w_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]
 SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch3.hip", "wgrad.hip", "wgrad_patch.hip", "pointwise.hip", "attention.hip", "attention_mfma.hip",
-           "sampler.hip"]
+           "sampler.hip", "conv_center.hip"]
 
 
 STAMP = os.path.join(HERE, "build", "sources.sha256")

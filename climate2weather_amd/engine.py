@@ -662,8 +662,13 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, dt: int, tape: Optional[Tape] = None, noise: Optional[Tuple] = None,
                 want_dx: bool = False, nhwc_out: bool = False, x_nhwc: Optional[torch.Tensor] = None, shape=None,
-                forcing: Optional[torch.Tensor] = None):
+                forcing: Optional[torch.Tensor] = None, fold: Optional[dict] = None):
         """eps_pred = ScoreUNet(x, t).  x: (B,C,H,W) fp32 on the GPU; t: numel 1 or B.
+        ``fold`` (inference, with ``nhwc_out``): dict(segs=[(eps trajectory (L,F,H,W) fp32, first window, count, first batch row)], k, F,
+        nwin) -- the batch rows are windows of trajectories and only what src/thor/score.py:76-88 keeps of them is wanted: where the
+        kernel exists the output convolution computes the centre frame's F rows only and writes them into the trajectories
+        (ops.conv_center; the other frames of a trajectory's first / last window through the full convolution of that one window) and
+        None is returned; otherwise the NHWC output rows are returned and the caller scatters them.
         noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion; eps may be an int
         seed instead of a tensor: the kernel regenerates the Philox stream of that seed (ops.philox_normal) and eps never exists.
         With ``tape`` every op records its backward closure (training / exact guidance)."""
@@ -963,6 +968,8 @@ class Engine:
                     tape.steps.append(bw_tail)
             else:
                 xin = cur
+                if fold is not None and not train and nhwc_out and self._fold_output(fold, "unet." + lv.tail_key, xin, B, Hc, Wc, dt):
+                    return None
                 cur, g_t, r_t = conv3("unet." + lv.tail_key, xin, Hc, Wc, Hc, Wc, CONV_S1, ldy=lay.cout_pad, cout=lay.cout_pad)
                 if train:
                     def bw_tail0(gy, xin=xin, g=g_t, rec=r_t, Hc=Hc, Wc=Wc, Cc=lv.channels):
@@ -980,6 +987,35 @@ class Engine:
         y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         ops.nhwc_to_nchw(cur, y, B, lay.out_channels, H * W, lay.cout_pad, dt)
         return y
+
+    use_center_conv = os.environ.get("C2W_NO_CENTER_CONV") != "1"  # A/B knob
+
+    def _fold_output(self, fold: dict, name: str, xin: torch.Tensor, B: int, H: int, W: int, dt: int) -> bool:
+        """The output convolution of a batch of trajectory windows, restricted to the frames fold() keeps (see forward).  False: not
+        available for this shape / type -- nothing was written."""
+        lay = self.layout
+        rec = lay.convs[name]
+        k, F, nwin = int(fold["k"]), int(fold["F"]), int(fold["nwin"])
+        w = 2 * k + 1
+        if not self.use_center_conv or rec.rows != w * F or rec.kstride != rec.cin or \
+                not ops.conv_center_supported(H, W, rec.cin, F, dt):
+            return False
+        HW = H * W
+        wts, bias = self._w(rec, dt), self._b(rec)
+        T = TORCH_DTYPE[dt]
+        for eps, i0, nw, pos in fold["segs"]:
+            rows = xin[pos * HW:]
+            ops.conv_center(rows, wts, bias, eps[i0 + k:], nw, H, W, rec.cin, rec.rows, k * F, F, F * HW, dt)
+            for gi in sorted({0, nwin - 1}):  # a trajectory's first / last window keeps k more frames: the full convolution of that one window
+                if not i0 <= gi < i0 + nw:
+                    continue
+                one = xin[(pos + gi - i0) * HW: (pos + gi - i0 + 1) * HW]
+                g = self._geom(1, H, W, rec.kstride, H, W, lay.cout_pad, lay.cout_pad, rec.rows, CONV_S1)
+                wop, wpk = self._conv_weights("f", rec, dt, g)
+                y1 = torch.empty((HW, lay.cout_pad), dtype=T, device=xin.device)
+                ops.conv(one, wop, bias, y1, g, dt, wpacked=wpk)
+                ops.window_scatter(y1, eps, 1, F, HW, k, gi, nwin, lay.cout_pad, dt)
+        return True
 
     def _mlp_layer(self, name: str, x: torch.Tensor, rows: int, tape: Optional[Tape], need_dx: bool = True,
                    add: Optional[torch.Tensor] = None, add_bw: Optional[Callable] = None) -> torch.Tensor:

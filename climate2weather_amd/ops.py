@@ -259,6 +259,16 @@ def mu_sigma(t, musig, n, eta):
     check(_lib.load().c2w_mu_sigma(_p(t), _p(musig), n, eta, _stream()), "c2w_mu_sigma")
 
 
+def conv_center_supported(H: int, W: int, Cin: int, nr: int, dtype: int) -> bool:
+    return bool(_lib.load().c2w_conv_center_supported(H, W, Cin, nr, dtype))
+
+
+def conv_center(x, w, bias, out, B, H, W, Cin, wrows, r0, nr, ostride, dtype):
+    """rows r0 .. r0 + nr - 1 of the 3x3 output convolution over the NHWC rows x, as fp32 planes out[b * ostride + c * H * W + pix]
+    (include/c2w_hip.h::c2w_conv_center): the frames the sampler's fold keeps, written where it puts them."""
+    check(_lib.load().c2w_conv_center(_p(x), _p(w), _p(bias), _p(out), B, H, W, Cin, wrows, r0, nr, ostride, dtype, _stream()), "c2w_conv_center")
+
+
 def publish_scalar(src, host_slot_ptr: int, seq: int):
     """src: 0-d / 1-element fp32 device tensor; host_slot_ptr: address of two ints of pinned host memory (value bits, sequence number)."""
     check(_lib.load().c2w_publish_scalar(_p(src), ctypes.c_void_p(host_slot_ptr), int(seq), _stream()), "c2w_publish_scalar")

@@ -231,9 +231,11 @@ class _WindowScore(AbstractScoreFunction):
                     ops.window_gather(xs[m], xin[pos * HW:], nw, F, HW, k, i0, lay.cin_pad, dt)
                     segs.append((m, i0, nw, pos))
                     pos += nw
-                y = eng.forward(None, td, dt, x_nhwc=xin, shape=(ng, w * F, H, W), nhwc_out=True)
-                for m, i0, nw, pos in segs:
-                    ops.window_scatter(y[pos * HW:], es[m], nw, F, HW, k, i0, nwin, lay.cout_pad, dt)
+                y = eng.forward(None, td, dt, x_nhwc=xin, shape=(ng, w * F, H, W), nhwc_out=True,
+                                fold=dict(segs=[(es[m], i0, nw, pos) for m, i0, nw, pos in segs], k=k, F=F, nwin=nwin))
+                if y is not None:  # the engine could not fold inside its output convolution: all w * F channels came back
+                    for m, i0, nw, pos in segs:
+                        ops.window_scatter(y[pos * HW:], es[m], nw, F, HW, k, i0, nwin, lay.cout_pad, dt)
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
         return eps if src_dev == self.device else eps.to(src_dev)
@@ -288,8 +290,10 @@ class _WindowScore(AbstractScoreFunction):
             def run(i0, nw):
                 xin = torch.empty((nw * H * W, lay.cin_pad), dtype=TORCH_DTYPE[dt], device=self.device)
                 ops.window_gather(xbuf, xin, nw, F, H * W, k, i0, lay.cin_pad, dt)
-                y = eng.forward(None, td, dt, x_nhwc=xin, shape=(nw, w * F, H, W), nhwc_out=True)
-                ops.window_scatter(y, eps, nw, F, H * W, k, i0, nwin, lay.cout_pad, dt)
+                y = eng.forward(None, td, dt, x_nhwc=xin, shape=(nw, w * F, H, W), nhwc_out=True,
+                                fold=dict(segs=[(eps, i0, nw, 0)], k=k, F=F, nwin=nwin))
+                if y is not None:
+                    ops.window_scatter(y, eps, nw, F, H * W, k, i0, nwin, lay.cout_pad, dt)
 
             batches = [(i0, min(bs, nwin - i0)) for i0 in range(0, nwin, bs)]
             for i0, nw in batches[:1] + batches[-1:]:  # eager once per distinct batch size: lazy kernel attributes / weight casts

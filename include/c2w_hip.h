@@ -187,6 +187,17 @@ int c2w_mse_loss_grad_noise(const void* y, unsigned long long seed, void* dy, fl
 int c2w_sq_err(const void* y, const float* eps, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype, void* stream);
 int c2w_sq_err_noise(const void* y, unsigned long long seed, float* out, float* loss_sum, int B, int C, int HW, int ldc, int dtype,
                      void* stream);
+/* The network's output convolution (model/nn.py:194: 3x3, stride 1, zero padding) restricted to what the sampler's fold keeps
+ * (src/thor/score.py:76-88: of a window's w * F output channels only the centre frame's F, all of them only for the first / last
+ * window of a trajectory): rows r0 .. r0 + nr - 1 (nr <= 16) of the [wrows][9][Cin] weight matrix `w` over the NHWC rows `x`
+ * ([B][H][W][Cin], 16-bit), bias added, rounded through the compute type like the full convolution's output, stored as fp32 planes:
+ *     out[b * ostride + c * H * W + pix],  c < nr
+ * -- with out = eps + (i0 + k) * F * H * W, ostride = F * H * W, r0 = k * F, nr = F the centre frames of windows i0 .. i0 + B - 1
+ * land where fold() puts them, and no pass over the 128-channel output rows remains.  c2w_conv_center_supported: bf16 / fp16,
+ * H % 8 == 0, W % 16 == 0, Cin in {64, 128}. */
+int c2w_conv_center_supported(int H, int W, int Cin, int nr, int dtype);
+int c2w_conv_center(const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int Cin, int wrows, int r0, int nr,
+                    long long ostride, int dtype, void* stream);
 /* training_loop.py:385 (`loss.detach().item()` after optimizer.step()): the fp32 device scalar `src` is copied into host_slot[0]
  * (its bits) and host_slot[1] = seq is stored after it, release at system scope.  host_slot: two ints of pinned, device-visible host
  * memory; the host polls host_slot[1] for `seq` instead of synchronising the stream the value was produced on. */

@@ -395,6 +395,22 @@ def window_scatter(y, eps, nw, F, HW, k, i0, nwin_total, ldc, dtype):
                 Ev[(gi + tau) * F * HW:(gi + tau + 1) * F * HW] = Y[j, :, tau * F:(tau + 1) * F].t().reshape(-1)
 
 
+def conv_center_supported(H, W, Cin, nr, dtype):
+    # the emulation has no tile shapes; it mirrors the kernel's domain except the element type (CPU tests run fp32)
+    return H % 8 == 0 and W % 16 == 0 and Cin in (64, 128) and 1 <= nr <= 16
+
+
+def conv_center(x, w, bias, out, B, H, W, Cin, wrows, r0, nr, ostride, dtype):
+    """include/c2w_hip.h::c2w_conv_center: rows r0 .. r0 + nr - 1 of the 3x3 convolution, rounded through the compute type, as fp32 planes."""
+    X = _rows(x, B * H * W, Cin).float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    Wm = w.reshape(-1)[: wrows * 9 * Cin].view(wrows, 3, 3, Cin)[r0:r0 + nr].float().permute(0, 3, 1, 2)
+    bv = bias.reshape(-1)[r0:r0 + nr].float() if bias is not None else None
+    Y = F.conv2d(X, Wm, bv, padding=1).to(x.dtype).float()  # (B, nr, H, W)
+    O = out.reshape(-1)
+    for b in range(B):
+        O[b * ostride: b * ostride + nr * H * W] = Y[b].reshape(-1)
+
+
 def sampler_predict(x, eps, nan_flag, n, a, b):
     X = x.reshape(-1)[:n]
     X.mul_(a).add_(eps.reshape(-1)[:n], alpha=b)

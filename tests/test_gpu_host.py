@@ -538,6 +538,44 @@ def test_window_batches_on_several_streams_equal_one_stream(monkeypatch):
     assert len(sf._side_streams(5)) == 4
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16", 2e-2), ("fp16", 3e-3)])
+def test_output_convolution_folds_inside_the_engine_on_the_gpu(prec, tol):
+    """engine.py::_fold_output with the HIP kernel (c2w_conv_center): the sampler's network calls compute only the frames fold() keeps
+    (src/thor/score.py:76-88) and write them into the trajectory; eps equals the full output rows + window_scatter to the rounding of
+    the compute type, for one trajectory and for co-sampled members, and bit for bit between two runs."""
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev).eval()
+    net.precision = prec
+    eng = net._get_engine()
+    sf = BatchedScoreFunction(net, markov_order=1, batch_size=5, device=dev, noise_process=SDAPipeline())
+    calls, real = [], ops.conv_center
+
+    def spy(*a, **kw):
+        calls.append(a[4])
+        return real(*a, **kw)
+    ops.conv_center = spy
+    try:
+        with torch.no_grad():
+            for shape in ((14, 2, 32, 32), (3, 9, 2, 32, 32)):
+                x = torch.randn(*shape, device=dev)
+                eng.use_center_conv = True
+                a = sf.score_fn(x, 0.4).clone()
+                n = sum(calls)
+                again = sf.score_fn(x, 0.4).clone()
+                eng.use_center_conv = False
+                b = sf.score_fn(x, 0.4).clone()
+                torch.cuda.synchronize()
+                assert n == (shape[-4] - 2) * (shape[0] if len(shape) == 5 else 1) and sum(calls) == 2 * n
+                del calls[:]
+                assert torch.equal(a, again)
+                assert (a - b).abs().max().item() <= tol * b.abs().max().item()
+    finally:
+        ops.conv_center = real
+        eng.use_center_conv = True
+
+
 def test_independent_stream_is_on_another_hardware_queue():
     """streams.py: HIP hands hardware queues to new streams in rotation and two streams on one queue run in order -- after a few
     streams exist, a freshly created one may sit on the caller's queue and the two-stream backward would silently serialise.
@@ -883,19 +921,38 @@ def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_
     x = torch.randn((L, Fv, H, H), device=dev, generator=g)
     t = torch.tensor(0.7)
     sf = BatchedScoreFunction(net, markov_order=k, batch_size=128, device=dev, noise_process=pipe)
+    eng = net._get_engine()
     with torch.no_grad():
-        eps_u = sf(x, t).clone()
-        assert eps_u.shape == x.shape and bool(torch.isfinite(eps_u).all())
-        # fold against direct module calls on whole batches of the evaluation (first, two middle ones, the ragged last: 8725 = 68 * 128 + 21)
-        for b0 in (0, 128 * 17, 128 * 40, 128 * 68):
-            nb = min(128, nwin - b0)
-            wins = torch.stack([x[i:i + w].reshape(w * Fv, H, H) for i in range(b0, b0 + nb)])
-            y = net(wins, t.to(dev)).view(nb, w, Fv, H, H)
-            assert torch.equal(eps_u[b0 + k: b0 + k + nb], y[:, k]), f"centre frames of windows {b0}..{b0 + nb - 1}"
-            if b0 == 0:
-                assert torch.equal(eps_u[:k], y[0, :k]), "leading frames come from the first window"
-            if b0 + nb == nwin:
-                assert torch.equal(eps_u[L - k:], y[-1, k + 1:]), "trailing frames come from the last window"
+        # fold against direct module calls on whole batches of the evaluation (first, two middle ones, the ragged last: 8725 = 68 * 128 + 21).
+        # With the full output rows scattered (use_center_conv off) every kept frame is bit-equal to the module's; with the centre
+        # frames out of c2w_conv_center (the default: only the kept rows are computed, engine.py::_fold_output) they are the same
+        # convolution summed in another order: equal to one rounding step of bf16, and bit-equal for all but a few per mille.
+        for center in (False, True):
+            eng.use_center_conv = center
+            eps_u = sf(x, t).clone()
+            assert eps_u.shape == x.shape and bool(torch.isfinite(eps_u).all())
+            for b0 in (0, 128 * 17, 128 * 40, 128 * 68):
+                nb = min(128, nwin - b0)
+                wins = torch.stack([x[i:i + w].reshape(w * Fv, H, H) for i in range(b0, b0 + nb)])
+                y = net(wins, t.to(dev)).view(nb, w, Fv, H, H)
+                got, want = eps_u[b0 + k: b0 + k + nb], y[:, k]
+                if not center:
+                    assert torch.equal(got, want), f"centre frames of windows {b0}..{b0 + nb - 1}"
+                else:
+                    d = (got - want).abs()
+                    assert bool((d <= 2.0 ** -7 * want.abs().clamp_min(2.0 ** -10)).all()), f"centre frames of windows {b0}..: max |d| {d.max().item():.3e}"
+                    assert float((d != 0).float().mean()) < 0.02
+                # the first / last window's other frames: out of the full output rows -- of the whole batch (bit-equal to the module's),
+                # or of that one window alone (another launch size, another kernel: equal to one rounding step)
+                def same(a, b, what):
+                    if not center:
+                        assert torch.equal(a, b), what
+                    else:
+                        assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs().clamp_min(2.0 ** -10)).all()), what
+                if b0 == 0:
+                    same(eps_u[:k], y[0, :k], "leading frames come from the first window")
+                if b0 + nb == nwin:
+                    same(eps_u[L - k:], y[-1, k + 1:], "trailing frames come from the last window")
         # conditioning
         A = PoolStrideOperator(16, 6)
         std = torch.tensor([0.1692666615037876, 0.0425178630338289, 0.3268027589410125, 0.3268027589410125]).view(1, Fv, 1, 1)

@@ -747,3 +747,37 @@ def test_big_kernels_are_run_to_run_identical_at_bench_size(dt):
     else:  # fp16: results below 2^-14 are subnormal and carry fewer bits than their doubles (measured: every mismatch is one of those)
         close(y2.float(), y0.float() * 2, dt, "conv linearity", tol=2e-3)
         close(dw2, dw0 * 2, dt, "weight-gradient linearity", tol=2e-3)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,H,W,Cin,wrows,r0,nr", [
+    (3, 16, 16, 64, 6, 2, 2),        # tiny net: F = 2, k = 1 (centre frame of three)
+    (2, 32, 48, 128, 52, 24, 4),     # F = 4, k = 6: the reference recipe's centre frame; 4 x 3 tiles per image
+    (5, 128, 128, 128, 65, 30, 5),   # F = 5, k = 6 at the benchmarked field size
+    (2, 8, 16, 128, 20, 4, 16),      # sixteen kept rows, ending at the matrix's last row
+    (1, 24, 32, 64, 6, 4, 2),        # the 16-row tile reaches past the matrix: rows >= wrows read as zeros
+])
+def test_conv_center_vs_emulation(dt, B, H, W, Cin, wrows, r0, nr):
+    """c2w_conv_center (model/nn.py:194 restricted to what src/thor/score.py:76-88 keeps) against conv2d on the selected rows; the
+    planes of other windows / channels in the destination stay untouched."""
+    assert ops.conv_center_supported(H, W, Cin, nr, dt)
+    x = rnd((B * H * W, Cin), dt, 1)
+    w = rnd((wrows, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = torch.randn(wrows, generator=torch.Generator().manual_seed(3)).to(dev())
+    nplanes = nr + 3
+    ostride = nplanes * H * W
+    out = torch.full((B, nplanes, H, W), -7.0, device=dev())
+    ref = out.clone()
+    ops.conv_center(x, w, bias, out, B, H, W, Cin, wrows, r0, nr, ostride, dt)
+    E.conv_center(x.cpu(), w.cpu(), bias.cpu(), ref_cpu := ref.cpu(), B, H, W, Cin, wrows, r0, nr, ostride, dt)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, nr:].cpu(), ref_cpu[:, nr:])  # nothing written outside the kept planes
+    close(out[:, :nr].cpu(), ref_cpu[:, :nr], dt, "conv_center")
+    # the same rows out of the full convolution agree to the rounding of the compute type (different summation order)
+    ldy = 128
+    y = torch.zeros((B * H * W, ldy), dtype=TD[dt], device=dev())
+    ops.conv(x, w, bias, y, geom(B, H, W, Cin, H, W, min(128, ((wrows + 15) // 16) * 16), ldy, wrows, ops.CONV_S1), dt)
+    full = y.float().view(B, H * W, ldy)[:, :, r0:r0 + nr].permute(0, 2, 1).reshape(B, nr, H, W)
+    close(out[:, :nr], full, dt, "conv_center vs full conv", tol=2 * TOL[dt] if dt == BF16 else None)
+    assert not ops.conv_center_supported(H + 4, W, Cin, nr, dt) and not ops.conv_center_supported(H, W, 192, nr, dt)
+    assert not ops.conv_center_supported(H, W, Cin, 17, dt) and not ops.conv_center_supported(H, W, Cin, nr, F32)

@@ -742,6 +742,49 @@ def test_co_sampled_members_equal_members_sampled_one_by_one(emu, cond):
         assert torch.allclose(both[m], alone, atol=1e-5, rtol=1e-5)
 
 
+def test_output_convolution_folds_inside_the_engine(emu):
+    """engine.py::_fold_output: where the kernel's domain allows (top level of 64 / 128 channels, 8 x 16-pixel tiles) the sampler's
+    network calls compute only the frames src/thor/score.py:76-88 keeps -- the centre frame of every window through ops.conv_center,
+    the first / last window's other frames through the full convolution of that window -- and write them into the trajectory.  Same
+    eps as scattering the full output rows, for one trajectory, for co-sampled members sharing batches, and for window ranges."""
+    torch.manual_seed(5)
+    net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=32, hidden_channels=[64, 64], hidden_blocks=[1, 1],
+                    attention_levels=[1], kernel_size=3, padding_mode="zeros").eval()
+    eng = net._get_engine()
+    calls = []
+    real = c2w_ops.conv_center
+
+    def spy(*a, **kw):
+        calls.append(a[4])  # windows per launch
+        return real(*a, **kw)
+    c2w_ops.conv_center = spy
+    try:
+        sf = BatchedScoreFunction(net, markov_order=1, batch_size=3, device=torch.device("cpu"), noise_process=SDAPipeline())
+        g = torch.Generator().manual_seed(9)
+        for shape in ((7, 2, 16, 16), (2, 6, 2, 16, 16)):
+            x = torch.randn(*shape, generator=g)
+            eng.use_center_conv = True
+            del calls[:]
+            a = sf.score_fn(x, 0.6).clone()
+            assert calls and sum(calls) == (shape[-4] - 2) * (shape[0] if len(shape) == 5 else 1)
+            eng.use_center_conv = False
+            del calls[:]
+            b = sf.score_fn(x, 0.6).clone()
+            assert not calls
+            assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+        x = torch.randn(9, 2, 16, 16, generator=g)
+        eng.use_center_conv = False
+        want = sf.score_fn(x, 0.3).clone()
+        eng.use_center_conv = True
+        out = torch.zeros_like(x)
+        sf.score_fn(x, 0.3, ranges=[(0, 2), (5, 2)], out=out)
+        sf.score_fn(x, 0.3, ranges=[(2, 3)], out=out)
+        assert torch.allclose(out, want, atol=1e-5, rtol=1e-5)
+    finally:
+        c2w_ops.conv_center = real
+        eng.use_center_conv = True
+
+
 def test_window_batch_floor_is_a_lower_bound_on_the_launch_size(emu, monkeypatch):
     """score_fn.py::window_batch_floor: ``batch_size`` (src/thor/score.py:156-185, a memory bound) is a LOWER bound on the windows
     per network call on the engine path -- scaled by the field size, never more than the trajectory has -- and 0 restores exactly
