@@ -66,6 +66,7 @@ _PROTOS = {
     "c2w_timestep_embedding": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "c2w_mu_sigma": [c_void_p, c_void_p, c_int, c_float, c_void_p],
     "c2w_publish_scalar": [c_void_p, c_void_p, c_int, c_void_p],
+    "c2w_gemv_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_center_supported": [c_int, c_int, c_int, c_int, c_int],
     "c2w_conv_center": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_void_p],
     "c2w_cast_f32": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],

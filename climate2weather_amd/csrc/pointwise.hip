@@ -1012,6 +1012,42 @@ extern "C" int c2w_sq_err_noise(const void* y, unsigned long long seed, float* o
     return sq_err_launch(y, nullptr, seed, true, out, loss_sum, B, C, HW, ldc, dtype, stream);
 }
 
+// One-row Linear (model/score.py:56-57,62-67 and the modulation projections model/nn.py:149 when t is ONE value for the whole batch --
+// every network call of the sampler): y[r] = act(b[r] + W[r][:K] . x).  As a GEMM that is a 16-pixel MFMA tile with one live column on
+// 4 workgroups walking K (30 us per layer, three layers in a row); as a matrix-vector product it is the weight matrix read once: one
+// wave per output row, coalesced 16-byte loads, a shuffle reduction.
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int rows, int K, int ldk, int act) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* wr = W + (size_t)r * ldk;
+    float s = 0.f;
+    if ((K & 3) == 0 && (ldk & 3) == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 a = *(const float4*)(wr + k), b = *(const float4*)(x + k);
+            s = fmaf(a.x, b.x, s);
+            s = fmaf(a.y, b.y, s);
+            s = fmaf(a.z, b.z, s);
+            s = fmaf(a.w, b.w, s);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) s = fmaf(wr[k], x[k], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += bias != nullptr ? bias[r] : 0.f;
+        y[r] = act == C2W_ACT_SILU ? silu_f(s) : (act == C2W_ACT_RELU ? fmaxf(s, 0.f) : s);
+    }
+}
+
+extern "C" int c2w_gemv_f32(const float* x, const float* W, const float* bias, float* y, int rows, int K, int ldk, int act, void* stream) {
+    if (!x || !W || !y || rows <= 0 || K <= 0 || ldk < K) return C2W_ERR_BAD_SHAPE;
+    if (act != C2W_ACT_NONE && act != C2W_ACT_SILU && act != C2W_ACT_RELU) return C2W_ERR_BAD_ARG;
+    gemv_f32_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, W, bias, y, rows, K, ldk, act);
+    return (int)hipGetLastError();
+}
+
 // A device scalar made readable by the host without a stream synchronisation (training_loop.py:385 reads the loss back every step):
 // one thread copies the value into a slot of host memory (pinned, device-visible) and then stores the sequence number the host polls
 // for -- release at system scope, so the value is there when the number is.

@@ -625,6 +625,10 @@ class Engine:
         model/nn.py:149)."""
         rec = self.layout.convs[name]
         y = torch.empty((rows, rec.rows), dtype=torch.float32, device=x.device)
+        if rows == 1 and tape is None and self.use_gemv and act in (ACT_NONE, ACT_SILU, ACT_RELU):
+            # one t for the whole batch (the sampler): a matrix-vector product instead of a 16-pixel MFMA tile with one live column
+            ops.gemv_f32(x, self._w(rec, DTYPE_F32), self._b(rec), y, rec.rows, rec.cin, rec.kstride, act)
+            return y
         g = self._geom(rows, 1, 1, rec.kstride, 1, 1, rec.rows, rec.rows, rec.rows, CONV_1X1)
         ops.conv(x, self._w(rec, DTYPE_F32), self._b(rec), y, g, DTYPE_F32, act=act)
         if tape is not None:
@@ -989,6 +993,7 @@ class Engine:
         return y
 
     use_center_conv = os.environ.get("C2W_NO_CENTER_CONV") != "1"  # A/B knob
+    use_gemv = os.environ.get("C2W_NO_GEMV") != "1"  # A/B knob: one-row Linear layers as matrix-vector products
 
     def _fold_output(self, fold: dict, name: str, xin: torch.Tensor, B: int, H: int, W: int, dt: int) -> bool:
         """The output convolution of a batch of trajectory windows, restricted to the frames fold() keeps (see forward).  False: not

@@ -269,6 +269,11 @@ def conv_center(x, w, bias, out, B, H, W, Cin, wrows, r0, nr, ostride, dtype):
     check(_lib.load().c2w_conv_center(_p(x), _p(w), _p(bias), _p(out), B, H, W, Cin, wrows, r0, nr, ostride, dtype, _stream()), "c2w_conv_center")
 
 
+def gemv_f32(x, W, bias, y, rows, K, ldk, act=ACT_NONE):
+    """y[r] = act(bias[r] + W[r][:K] . x): a Linear layer applied to ONE row (include/c2w_hip.h::c2w_gemv_f32)."""
+    check(_lib.load().c2w_gemv_f32(_p(x), _p(W), _p(bias), _p(y), rows, K, ldk, act, _stream()), "c2w_gemv_f32")
+
+
 def publish_scalar(src, host_slot_ptr: int, seq: int):
     """src: 0-d / 1-element fp32 device tensor; host_slot_ptr: address of two ints of pinned host memory (value bits, sequence number)."""
     check(_lib.load().c2w_publish_scalar(_p(src), ctypes.c_void_p(host_slot_ptr), int(seq), _stream()), "c2w_publish_scalar")

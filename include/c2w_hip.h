@@ -198,6 +198,10 @@ int c2w_sq_err_noise(const void* y, unsigned long long seed, float* out, float* 
 int c2w_conv_center_supported(int H, int W, int Cin, int nr, int dtype);
 int c2w_conv_center(const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int Cin, int wrows, int r0, int nr,
                     long long ostride, int dtype, void* stream);
+/* One-row fp32 Linear: y[r] = act(bias[r] + W[r][0..K) . x), W rows `ldk` floats apart; act = C2W_ACT_NONE / SILU / RELU.  The time
+ * embedding MLP and the modulation projections (model/score.py:56-57,62-67; model/nn.py:149) when t is one value for the whole batch
+ * (every network call of the sampler). */
+int c2w_gemv_f32(const float* x, const float* W, const float* bias, float* y, int rows, int K, int ldk, int act, void* stream);
 /* training_loop.py:385 (`loss.detach().item()` after optimizer.step()): the fp32 device scalar `src` is copied into host_slot[0]
  * (its bits) and host_slot[1] = seq is stored after it, release at system scope.  host_slot: two ints of pinned, device-visible host
  * memory; the host polls host_slot[1] for `seq` instead of synchronising the stream the value was produced on. */

@@ -395,6 +395,13 @@ def window_scatter(y, eps, nw, F, HW, k, i0, nwin_total, ldc, dtype):
                 Ev[(gi + tau) * F * HW:(gi + tau + 1) * F * HW] = Y[j, :, tau * F:(tau + 1) * F].t().reshape(-1)
 
 
+def gemv_f32(x, W, bias, y, rows, K, ldk, act=0):
+    z = W.reshape(-1)[: rows * ldk].view(rows, ldk)[:, :K].float() @ x.reshape(-1)[:K].float()
+    if bias is not None:
+        z = z + bias.reshape(-1)[:rows]
+    y.reshape(-1)[:rows] = F.silu(z) if act == ACT_SILU else (F.relu(z) if act == ACT_RELU else z)
+
+
 def conv_center_supported(H, W, Cin, nr, dtype):
     # the emulation has no tile shapes; it mirrors the kernel's domain except the element type (CPU tests run fp32)
     return H % 8 == 0 and W % 16 == 0 and Cin in (64, 128) and 1 <= nr <= 16

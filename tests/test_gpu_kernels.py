@@ -781,3 +781,25 @@ def test_conv_center_vs_emulation(dt, B, H, W, Cin, wrows, r0, nr):
     close(out[:, :nr], full, dt, "conv_center vs full conv", tol=2 * TOL[dt] if dt == BF16 else None)
     assert not ops.conv_center_supported(H + 4, W, Cin, nr, dt) and not ops.conv_center_supported(H, W, 192, nr, dt)
     assert not ops.conv_center_supported(H, W, Cin, 17, dt) and not ops.conv_center_supported(H, W, Cin, nr, F32)
+
+
+@pytest.mark.parametrize("rows,K,ldk,act", [(512, 32, 32, ops.ACT_SILU), (512, 512, 512, ops.ACT_SILU), (8448, 512, 512, ops.ACT_NONE),
+                                            (64, 5, 32, ops.ACT_NONE), (7, 33, 33, ops.ACT_RELU)])
+def test_gemv_f32_vs_emulation(rows, K, ldk, act):
+    """c2w_gemv_f32: the time-embedding MLP / modulation projections for ONE t (model/score.py:56-57,62-67; model/nn.py:149); also
+    against the fp32 matrix-core GEMM the batched path uses for the same layer."""
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(ldk, generator=g).to(dev())
+    Wm = (torch.randn(rows, ldk, generator=g) / math.sqrt(K)).to(dev())
+    b = torch.randn(rows, generator=g).to(dev())
+    y = torch.full((rows + 3,), -7.0, device=dev())
+    ops.gemv_f32(x, Wm, b, y, rows, K, ldk, act)
+    ref = torch.full((rows + 3,), -7.0)
+    E.gemv_f32(x.cpu(), Wm.cpu(), b.cpu(), ref, rows, K, ldk, act)
+    torch.cuda.synchronize()
+    assert torch.equal(y[rows:].cpu(), ref[rows:])
+    close(y[:rows].cpu(), ref[:rows], F32, "gemv")
+    if ldk % 32 == 0 and K == ldk and act != ops.ACT_RELU:
+        y2 = torch.zeros((1, rows), device=dev())
+        ops.conv(x.view(1, ldk), Wm, b, y2, geom(1, 1, 1, ldk, 1, 1, rows, rows, rows, ops.CONV_1X1), F32, act=act)
+        close(y[:rows], y2.view(-1), F32, "gemv vs fp32 MFMA linear")
