@@ -230,6 +230,7 @@ class Engine:
         self._wgrad_behind = os.environ.get("C2W_WGRAD_BEHIND") == "1"  # A/B knob: weight gradients one layer behind
         self._wg_pending = None
         self._pub = None  # [pinned (64, 2) int32 ring, its numpy view, publications so far] (publish / published)
+        self._skip_dw = False  # inside backward(want_dw=False): weight-gradient launches are skipped
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
         self.debug_trace: Optional[list] = None  # diagnostics: a list collects (name, output tensor[, operands of a conv]) of every conv / attention launch of a forward
         self.attach(net)
@@ -595,10 +596,14 @@ class Engine:
 
     def _wg(self, x: torch.Tensor, gy: torch.Tensor, rec: ConvRec, g: dict, dt: int) -> None:
         """dW, dbias of ``rec`` (dense operand) into the flat gradient buffer, on the gradient stream."""
+        if self._skip_dw:
+            return
         self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
 
     def _wgrad(self, rec: ConvRec, x: torch.Tensor, gy: torch.Tensor, g: dict, dt: int) -> None:
         """dW (+ dbias) of ``rec`` into the flat gradient buffer; a padded-operand layer goes through a padded scratch."""
+        if self._skip_dw:
+            return
         if rec.kstride == rec.cin:
             self._wg(x, gy, rec, g, dt)
             return
@@ -1058,11 +1063,22 @@ class Engine:
         return h
 
     # ------------------------------------------------------------------ backward
-    def backward(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool = False) -> Optional[torch.Tensor]:
+    def backward(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool = False, want_dw: bool = True) -> Optional[torch.Tensor]:
         """Run the recorded closures in reverse.  ``gy_nhwc``: gradient w.r.t. the network output in NHWC rows
-        [B*H*W][cout_pad] (padding channels zero).  Parameter gradients are ACCUMULATED into ``flat_grad``."""
+        [B*H*W][cout_pad] (padding channels zero).  Parameter gradients are ACCUMULATED into ``flat_grad``.
+        ``want_dw=False``: input gradient only -- no weight-gradient launch, no modulation path (exact guidance through a network
+        whose parameters do not require gradients, src/thor/score.py:28-33 on the frozen copy exp/downscaling.py:110-126 loads)."""
+        if not want_dw:
+            self._skip_dw = True
+            try:
+                return self._backward(tape, gy_nhwc, want_dx, False)
+            finally:
+                self._skip_dw = False
         if self.flat_grad is None:
             raise RuntimeError("call ensure_grad_buffer() before backward")
+        return self._backward(tape, gy_nhwc, want_dx, True)
+
+    def _backward(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool, want_dw: bool) -> Optional[torch.Tensor]:
         if self._dg_ready is not None:  # operands prefetched on the gradient stream: this stream reads them from here on
             torch.cuda.current_stream().wait_event(self._dg_ready)
             self._dg_ready = None
@@ -1079,10 +1095,11 @@ class Engine:
         for bw in reversed(steps[n_mlp:]):
             g = bw(g)
         dx0 = g
-        # modulation path: dm_all -> proj -> map_layer1 -> map_layer0
-        gm = tape.meta["dm_all"]
-        for bw in reversed(steps[:n_mlp]):
-            gm = bw(gm)
+        # modulation path: dm_all -> proj -> map_layer1 -> map_layer0 (parameter gradients only: t carries none)
+        if want_dw:
+            gm = tape.meta["dm_all"]
+            for bw in reversed(steps[:n_mlp]):
+                gm = bw(gm)
         self.join_grad_stream()  # every gradient is in flat_grad for whoever runs next on this stream (optimizer, autograd)
         tape.steps = []
         tape.gskip.clear()

@@ -82,8 +82,9 @@ class _ScoreUNetFn(torch.autograd.Function):
         if gy is None:
             return (None, None, None, None, None) + (None,) * n_params
         # gradients of this call only: use a private flat buffer so autograd's accumulation semantics hold
+        want_dw = any(ctx.needs_input_grad[5:])  # a frozen network (requires_grad_(False): the sampler's copy) needs no weight gradient
         saved = eng.flat_grad
-        eng.flat_grad = torch.zeros_like(eng.flat)
+        eng.flat_grad = torch.zeros_like(eng.flat) if want_dw else None
         try:
             dt = m["dt"]
             g_nhwc = torch.empty((m["B"] * m["H"] * m["W"], lay.cout_pad), dtype=TORCH_DTYPE[dt], device=gy.device)
@@ -92,10 +93,12 @@ class _ScoreUNetFn(torch.autograd.Function):
             else:
                 gy = gy.contiguous().float()
                 ops.nchw_to_nhwc(gy, None, None, g_nhwc, m["B"], m["C"], m["H"] * m["W"], lay.cout_pad, dt)
-            dx = eng.backward(tape, g_nhwc, want_dx=ctx.x_needs_grad)
+            dx = eng.backward(tape, g_nhwc, want_dx=ctx.x_needs_grad, want_dw=want_dw)
             fg = eng.flat_grad
         finally:
             eng.flat_grad = saved
+        if not want_dw:
+            return (dx, None, None, None, None) + (None,) * n_params
         grads = tuple(torch.as_strided(fg, shape, strides, off) for (off, shape, strides) in lay.views.values())
         return (dx, None, None, None, None) + grads
 

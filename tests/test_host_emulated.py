@@ -785,6 +785,34 @@ def test_output_convolution_folds_inside_the_engine(emu):
         eng.use_center_conv = True
 
 
+def test_input_gradient_of_a_frozen_network_launches_no_weight_gradient(emu, monkeypatch):
+    """Exact guidance (src/thor/score.py:28-33, the API default exact_grad=True) differentiates the network with respect to its INPUT;
+    the reference's sampler runs it on a snapshot saved with requires_grad_(False) (training_loop.py:253-265).  For such a network the
+    backward pass runs the input-gradient chain only: same dx as with trainable parameters, no weight-gradient launch, no parameter
+    .grad."""
+    net = _tiny().eval()
+    x = torch.randn(2, 6, 16, 16, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([0.3, 0.7])
+    xa = x.clone().requires_grad_(True)
+    net(xa, t).square().sum().backward()
+    assert all(p.grad is not None for p in net.parameters())
+    calls = []
+    real = c2w_ops.conv_wgrad
+    monkeypatch.setattr(c2w_ops, "conv_wgrad", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    net.zero_grad(set_to_none=True)
+    net.requires_grad_(False)
+    xb = x.clone().requires_grad_(True)
+    net(xb, t).square().sum().backward()
+    assert not calls and all(p.grad is None for p in net.parameters())
+    assert torch.equal(xa.grad, xb.grad)
+    (gx,) = torch.autograd.grad(net(xb, t).square().sum(), xb)
+    assert torch.equal(gx, xa.grad) and not calls
+    net.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    net(xc, t).square().sum().backward()
+    assert calls and all(p.grad is not None for p in net.parameters()) and torch.equal(xc.grad, xa.grad)
+
+
 def test_window_batch_floor_is_a_lower_bound_on_the_launch_size(emu, monkeypatch):
     """score_fn.py::window_batch_floor: ``batch_size`` (src/thor/score.py:156-185, a memory bound) is a LOWER bound on the windows
     per network call on the engine path -- scaled by the field size, never more than the trajectory has -- and 0 restores exactly
