@@ -198,7 +198,9 @@ class _WindowScore(AbstractScoreFunction):
             raise ValueError(f"network expects {lay.in_channels} channels, window gives {w * F}")
         total = M * nwin
         bs = min(max(self.batch_size or total, self._window_floor(H * W)), total)
-        if xd.dim() == 5:  # co-sampled members: equal batches instead of full ones and a ragged tail (148 windows: 2 x 74, not 128 + 20)
+        if xd.dim() == 5 or int(self.window_batch_floor) > 0:
+            # equal batches instead of full ones and a ragged tail (co-sampled members, 148 windows: 2 x 74, not 128 + 20; L = 1037
+            # under the floor: 5 x 205, not 4 x 256 + 1 -- a one-window network call costs 1.5 ms of launches for nothing)
             bs = -(-total // -(-total // bs))
         if self.use_graphs and xd.is_cuda and src_dev == self.device and xd.dim() == 4:
             return self._score_graphed(xd, t, eng, dt, lay, k, w, nwin, bs)

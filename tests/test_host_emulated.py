@@ -843,6 +843,11 @@ def test_window_batch_floor_is_a_lower_bound_on_the_launch_size(emu, monkeypatch
     three = sf.score_fn(noise, 0.5)
     assert calls == [3, 3, 1]
     assert torch.allclose(three, exact, atol=1e-6, rtol=1e-6)
+    del calls[:]
+    monkeypatch.setattr(sf, "_window_floor", lambda pixels: 5)  # 7 windows in launches of at least 5: two equal ones, not 5 + 2
+    two = sf.score_fn(noise, 0.5)
+    assert calls == [4, 3]
+    assert torch.allclose(two, exact, atol=1e-6, rtol=1e-6)
     assert type(sf).window_batch_floor == 256
 
 
