@@ -1079,6 +1079,26 @@ class Engine:
         return self._backward(tape, gy_nhwc, want_dx, True)
 
     def _backward(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool, want_dw: bool) -> Optional[torch.Tensor]:
+        it = self.backward_steps(tape, gy_nhwc, want_dx, want_dw)
+        try:
+            while True:
+                next(it)
+        except StopIteration as done:
+            return done.value
+
+    def backward_steps(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool = False, want_dw: bool = True):
+        """``backward`` as a generator: yields after every recorded closure the lowest flat offset whose gradient is final so far
+        (``layout.numel`` before the first; see Tape.progress) -- a caller may hand finished suffixes of the gradient buffer on while
+        the rest of the pass is still to be enqueued (score.py::_GradSegment: torch's DistributedDataParallel all-reduces a bucket as
+        soon as its gradients have been delivered).  The generator's return value is dx (or None)."""
+        low = [self.layout.numel]
+        outer = tape.progress
+
+        def progress(off: int) -> None:
+            low[0] = min(low[0], off)
+            if outer is not None:
+                outer(off)
+        tape.progress = progress
         if self._dg_ready is not None:  # operands prefetched on the gradient stream: this stream reads them from here on
             torch.cuda.current_stream().wait_event(self._dg_ready)
             self._dg_ready = None
@@ -1094,15 +1114,18 @@ class Engine:
         g = gy_nhwc
         for bw in reversed(steps[n_mlp:]):
             g = bw(g)
+            yield low[0]
         dx0 = g
         # modulation path: dm_all -> proj -> map_layer1 -> map_layer0 (parameter gradients only: t carries none)
         if want_dw:
             gm = tape.meta["dm_all"]
             for bw in reversed(steps[:n_mlp]):
                 gm = bw(gm)
+                yield low[0]
         self.join_grad_stream()  # every gradient is in flat_grad for whoever runs next on this stream (optimizer, autograd)
         tape.steps = []
         tape.gskip.clear()
+        tape.progress = outer
         if not want_dx or dx0 is None:
             return None
         m = tape.meta

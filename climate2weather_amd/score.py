@@ -103,6 +103,121 @@ class _ScoreUNetFn(torch.autograd.Function):
         return (dx, None, None, None, None) + grads
 
 
+class _SegCtrl:
+    """What the nodes of one segmented call share (see _GradSegment)."""
+    __slots__ = ("net", "holder", "dt", "nseg", "bounds", "owned", "y", "it", "fg", "events", "x_needs_grad")
+
+    def __init__(self, net, holder, dt, nseg, bounds, owned):
+        self.net, self.holder, self.dt, self.nseg, self.bounds, self.owned = net, holder, dt, nseg, bounds, owned
+        self.y = self.it = self.fg = None
+        self.events = {}
+        self.x_needs_grad = False
+
+
+class _GradSegment(torch.autograd.Function):
+    """The same network call as _ScoreUNetFn, as a CHAIN of autograd nodes that deliver the parameter gradients in segments while
+    the backward pass is still running -- for torch's DistributedDataParallel (fabric.setup_module, training_loop.py:116), whose
+    reducer all-reduces a bucket as soon as autograd has delivered its gradients: out of one node they would all arrive together,
+    behind the last launch of the pass.
+
+    The flat gradient buffer fills from its end (engine.Tape.progress: a layer used late in the forward lies late in the buffer
+    and is differentiated first), so it is cut into ``nseg`` ranges of equal size at parameter boundaries.  Node s runs the slice
+    of the recorded backward that completes range s; the chain is built so that autograd reaches node nseg - 1 (which also returns
+    the network output) first and node 0 (which ran the forward and takes x) last.  A node hands over the PREVIOUS slice's range:
+    its weight-gradient launches were enqueued a slice ago on the gradient stream, so waiting for them (an event, not a join) does
+    not hold up the input-gradient chain.  Node 0 delivers the last two ranges behind the pass's own final join.
+    Plain torch.autograd only (no functorch transforms: those keep the single node)."""
+
+    @staticmethod
+    def forward(ctx, a, t, ctrl, idx, *params):
+        ctx.ctrl, ctx.idx = ctrl, idx
+        if idx == 0:
+            eng = ctrl.net._get_engine()
+            tape = Tape()
+            if ctrl.holder.loss is not None:
+                y, ctrl.holder.loss_sum = _forward_loss(eng, a, t, ctrl.dt, ctrl.holder.loss, tape)
+            else:
+                y = eng.forward(a, t, ctrl.dt, tape=tape, want_dx=True, forcing=ctrl.holder.forcing)
+            ctrl.holder.tape = tape
+            ctrl.y = y
+            ctrl.x_needs_grad = bool(ctx.needs_input_grad[0]) and ctrl.holder.loss is None
+        if idx == ctrl.nseg - 1:
+            y, ctrl.y = ctrl.y, None
+            return y
+        return torch.zeros((), dtype=torch.float32, device=ctrl.net._get_engine().flat.device)  # the token the next node hangs on
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import ops
+        ctrl, s = ctx.ctrl, ctx.idx
+        eng: Engine = ctrl.net._get_engine()
+        lay = eng.layout
+        tape = ctrl.holder.tape
+        if s == ctrl.nseg - 1:  # autograd's first stop: start the pass
+            m = tape.meta
+            dt = m["dt"]
+            g_nhwc = torch.empty((m["B"] * m["H"] * m["W"], lay.cout_pad), dtype=TORCH_DTYPE[dt], device=g.device)
+            if "loss" in m:
+                _loss_output_gradient(m, g, g_nhwc, lay, dt)
+            else:
+                ops.nchw_to_nhwc(g.contiguous().float(), None, None, g_nhwc, m["B"], m["C"], m["H"] * m["W"], lay.cout_pad, dt)
+            ctrl.fg = torch.zeros_like(eng.flat)  # gradients of this call only (autograd accumulates into .grad itself)
+            ctrl.it = eng.backward_steps(tape, g_nhwc, want_dx=ctrl.x_needs_grad, want_dw=True)
+        dx = None
+        saved, eng.flat_grad = eng.flat_grad, ctrl.fg
+        try:
+            try:
+                low = lay.numel
+                while s == 0 or low > ctrl.bounds[s]:
+                    low = next(ctrl.it)
+            except StopIteration as done:
+                dx = done.value
+        finally:
+            eng.flat_grad = saved
+        side = eng.grad_stream()
+        if side is not None and s > 0:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            ctrl.events[s] = ev
+            prev = ctrl.events.pop(s + 1, None)
+            if prev is not None:  # the range handed over now was enqueued a slice ago: this wait is (nearly) free
+                torch.cuda.current_stream().wait_event(prev)
+        fg = ctrl.fg
+        views = lay.views
+        grads = tuple(torch.as_strided(fg, views[k][1], views[k][2], views[k][0]) for k in ctrl.owned[s])
+        if s == 0:
+            ctrl.it = ctrl.fg = None
+            return (dx, None, None, None) + grads
+        return (torch.zeros((), dtype=torch.float32, device=fg.device), None, None, None) + grads
+
+
+def _segmented_call(net, eng: Engine, x, t, dt: int, holder: "_TapeHolder", nseg: int):
+    """Build the _GradSegment chain for one network call; returns its output (the network output or the fused loss tensor)."""
+    lay = eng.layout
+    names = list(lay.views)
+    offs = [lay.views[k][0] for k in names]
+    nseg = max(1, min(nseg, len(names)))
+    bounds = [0]
+    for i in range(1, nseg):  # range i starts at the parameter boundary nearest to i / nseg of the buffer (strictly increasing)
+        target = i * lay.numel // nseg
+        b = min((o for o in offs if o > bounds[-1]), key=lambda o: abs(o - target), default=None)
+        if b is None:
+            break
+        bounds.append(b)
+    nseg = len(bounds)
+    seg_of = lambda off: max(i for i in range(nseg) if bounds[i] <= off)  # noqa: E731
+    rng = [[k for k, o in zip(names, offs) if seg_of(o) == i] for i in range(nseg)]
+    # node s hands over range s + 1 (node 0: ranges 0 and 1; the node autograd reaches first: nothing)
+    owned = [rng[0] + (rng[1] if nseg > 1 else [])] + [rng[s + 1] if s + 1 < nseg else [] for s in range(1, nseg)]
+    by_name = dict(zip(names, eng._bound))
+    ctrl = _SegCtrl(net, holder, dt, nseg, bounds, owned)
+    out = _GradSegment.apply(x, t, ctrl, 0, *[by_name[k] for k in owned[0]])
+    for s in range(1, nseg):
+        out = _GradSegment.apply(out, None, ctrl, s, *[by_name[k] for k in owned[s]])
+    return out
+
+
 def _forward_loss(eng: Engine, x, t, dt: int, req: dict, tape: Optional[Tape]):
     """The training-side composition of the reference in one launch sequence (src/thor/pipelines.py:22-35 around model/score.py:59-70):
     x_t = mu(t) x + sigma(t) eps fused into the input conversion, the network, and the unreduced loss (eps_pred - eps)^2 written
@@ -337,7 +452,8 @@ class ScoreUNet(torch.nn.Module):
         if req is not None:
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 holder = _TapeHolder(loss=req)
-                out = _ScoreUNetFn.apply(x, t, self, dt, holder, *params)
+                nseg = self._segments(params, x)
+                out = _segmented_call(self, eng, x, t, dt, holder, nseg) if nseg > 1 else _ScoreUNetFn.apply(x, t, self, dt, holder, *params)
                 ls = holder.loss_sum
             else:
                 out, ls = _forward_loss(eng, x, t, dt, req, None)
@@ -348,11 +464,32 @@ class ScoreUNet(torch.nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         shape = x.shape
         x4 = x.reshape(-1, *shape[-3:]) if x.dim() != 4 else x
-        if needs_grad or _in_functorch_transform(x):
+        nseg = self._segments(params, x4) if needs_grad else 1
+        if nseg > 1:
+            y = _segmented_call(self, eng, x4, t, dt, _TapeHolder(forcing=forcing), nseg)
+        elif needs_grad or _in_functorch_transform(x):
             y = _ScoreUNetFn.apply(x4, t, self, dt, _TapeHolder(forcing=forcing), *params)
         else:
             y = eng.forward(x4, t, dt, forcing=forcing)
         return y.reshape(shape).to(x.dtype)
+
+    # Parameter gradients delivered in this many segments during the backward pass (_GradSegment) instead of all at its end: None =
+    # 8 when torch.distributed runs more than one rank (a DistributedDataParallel wrapper can then all-reduce its buckets under the
+    # pass), else 1; C2W_GRAD_SEGMENTS or the attribute override it.
+    grad_segments = None
+
+    def _segments(self, params, x) -> int:
+        n = self.grad_segments
+        if n is None:
+            env = os.environ.get("C2W_GRAD_SEGMENTS")
+            if env is not None:
+                n = int(env)
+            else:
+                import torch.distributed as dist
+                n = 8 if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else 1
+        if n <= 1 or not torch.is_grad_enabled() or not all(p.requires_grad for p in params) or _in_functorch_transform(x):
+            return 1
+        return int(n)
 
     def _ordered_params(self, eng: Engine):
         named = dict(self.named_parameters())

@@ -202,8 +202,19 @@ def run_module_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: s
     opt.zero_grad(set_to_none=True)
     tt = t[sl].reshape(-1, 1, 1, 1)
     xt = pipe.mu(tt) * x[sl] + pipe.sigma(tt) * eps[sl]  # src/thor/pipelines.py:22-25 with the golden noise injected
+    # more than one rank: the module's backward is the segmented chain (score.py::_GradSegment), so that DDP's reducer receives the
+    # output side's gradients while the pass is still running -- the hooks below see them arrive in at least three instalments
+    assert net._segments(list(net.parameters()), xt) == 8
+    arrivals, launches = [], []
+    real_wgrad = c2w_ops.conv_wgrad
+    c2w_ops.conv_wgrad = lambda *a, **kw: (launches.append(1), real_wgrad(*a, **kw))[1]
+    hooks = [p.register_hook(lambda g_, n=n: arrivals.append(len(launches))) for n, p in net.named_parameters()]
     loss = ((ddp(xt, t[sl].reshape(-1)) - eps[sl]) ** 2).mean()
     loss.backward()
+    c2w_ops.conv_wgrad = real_wgrad
+    for h in hooks:
+        h.remove()
+    assert len(arrivals) == len(list(net.parameters())) and len(set(arrivals)) >= 3 and arrivals[0] < len(launches), (sorted(set(arrivals)), len(launches))
     grads = {n: p.grad.clone() for n, p in net.named_parameters()}
     opt.step()
     torch.save(dict(loss=float(loss), grads=grads, sd={k: v.clone() for k, v in net.state_dict().items()}),

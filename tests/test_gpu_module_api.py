@@ -203,6 +203,42 @@ def test_loss_item_does_not_drain_the_stream():
     assert type(plain) is torch.Tensor
 
 
+@pytest.mark.parametrize("precision,autocast", [("fp32", None), ("auto", torch.bfloat16)])
+def test_segmented_gradient_delivery_equals_the_single_node_on_the_gpu(precision, autocast):
+    """score.py::_GradSegment on the HIP engine (two-stream backward, events between the slices): the chain of nodes hands the same
+    gradients over as the single node -- the 3x3 / 1x1 weight gradients bit for bit (split-K sums in a fixed order), everything that
+    goes through fp32 atomics (biases, modulation path) to round-off -- and the first of them before the pass has been enqueued."""
+    pipe = SDAPipeline()
+    a, b = _tiny(precision=precision), _tiny(precision=precision)
+    b.grad_segments = 4
+    launches, order = [], []
+    real = ops.conv_wgrad
+    ops.conv_wgrad = lambda *a_, **kw: (launches.append(1), real(*a_, **kw))[1]
+    try:
+        for net in (a, b):
+            if net is b:
+                for n, p in b.named_parameters():
+                    p.register_hook(lambda g, n=n: order.append(len(launches)))
+                del launches[:]
+            torch.manual_seed(5)
+            with (torch.autocast("cuda", dtype=autocast) if autocast else torch.autocast("cuda", enabled=False)):
+                loss = pipe.loss(net=net, x=_batch(0, DEV)).mean()
+            loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_wgrad = real
+    assert len(order) == len(list(b.parameters())) and order[0] < len(launches) and len(set(order)) >= 3
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        if n.endswith("weight") and p.dim() >= 3:
+            assert torch.equal(p.grad, q.grad), n
+        else:
+            assert _close(q.grad, p.grad, 1e-4 if autocast is None else 2e-2), n
+    # the optimizer's flat path takes these gradients (views of one private buffer) like the single node's
+    ob = AdamW(b.parameters(), **HP)
+    ob.step()
+    assert 0 in ob._flat
+
+
 def test_full_size_network_one_reference_shaped_step():
     """The default network (configs/sda_unet.yml, C = 65, 128 x 128) through one iteration of the reference's loop with all five
     class_name seams pointing here, bf16 autocast, B = 4: flat path engaged, EMA moved, and the weights equal torch.optim.AdamW's on

@@ -785,6 +785,56 @@ def test_output_convolution_folds_inside_the_engine(emu):
         eng.use_center_conv = True
 
 
+@pytest.mark.parametrize("fused_loss", [False, True])
+def test_parameter_gradients_are_delivered_in_segments_during_the_backward_pass(emu, monkeypatch, fused_loss):
+    """score.py::_GradSegment: under torch's DistributedDataParallel (fabric.setup_module, training_loop.py:116) the reducer can only
+    all-reduce a bucket once autograd has delivered its gradients.  With ``grad_segments`` the module's backward is a chain of nodes
+    that hand finished ranges of the flat gradient buffer over while the rest of the pass is still to be enqueued: same gradients bit
+    for bit as the single node, the output side's parameters first, and weight-gradient launches still to come when the first hooks fire."""
+    x = torch.randn(2, 6, 16, 16, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([0.3, 0.7])
+    pipe = SDAPipeline()
+
+    def run(net, xin):
+        if fused_loss:
+            torch.manual_seed(11)
+            return pipe.loss(net=net, x=xin).mean()
+        return net(xin, t).square().sum()
+    a, b = _tiny().train(), _tiny().train()
+    xa = x.clone().requires_grad_(not fused_loss)
+    la = run(a, xa)
+    la.backward()
+    launches = []
+    real = c2w_ops.conv_wgrad
+    monkeypatch.setattr(c2w_ops, "conv_wgrad", lambda *a_, **kw: (launches.append(1), real(*a_, **kw))[1])
+    b.grad_segments = 4
+    order = []
+    for n, p in b.named_parameters():
+        p.register_hook(lambda g, n=n: order.append((n, len(launches))))
+    xb = x.clone().requires_grad_(not fused_loss)
+    lb = run(b, xb)
+    assert torch.equal(la.detach(), lb.detach())
+    lb.backward()
+    total = len(launches)
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(p.grad, q.grad), n
+    if not fused_loss:
+        assert torch.equal(xa.grad, xb.grad)
+    names = [n for n, _ in order]
+    assert sorted(names) == sorted(n for n, _ in b.named_parameters())  # every parameter exactly once
+    first, last = order[0], order[-1]
+    assert first[1] < total, "the first gradients are handed over before the last weight-gradient launch is enqueued"
+    assert first[0].startswith("unet.") and last[1] == total
+    assert any(n.startswith("map_layer") for n in names[-8:])  # the time-embedding MLP is differentiated last
+    seen_at = sorted({k for _, k in order})
+    assert len(seen_at) >= 3, seen_at  # at least three distinct points of the pass at which gradients arrived
+    # a frozen network and functorch transforms keep the single node
+    b.requires_grad_(False)
+    assert b._segments(list(b.parameters()), x) == 1
+    b.requires_grad_(True)
+    assert b._segments(list(b.parameters()), x) == 4 and a._segments(list(a.parameters()), x) == 1
+
+
 def test_input_gradient_of_a_frozen_network_launches_no_weight_gradient(emu, monkeypatch):
     """Exact guidance (src/thor/score.py:28-33, the API default exact_grad=True) differentiates the network with respect to its INPUT;
     the reference's sampler runs it on a snapshot saved with requires_grad_(False) (training_loop.py:253-265).  For such a network the
