@@ -44,6 +44,9 @@ template <> struct Mma<float> {
 
 template <int N> struct IC { static constexpr int value = N; };
 
+#ifndef C2W_HEXP
+#define C2W_HEXP 0
+#endif
 #ifndef C2W_EXP
 #define C2W_EXP 0  // diagnostic timing builds only: 1 no MFMA, 2 no LDS fragment reads, 4 no LDS-DMA in the loop, 8 no barrier,
 #endif             // 16 cycle stamps (s_memtime) to the buffer registered with c2w_debug_set (tools/stamp_conv_patch.py)
@@ -376,13 +379,15 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         wait_vm4(np);
         __builtin_amdgcn_s_barrier();
         if (s == 0) C2W_STAMP(st1);
-        if (TAP == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+        // C2W_HEXP (diagnostic timing builds of THIS kernel only, wrong results): 1 the patch is not reloaded at chunk boundaries,
+        // 2 no weight LDS-DMA in the loop (the two prologue stages' tiles are re-read)
+        if (!(C2W_HEXP & 1) && TAP == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
             issue_patch(c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         np = 0;
-        if (s + 2 < NS) {
+        if (!(C2W_HEXP & 2) && s + 2 < NS) {
             issue_w(TAP + 2 >= 9 ? c + 1 : c, T2, (TAP + 2) % 3);
             np = 4;
         }
