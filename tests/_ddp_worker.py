@@ -299,3 +299,61 @@ def run_five_strings_ddp(rank: int, world: int, port: int, golden_dir: str, out_
     torch.save(res, os.path.join(out_dir, f"five{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_module_ddp_gpu(rank: int, world: int, port: int, out_dir: str):
+    """The drop-in path under torch's DistributedDataParallel over RCCL on the HIP engine: the five-string loop in bf16 autocast, the
+    module's backward as the segmented chain (score.py::_GradSegment; forced on for one rank), three steps -- next to the same three
+    steps without a process group and with the single node.  What this can show on one GPU: DDP's reducer (bucket copies on the
+    caller's stream, all-reduce on its own) reads gradients that the engine's gradient stream wrote, ordered by the chain's events."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from climate2weather_amd import ops as c2w_ops
+    from climate2weather_amd.ema import StandardEMA
+    from climate2weather_amd.optim import AdamW
+    from climate2weather_amd.pipelines import SDAPipeline
+    from climate2weather_amd.score import ScoreUNet
+
+    cfg = dict(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128, 128], hidden_blocks=[1, 1, 1],
+               attention_levels=[2], kernel_size=3, padding_mode="zeros")
+    gen = torch.Generator().manual_seed(11)
+    data = [(torch.randn(4 * world, 6, 32, 32, generator=gen) * 0.5 + 0.5) for _ in range(3)]
+
+    def loop(use_ddp: bool):
+        torch.manual_seed(3)
+        net = ScoreUNet(**cfg).to(dev)
+        net.grad_segments = 4 if use_ddp else 1
+        mod = torch.nn.parallel.DistributedDataParallel(net, device_ids=[rank]) if use_ddp else net
+        pipeline, optimizer, ema = SDAPipeline(), AdamW(params=net.parameters(), lr=1e-3, weight_decay=1e-3, betas=[0.9, 0.999]), StandardEMA(net=net)
+        arrivals, launches = [], []
+        real = c2w_ops.conv_wgrad
+        c2w_ops.conv_wgrad = lambda *a, **kw: (launches.append(1), real(*a, **kw))[1]
+        hooks = [p.register_hook(lambda g_: arrivals.append(len(launches))) for p in net.parameters()]
+        losses = []
+        try:
+            for i in range(3):
+                optimizer.zero_grad()
+                torch.manual_seed(100 + i)  # the loss draws t and the noise seed from torch's CPU stream
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = pipeline.loss(net=mod, x=data[i][4 * rank: 4 * rank + 4].to(dev)).mean().mul(1.0)
+                loss.backward()
+                optimizer.step()
+                losses.append(loss.detach().item())
+                ema.update()
+        finally:
+            c2w_ops.conv_wgrad = real
+            for h in hooks:
+                h.remove()
+        torch.cuda.synchronize()
+        n_par = len(list(net.parameters()))
+        return dict(losses=losses, flat=net._get_engine().flat.detach().clone().cpu(), flat_path=bool(optimizer._flat),
+                    arrivals=arrivals[:n_par], launches=len(launches) // 3, ema=ema.emas[0]._get_engine().flat.detach().clone().cpu())
+    res = dict(ddp=loop(True), world=world)
+    if world == 1:
+        res["plain"] = loop(False)
+    torch.save(res, os.path.join(out_dir, f"modgpu{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

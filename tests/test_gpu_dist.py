@@ -120,6 +120,32 @@ def test_full_size_bf16_steps_through_an_rccl_communicator(tmp_path, world):
         assert torch.equal(outs[0]["dist"]["flat"], outs[1]["dist"]["flat"])  # ranks in lock step
 
 
+@pytest.mark.parametrize("world", [1, pytest.param(2, marks=two_gpus)])
+def test_drop_in_module_under_torch_ddp_over_rccl_with_segmented_gradient_delivery(tmp_path, world):
+    """training_loop.py:116,369-391 on the HIP engine: the module wrapped in torch's DistributedDataParallel over RCCL, five class-name
+    seams, bf16 autocast, the backward pass as the segmented chain (score.py::_GradSegment).  DDP's reducer copies gradients into its
+    buckets on the caller's stream and all-reduces them on its own while the engine's gradient stream is still writing later ranges:
+    the chain's events order the two.  One rank: the same steps as the loop without a process group (a one-rank mean is the
+    identity); two ranks: lock step."""
+    import torch.multiprocessing as mp
+    from _ddp_worker import run_module_ddp_gpu
+    mp.spawn(run_module_ddp_gpu, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"modgpu{r}.pt", weights_only=False) for r in range(world)]
+    for o in outs:
+        d = o["ddp"]
+        assert d["flat_path"] and all(np.isfinite(d["losses"]))
+        assert len(set(d["arrivals"])) >= 3 and d["arrivals"][0] < d["launches"], (sorted(set(d["arrivals"])), d["launches"])
+    if world == 1:
+        d, p = outs[0]["ddp"], outs[0]["plain"]
+        assert len(set(p["arrivals"])) == 1  # the single node delivers everything at the end
+        assert d["losses"] == pytest.approx(p["losses"], rel=2e-3)
+        # three AdamW steps of lr 1e-3: bf16 gradients + atomics-order noise may flip g / (|g| + eps) where |g| ~ eps
+        assert (d["flat"] - p["flat"]).abs().max().item() <= 6.5e-3 and (d["flat"] - p["flat"]).abs().mean().item() <= 2e-4
+        assert (d["ema"] - p["ema"]).abs().max().item() <= 1e-5
+    else:
+        assert torch.equal(outs[0]["ddp"]["flat"], outs[1]["ddp"]["flat"])
+
+
 @two_gpus
 def test_time_sharded_sampler_over_rccl_two_ranks(golden_dir, tmp_path):
     import torch.multiprocessing as mp
