@@ -608,7 +608,8 @@ def run_rank(a):
         dist.destroy_process_group()
 
 
-def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16"), item=True, lazy=False):
+def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16"), item=True, lazy=False,
+               wrap=None):
     """What a maintainer gets who changes ONLY the five class_name / func_name strings of train.py:164-193 and
     leaves training_loop.py alone: the loop of training_loop.py:369-391, statement for statement -- optimizer.zero_grad(); data =
     next(dataset_iterator) (a dense (B,C,H,W) tensor); loss = pipeline.loss(net, data).mean().mul(loss_scaling) under autocast;
@@ -651,6 +652,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         torch.manual_seed(0)
         net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
         net.train()
+        mod = wrap(net) if wrap is not None else net  # tools/bench_module_api.py --ddp: torch's DistributedDataParallel (fabric.setup_module)
         pipeline = SDAPipeline()
         optimizer = AdamW(params=net.parameters(), lr=1e-4, weight_decay=1e-3, betas=[0.9, 0.999])  # train.py:176-181 through the class_name seam
         ema = StandardEMA(net=net)
@@ -663,7 +665,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
             optimizer.zero_grad()
             data = feed.next_batch(B, lazy=lazy)
             with torch.autocast("cuda", dtype=ac):
-                loss = pipeline.loss(net=net, x=data).mean().mul(1.0)
+                loss = pipeline.loss(net=mod, x=data).mean().mul(1.0)
             (scaler.scale(loss) if scaler is not None else loss).backward()
             lr = linear_learning_rate_schedule(state["cur_ndata"], total_ndata, 1e-4)
             for g in optimizer.param_groups:
@@ -681,7 +683,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         r.update(final_loss=round(float(state["losses"][-1]), 5), flat_optimizer_path=bool(optimizer._flat), optimizer_steps_taken=optimizer.steps_taken(),
                  loss_scale=scaler.get_scale() if scaler is not None else None)
         res[name] = r
-        del net, optimizer, ema, feed, ds, pipeline, step  # the allocator keeps its blocks: the next leg has the same working set
+        del net, mod, optimizer, ema, feed, ds, pipeline, step  # the allocator keeps its blocks: the next leg has the same working set
     # the fused Trainer in the reference's arithmetic type (loss scale, inf check and skipped steps on the device)
     for prec in ("fp16", "bf16"):
         if "trainer_" + prec not in legs:
