@@ -426,7 +426,10 @@ def test_graph_replayed_score_function_sees_weights_written_through_the_paramete
 def test_bf16_and_fp16_training_track_fp32_training():
     """60 optimizer steps on a small network and a fixed synthetic batch stream: the bf16 throughput mode and the fp16 mode (the
     reference's own "16-mixed", under the device-resident dynamic loss scale) must learn like the fp32 parity mode (same data,
-    noise and times injected): losses fall, and the curves stay within 5 % of the fp32 one."""
+    noise and times injected): losses fall, and the curves stay close to the fp32 one -- fp16 within 2 % (observed +0.2 %, the same
+    from run to run), bf16 within 10 %: 60 steps of lr 2e-3 amplify the order of the fp32 atomics behind 8-bit significands, and
+    the tail of the bf16 curve lands anywhere between -0.1 % and +4.6 % of the fp32 one from run to run
+    (tools/probes/flake_training_curves.py; a 5 % bound failed once in ten full-suite runs)."""
     cfg = dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
     curves = {}
     for prec in ("fp32", "bf16", "fp16"):
@@ -449,9 +452,9 @@ def test_bf16_and_fp16_training_track_fp32_training():
         last = sum(curves[prec][-10:]) / 10
         assert last < 0.6 * first, (prec, first, last)
     a = torch.tensor(curves["fp32"][-20:]).mean().item()
-    for prec in ("bf16", "fp16"):
+    for prec, bound in (("bf16", 0.10), ("fp16", 0.02)):
         b = torch.tensor(curves[prec][-20:]).mean().item()
-        assert abs(a - b) <= 0.05 * a, (prec, a, b)
+        assert abs(a - b) <= bound * a, (prec, a, b)
 
 
 def test_training_step_with_regenerated_noise_equals_the_step_on_the_written_noise_tensor():
