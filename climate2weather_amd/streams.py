@@ -15,15 +15,18 @@ from typing import Optional
 
 import torch
 
-_PROBE_CYCLES = 4_000_000  # ~1.7 ms of torch.cuda._sleep on the stream that must NOT hold the candidate up
+_PROBE_CYCLES = 8_000_000  # ~3.4 ms of torch.cuda._sleep on the stream that must NOT hold the candidate up
 
 
 def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None) -> bool:
     """True if a launch on ``side`` completes while a kernel enqueued earlier on ``main`` (default: the current stream) is still
-    running, i.e. the two streams are on different hardware queues.  Costs one ~1.7-ms spin kernel on ``main``."""
+    running, i.e. the two streams are on different hardware queues.  Costs one ~3.4-ms spin kernel on ``main``."""
     main = main or torch.cuda.current_stream(side.device)
     flag = torch.zeros(1, dtype=torch.int32, device=side.device)
     main.synchronize()
+    with torch.cuda.stream(side):  # first use of a stream can take milliseconds (its hardware queue is created): not part of the verdict
+        flag.zero_()
+    side.synchronize()
     with torch.cuda.stream(main):
         torch.cuda._sleep(_PROBE_CYCLES)
     with torch.cuda.stream(side):

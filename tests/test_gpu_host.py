@@ -596,7 +596,7 @@ def test_independent_stream_is_on_another_hardware_queue():
     torch.cuda.synchronize()
     if all(verdicts):
         pytest.skip("no plain stream shared the default stream's queue on this runtime: the premise could not be shown (the helper still works)")
-    assert 1 <= verdicts.count(False) <= 6, verdicts  # one slot of the rotation, not a broken probe
+    assert 1 <= verdicts.count(False) <= 8, verdicts  # some slots of the rotation, not a broken probe
     # the engine's gradient stream is such a stream
     torch.manual_seed(0)
     net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
