@@ -9,7 +9,9 @@ default configs/sda_unet.yml network, synthetic (B, F*w, 128, 128) fields, bf16 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
         the ranks are the launcher's: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live (HIP events on the launch stream around every launch of the
+Rank 0 prints ONE compact JSON line (< 6 KB: the headline, `roofline`, `cpu_baseline` and a few scalars -- compact_line() below;
+tests/test_bench_launcher.py bounds its size) and writes everything else (`by_kernel`, the deep variant, the module-API legs, the
+sampler legs) to gpurun_out/bench_extras.json, named in the line's `extras_file`.  `roofline` is measured live (HIP events on the launch stream around every launch of the
 dominant kernel inside the timed region); `by_kernel` comes from extra steps AFTER the timed region in which every implicit-GEMM
 launch is bracketed by events and the two backward streams are serialised (each kernel alone on the chip); `cpu_baseline` is the
 CPU oracle (oracle/, a plain-PyTorch restatement of the same step) timed on this box's host cores, rank 0 at N=1 only.
@@ -374,6 +376,98 @@ def _step_stats(ms):
     return dict(median=round(srt[len(srt) // 2], 3), min=round(srt[0], 3), max=round(srt[-1], 3), mean=round(sum(ms) / len(ms), 3), n=len(ms))
 
 
+
+# ----------------------------------------------------------------------------------------------------------------- the line
+COMPACT_LIMIT = 6144  # bytes; the driver keeps the last 8 KB of stdout (round 4: a 24 KB line left it nothing to parse)
+
+
+def extras_path() -> str:
+    return os.environ.get("C2W_BENCH_EXTRAS", os.path.join(REPO, "gpurun_out", "bench_extras.json"))
+
+
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def compact_line(full: dict, extras_file=None) -> str:
+    """The ONE line stdout carries: the contract's keys, `roofline` and `cpu_baseline` reduced to their numbers and one short sentence
+    each, and the scalars the other legs boil down to.  Everything it leaves out is in `extras_file`.  Never longer than COMPACT_LIMIT."""
+    roof, cpu = full.get("roofline"), full.get("cpu_baseline")
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data", "config")}
+    if roof:
+        prof = roof.get("from_profile") or {}
+        dom = next((v for k, v in (prof.get("mfma_busy_by_kernel_in_step") or {}).items() if ", 4, true> x8192" in k), {})
+        line["roofline"] = dict(
+            bound=roof.get("bound"), achieved=roof.get("achieved"), peak=roof.get("peak"), unit=roof.get("unit"), frac=roof.get("frac"),
+            traffic=roof.get("traffic"), kernel=str(roof.get("kernel_short") or roof.get("kernel"))[:160], avg_launch_ms=roof.get("avg_launch_ms"),
+            flops_per_launch=roof.get("flops_per_launch"), launches_timed=roof.get("launches_timed"),
+            traffic_source=prof.get("source"), mfma_busy=dom.get("mfma_busy"), clock_ghz=dom.get("clock_ghz"),
+            vendor_gemm_tflops=_get(roof, "vendor_gemm_reference", "tflops"),
+            all_launches_frac=_get(roof, "all_launches", "frac"))
+    else:
+        line["roofline"] = None
+    if cpu:
+        line["cpu_baseline"] = dict(value=cpu.get("value"), unit=cpu.get("unit"), cores=cpu.get("cores"), kind=cpu.get("kind"),
+                                    sample=str(cpu.get("sample"))[:260], cpu_model=cpu.get("cpu_model"), logical_cpus=cpu.get("logical_cpus"),
+                                    c52_train_windows_per_s=_get(cpu, "legs", "C=52", "train_windows_per_s"))
+        if cpu.get("value"):
+            line["gpu_over_cpu"] = round(full.get("value", 0.0) / cpu["value"], 1)
+    else:
+        line["cpu_baseline"] = None
+    for k in ("step_ms", "mfma_frac_whole_step", "model_tflops_per_gpu", "final_loss", "optimizer_steps_per_s", "world_size_rccl",
+              "sampler_windows_per_s_per_gpu", "sampler_cosampled_windows_per_s_per_gpu"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    # the reference's own arithmetic (fp16, train.py:98) and its own recipe (4 variables -> 52 channels, run_training.sh:39-45), same step
+    for key, path in (("trainer_fp16_windows_per_s", ("module_api", "trainer_fp16", "windows_per_s")),
+                      ("trainer_bf16_c52_windows_per_s", ("module_api", "trainer_bf16_c52", "windows_per_s")),
+                      ("module_api_bf16_autocast_windows_per_s", ("module_api", "bf16_autocast", "windows_per_s")),
+                      ("module_api_fp16_gradscaler_windows_per_s", ("module_api", "fp16_autocast_gradscaler", "windows_per_s")),
+                      ("serialised_step_ms", ("by_kernel", "serialised_step_ms")),
+                      ("deep_variant_train_windows_per_s", ("deep_variant", "train_windows_per_s")),
+                      ("deep_variant_train_mfma_frac", ("deep_variant", "train_mfma_frac")),
+                      ("sampler_member_sharded_window_forwards_per_s", ("sampler_member_sharded", "window_forwards_per_s"))):
+        v = _get(full, *path)
+        if v is not None:
+            line[key] = v
+    legs = _get(full, "sampler_configs3", "legs") or []
+    short = {f"L{l['L']}_m{l['members']}_c{l['corrections']}": l.get("window_forwards_per_s") for l in legs if isinstance(l, dict) and "L" in l}
+    if short:
+        line["sampler_conditioned_window_forwards_per_s"] = short
+    line["extras_file"] = extras_file
+    text = json.dumps(line)
+    if len(text) >= COMPACT_LIMIT:  # cannot happen with the fields above; if a string grew, the optional scalars go first
+        for k in list(line)[::-1]:
+            if k in ("extras_file",) or k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                continue
+            del line[k]
+            text = json.dumps(line)
+            if len(text) < COMPACT_LIMIT:
+                break
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def emit(json_fd, full: dict):
+    """Everything to the extras file (and nothing of it to stdout); the compact line, alone and last, to the saved stdout descriptor."""
+    path = extras_path()
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        shown = os.path.relpath(path, REPO)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
+        shown = None
+    os.write(json_fd, (compact_line(full, shown) + "\n").encode())
+
+
 # ----------------------------------------------------------------------------------------------------------------- one rank
 def run_rank(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -603,12 +697,12 @@ def run_rank(a):
             out["cpu_baseline"] = cpu_baseline(C, a.size, DEFAULT_CFG)
         else:
             out["cpu_baseline"] = None
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(json_fd, out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
-def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16"), item=True, lazy=False,
+def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16", "trainer_bf16_c52"), item=True, lazy=False,
                wrap=None):
     """What a maintainer gets who changes ONLY the five class_name / func_name strings of train.py:164-193 and
     leaves training_loop.py alone: the loop of training_loop.py:369-391, statement for statement -- optimizer.zero_grad(); data =
@@ -685,18 +779,19 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         res[name] = r
         del net, mod, optimizer, ema, feed, ds, pipeline, step  # the allocator keeps its blocks: the next leg has the same working set
     # the fused Trainer in the reference's arithmetic type (loss scale, inf check and skipped steps on the device)
-    for prec in ("fp16", "bf16"):
-        if "trainer_" + prec not in legs:
+    # ... and in bf16 on the reference's own recipe: 4 variables x window 13 = 52 channels (run_training.sh:39-45)
+    for leg, prec, nvars in (("trainer_fp16", "fp16", a.vars), ("trainer_bf16", "bf16", a.vars), ("trainer_bf16_c52", "bf16", 4)):
+        if leg not in legs:
             continue
         torch.manual_seed(0)
-        net = ScoreUNet(channels=C, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
+        net = ScoreUNet(channels=nvars * w, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
         tr = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4), weight_decay=1e-3, ema_rates=[0.9999],
                      precision=prec, batch_size=B, seed=1000)
-        ds = SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=a.vars, height=a.size, width=a.size, window=w, seed=0)
+        ds = SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=nvars, height=a.size, width=a.size, window=w, seed=0)
         feed = DeviceWindowFeed(ds, dev, seed=0)
         r = timed(lambda: tr.step(feed.next_batch(B, lazy=True)))
-        r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale())
-        res["trainer_" + prec] = r
+        r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale(), channels=nvars * w)
+        res[leg] = r
         del tr, net, feed, ds
     # the like-for-like ratio: every leg over the fused bf16 Trainer timed in THIS process, minutes after the headline and on the
     # same allocator state (vs_trainer compares with the headline line, taken in another process at another moment)
