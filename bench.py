@@ -774,7 +774,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
             ema.update(cur_ndata=state["cur_ndata"], batch_size=B)
 
         r = timed(step)
-        r.update(final_loss=round(float(state["losses"][-1]), 5), flat_optimizer_path=bool(optimizer._flat), optimizer_steps_taken=optimizer.steps_taken(),
+        r.update(final_loss=round(float(state["losses"][-1]), 5), flat_optimizer_path=optimizer.fused_path_active(), optimizer_steps_taken=optimizer.steps_taken(),
                  loss_scale=scaler.get_scale() if scaler is not None else None)
         res[name] = r
         del net, mod, optimizer, ema, feed, ds, pipeline, step  # the allocator keeps its blocks: the next leg has the same working set

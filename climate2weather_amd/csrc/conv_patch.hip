@@ -14,7 +14,7 @@
 //   * weights ring: 3 slots of [128 co][128 B]; slot = tap % 3 is a compile-time constant.
 // MFMA tiling: 128 px x 128 co per workgroup, 4 waves x (4x4) 16x16 tiles, A = weights, B = pixels.
 // (The 16x16-tile, one-workgroup-per-CU form of this kernel -- 156 KB of LDS -- measured 5 % behind two half-tile workgroups per CU
-// and was removed in round 3; the cycle-stamp / ablation builds live in csrc/experimental/conv_patch_lab.hip.)
+// and was removed in round 3; the cycle-stamp / ablation builds live in lab/csrc/conv_patch_lab.hip.)
 #include <cstdlib>
 
 #include "conv_epilogue.h"

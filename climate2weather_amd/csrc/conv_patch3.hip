@@ -25,7 +25,7 @@
 //
 // The schedule / epilogue experiments that were measured and rejected (two-group wave schedule, four-slot ring, direct stores from
 // the accumulators, staggered workgroup start, LDS-DMA placement variants, the 4-wave and 8-row-tile forms), the ablation and
-// timestamp builds live in csrc/experimental/conv_patch3_lab.hip, which tools/build_variant.sh compiles INSTEAD of this file;
+// timestamp builds live in lab/csrc/conv_patch3_lab.hip (repo root, not shipped), which lab/build_variant.sh compiles INSTEAD of this file;
 // their results: profiles/r02_experiments.md section 2, profiles/r03_experiments.md.
 #include <cstdlib>
 

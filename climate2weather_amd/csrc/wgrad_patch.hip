@@ -22,7 +22,7 @@
 
 #include "knobs.h"
 // (schedule variants measured and rejected -- burst LDS-DMA issue, fragments one tap ahead, carried kh = 2 fragments -- and the ablation
-// builds live in csrc/experimental/wgrad_patch_lab.hip; results in profiles/r02_experiments.md section 1)
+// builds live in lab/csrc/wgrad_patch_lab.hip; results in profiles/r02_experiments.md section 1)
 
 
 namespace {

@@ -217,7 +217,7 @@ class Engine:
         self._pk_ok: Dict[tuple, bool] = {}    # launch geometry -> does c2w_conv_forward take packed weights there
         self._pk_want: Dict[tuple, dict] = {}   # (kind, dtype) -> {name of a matrix that is kept packed: weight version of its copy}
         self._pk_desc: Dict[tuple, torch.Tensor] = {}  # ((kind, dtype), names) -> descriptor table of one pack launch
-        self._pk_sync: Dict[tuple, tuple] = {}  # (kind, dtype) -> (event behind the last pack launch, ids of the streams ordered behind it)
+        self._pk_sync: Dict[tuple, list] = {}  # (kind, dtype) -> [(event behind a pack launch, ids of the streams ordered behind it)]
         self.use_packed_weights = os.environ.get("C2W_NO_WPACKED") is None
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
@@ -229,7 +229,7 @@ class Engine:
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
         self._wgrad_behind = os.environ.get("C2W_WGRAD_BEHIND") == "1"  # A/B knob: weight gradients one layer behind
         self._wg_pending = None
-        self._pub = None  # [pinned (64, 2) int32 ring, its numpy view, publications so far] (publish / published)
+        self._pub = None  # ops.HostRing of published scalars (publish / published)
         self._skip_dw = False  # inside backward(want_dw=False): weight-gradient launches are skipped
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
         self.debug_trace: Optional[list] = None  # diagnostics: a list collects (name, output tensor[, operands of a conv]) of every conv / attention launch of a forward
@@ -260,7 +260,7 @@ class Engine:
         for i in self._bound_by_id:
             _ENGINE_BY_PARAM_ID[i] = me
         self.generation = getattr(self, "generation", 0) + 1  # bumped per (re-)attach: holders of flat-layout plans re-validate
-        self._slots, self._slots_net = None, (lambda: None)
+        self._slots, self._slots_net, self._links = None, (lambda: None), []
         self._offs4 = [4 * off for off, _, _ in lay.views.values()]
         self._pver = self._param_versions()
         self.flat = flat
@@ -290,6 +290,11 @@ class Engine:
         if slots is None or self._slots_net() is not net:
             slots = self._slots = [_resolve(net, name) for name in self.layout.views]
             self._slots_net = weakref.ref(net)
+            self._links = _module_links(net, self.layout.views)
+        for parent, key, child in self._links:  # module surgery after the first forward (net.unet.x = new_module): the cached slots are stale
+            if parent._modules.get(key) is not child:
+                self._slots = None
+                return False
         base = self.flat.data_ptr()
         for (mod, attr), bound, off in zip(slots, self._bound, self._offs4):
             p = mod._parameters[attr]
@@ -446,13 +451,20 @@ class Engine:
             if buf.is_cuda:  # forwards on OTHER streams (score_fn: window batches alternate between streams) must see this launch
                 ev = torch.cuda.Event()
                 ev.record()
-                self._pk_sync[key] = (ev, {torch.cuda.current_stream().cuda_stream})
-        elif buf.is_cuda and key in self._pk_sync:
-            ev, seen = self._pk_sync[key]
+                rec_ = (ev, {torch.cuda.current_stream().cuda_stream})
+                # one record per pack launch that is still the newest writer of some matrix: a launch that rewrote EVERYTHING wanted
+                # supersedes the older ones; a newcomer's launch joins them (a stream that packs a newcomer has not thereby waited for
+                # the packs other streams made earlier)
+                if len(stale) == len(want):
+                    self._pk_sync[key] = [rec_]
+                else:
+                    self._pk_sync.setdefault(key, []).append(rec_)
+        if buf.is_cuda and key in self._pk_sync:
             sid = torch.cuda.current_stream().cuda_stream
-            if sid not in seen:  # once per (pack launch, stream): order this stream behind the launch that wrote the copies
-                torch.cuda.current_stream().wait_event(ev)
-                seen.add(sid)
+            for ev, seen in self._pk_sync[key]:
+                if sid not in seen:  # once per (pack launch, stream): order this stream behind every launch that wrote copies it may read
+                    torch.cuda.current_stream().wait_event(ev)
+                    seen.add(sid)
         return buf[ent[0]:]
 
     def repack_wanted(self, dt: int) -> None:
@@ -520,35 +532,17 @@ class Engine:
 
     def publish(self, scalar: torch.Tensor):
         """Enqueue, behind the launch that produced the fp32 device scalar ``scalar``, its copy into a slot of pinned host memory
-        (ops.publish_scalar); returns (slot, sequence number) for ``published``.  A ring of 64 slots: a reader that comes more than
-        64 publications late finds a newer number in its slot and falls back to an ordinary read."""
+        (ops.HostRing); returns (slot, sequence number) for ``published``."""
         if self._pub is None:
-            buf = torch.zeros((64, 2), dtype=torch.int32).pin_memory()
-            self._pub = [buf, buf.numpy(), 0]
-        buf, _, n = self._pub
-        n += 1
-        self._pub[2] = n
-        slot = n % 64
-        ops.publish_scalar(scalar, buf.data_ptr() + 8 * slot, n)
-        return slot, n
+            self._pub = ops.HostRing()
+        return self._pub.publish(scalar)
 
     def published(self, slot: int, seq: int, timeout_s: float = 20.0):
         """The value of publication ``seq`` as a Python float once the device has written it (polling host memory: no stream is
         synchronised), or None if the slot has been reused or nothing arrived in ``timeout_s``."""
-        import time
-        arr = self._pub[1]
-        t0 = None
-        while True:
-            got = int(arr[slot, 1])
-            if got == seq:
-                return float(arr[slot, 0:1].view("float32")[0])
-            if got > seq:
-                return None
-            if t0 is None:
-                t0 = time.perf_counter()
-            elif time.perf_counter() - t0 > timeout_s:
-                return None
-            time.sleep(0)
+        import struct
+        bits = self._pub.read_bits(slot, seq, timeout_s)
+        return None if bits is None else struct.unpack("<f", struct.pack("<i", bits))[0]
 
     def _on_grad_stream(self, fn, *tensors) -> None:
         """Run ``fn`` (launches that read ``tensors`` and write gradient memory) on the gradient stream, behind everything
@@ -1132,6 +1126,20 @@ class Engine:
         dx = torch.empty((m["B"], m["C"], m["H"], m["W"]), dtype=torch.float32, device=dx0.device)
         ops.nhwc_to_nchw(dx0, dx, m["B"], m["C"], m["H"] * m["W"], self.layout.cin_pad, m["dt"])
         return dx
+
+
+def _module_links(net, names):
+    """(parent module, child key, child module) for every module on the path to one of the parameters ``names``, each link once."""
+    links, seen = [], set()
+    for name in names:
+        mod = net
+        for p in name.split(".")[:-1]:
+            child = mod._modules[p]
+            if (id(mod), p) not in seen:
+                seen.add((id(mod), p))
+                links.append((mod, p, child))
+            mod = child
+    return links
 
 
 def _resolve(net, name: str):

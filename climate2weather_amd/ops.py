@@ -279,6 +279,43 @@ def publish_scalar(src, host_slot_ptr: int, seq: int):
     check(_lib.load().c2w_publish_scalar(_p(src), ctypes.c_void_p(host_slot_ptr), int(seq), _stream()), "c2w_publish_scalar")
 
 
+class HostRing:
+    """A ring of (value bits, sequence number) slots in pinned host memory that kernels publish 4-byte device scalars into
+    (publish_scalar) and the host polls WITHOUT synchronising a stream: the loss value of a training step (Engine.publish), the
+    sampler's NaN flag of every step (pipelines.SDAPipeline.sample).  A reader that comes more than ``slots`` publications late
+    finds a newer number in its slot and gets None."""
+
+    def __init__(self, slots: int = 64):
+        self.slots = slots
+        self.buf = torch.zeros((slots, 2), dtype=torch.int32).pin_memory()
+        self.arr = self.buf.numpy()
+        self.n = 0
+
+    def publish(self, scalar):
+        """Enqueue, behind whatever produced the 4-byte device scalar, its copy into the next slot; -> (slot, sequence number)."""
+        self.n += 1
+        slot = self.n % self.slots
+        publish_scalar(scalar, self.buf.data_ptr() + 8 * slot, self.n)
+        return slot, self.n
+
+    def read_bits(self, slot: int, seq: int, timeout_s: float = 20.0):
+        """The published 32 bits as an int once the device has written publication ``seq`` (polling host memory), or None if the slot has
+        been reused or nothing arrived within ``timeout_s`` (0: do not wait)."""
+        import time
+        t0 = None
+        while True:
+            got = int(self.arr[slot, 1])
+            if got == seq:
+                return int(self.arr[slot, 0])
+            if got > seq or timeout_s <= 0:
+                return None
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > timeout_s:
+                return None
+            time.sleep(0)
+
+
 def cast_f32(src, dst, n, dtype):
     check(_lib.load().c2w_cast_f32(_p(src), _p(dst), n, dtype, _stream()), "c2w_cast_f32")
 

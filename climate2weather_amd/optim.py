@@ -11,8 +11,9 @@ Fabric's "16-mixed" GradScaler runs without a 228-tensor ``unscale_`` and withou
 When a group's parameters are exactly those of ONE engine-backed ScoreUNet (the reference's case), a step is one launch of the fused
 AdamW kernel over the network's flat fp32 buffer (engine.py::Layout; exp_avg / exp_avg_sq are two more flat buffers whose per-parameter
 views populate ``state``), which also refreshes the 16-bit weight shadow the next forward reads -- instead of 228 tensors' worth of
-multi-tensor launches followed by a separate cast.  Anything else (other modules, CPU tensors, partial parameter sets, gradients that
-do not lie in one flat buffer) takes torch's own functional AdamW per tensor: same numbers, torch's speed.
+multi-tensor launches followed by a separate cast.  Gradients that all exist but do not lie in one flat buffer (DDP bucket views) are
+first copied into the engine's flat gradient buffer by one multi-tensor launch.  Anything else (other modules, CPU tensors, partial
+parameter sets, missing gradients) takes torch's own functional AdamW per tensor on the same state: same numbers, torch's speed.
 """
 from __future__ import annotations
 
@@ -80,7 +81,7 @@ class AdamW(torch.optim.Optimizer):
                 return None
         old = st
         st = dict(eng=weakref.ref(eng), generation=eng.generation, m=torch.zeros_like(eng.flat), v=torch.zeros_like(eng.flat),
-                  steps=0, amp=None)
+                  steps=0, amp=None, active=True)
         if old is not None and old["m"].shape == st["m"].shape and old["m"].device == st["m"].device:  # re-attached engine (e.g. load_state_dict with assign): keep the moments
             st["m"], st["v"], st["steps"], st["amp"] = old["m"], old["v"], old["steps"], old["amp"]
         else:  # moments torch-style state may already hold (load_state_dict before the first step, or steps taken on the per-tensor path)
@@ -150,10 +151,31 @@ class AdamW(torch.optim.Optimizer):
         if sdt is not None:
             eng.prefetch_backward_operands(sdt)  # the next backward's transposed / packed operands, on the gradient stream, next to the next forward
 
+    @staticmethod
+    def _gather_grads(eng) -> Optional[torch.Tensor]:
+        """Gradients that exist for every parameter but do NOT lie in one flat buffer (torch DDP with gradient_as_bucket_view=True: views of
+        the reducer's buckets; zero_grad(set_to_none=False) followed by accumulation into foreign tensors): copied, by one multi-tensor
+        launch, into the engine's flat gradient buffer, so that the step stays the fused one.  None if a gradient is missing or not a
+        dense fp32 tensor on the engine's device (then the step goes per tensor)."""
+        bound = eng._bound
+        grads = [p.grad for p in bound]
+        dev = eng.flat.device
+        if any(g is None or g.dtype != torch.float32 or g.device != dev or g.is_sparse or g.shape != p.shape for g, p in zip(grads, bound)):
+            return None
+        flat = eng.ensure_grad_buffer()
+        views = [torch.as_strided(flat, shape, strides, off) for off, shape, strides in eng.layout.views.values()]
+        torch._foreach_copy_(views, grads)
+        return flat
+
+    def fused_path_active(self, gi: int = 0) -> bool:
+        """Did the last step of group ``gi`` run as the one fused launch over the flat buffer?"""
+        st = self._flat.get(gi)
+        return st is not None and bool(st["active"])
+
     def steps_taken(self, gi: int = 0) -> int:
         """AdamW steps actually applied to group ``gi`` (skipped overflow steps excluded; synchronises under AMP)."""
         st = self._flat.get(gi)
-        if st is None:
+        if st is None or not st["active"]:
             ps = self.state.get(self.param_groups[gi]["params"][0])
             return int(float(ps["step"])) if ps else 0
         return int(st["amp"][3].item()) if st["amp"] is not None else st["steps"]
@@ -172,21 +194,47 @@ class AdamW(torch.optim.Optimizer):
             if st is not None:
                 eng = st["eng"]()
                 gflat = self._flat_grad(eng)
+                if gflat is None:
+                    gflat = self._gather_grads(eng)
                 if gflat is not None:
+                    if not st["active"]:
+                        self._enter_flat(gi, st)
                     self._step_flat(group, st, eng, gflat, grad_scale, found_inf)
                     continue
-                self._leave_flat(gi, st)
+                if st["active"]:
+                    self._leave_flat(gi, st)
             self._step_per_tensor(group, grad_scale, found_inf)
         return loss
 
     def _leave_flat(self, gi: int, st: dict) -> None:
-        """Gradients no longer lie in one flat buffer: continue per tensor on the same state (the views stay valid tensors)."""
+        """Some gradient is missing or foreign: continue per tensor ON THE SAME STATE.  The record stays (its flat exp_avg / exp_avg_sq
+        buffers are what ``state`` holds views of -- torch's functional AdamW updates them in place), marked inactive; only the shared
+        step counter becomes one tensor per parameter, as torch's per-tensor path increments each.  Nothing is reallocated, and the
+        next step whose gradients are all there re-enters the fused path (_enter_flat)."""
         steps = self.steps_taken(gi)
         for p in self.param_groups[gi]["params"]:
             ps = self.state.get(p)
             if ps:
                 ps["step"] = torch.tensor(float(steps), dtype=torch.float32)
-        del self._flat[gi]
+        st["active"] = False
+
+    def _enter_flat(self, gi: int, st: dict) -> None:
+        """Back on the fused path after per-tensor steps: the moments never left the flat buffers; the step counter is the per-tensor
+        path's (every parameter of a group has taken the same number of steps unless gradients were missing for some: the maximum)."""
+        steps = 0
+        for p in self.param_groups[gi]["params"]:
+            ps = self.state.get(p)
+            if ps:
+                steps = max(steps, int(float(ps["step"])))
+        st["steps"] = steps
+        st["step_t"].fill_(float(steps))
+        if st["amp"] is not None:
+            st["amp"][3] = float(steps)
+        for p in self.param_groups[gi]["params"]:
+            ps = self.state.get(p)
+            if ps:
+                ps["step"] = st["step_t"]
+        st["active"] = True
 
     def _step_per_tensor(self, group: dict, grad_scale, found_inf) -> None:
         from torch.optim.adamw import adamw
@@ -222,7 +270,7 @@ class AdamW(torch.optim.Optimizer):
         sd = super().state_dict()
         taken = {}
         for gi, g in enumerate(sd["param_groups"]):
-            if gi in self._flat:
+            if gi in self._flat and self._flat[gi]["active"]:
                 for idx in g["params"]:
                     taken[idx] = self.steps_taken(gi)
         for idx, ps in sd["state"].items():

@@ -109,6 +109,12 @@ class SDAPipeline:
         zs = iter(z_draws) if z_draws is not None else None
         z = torch.empty_like(x) if corrections > 0 else None
         nan_flag = torch.zeros(1, dtype=torch.int32, device=device) if fused else None
+        # The reference raises in the step that produced the NaN (src/thor/pipelines.py:90-91: an isnan over the state = a device
+        # synchronisation per step).  Here the update kernels or a flag on the device; a one-thread kernel publishes the flag into pinned
+        # host memory behind every step (ops.HostRing: the mechanism loss.item() uses) and the host reads step i - 1's publication after
+        # it has ENQUEUED step i: it never drains a stream, runs at most one step ahead of the device, and raises one step late.
+        ring = ops.HostRing() if fused else None
+        pending = None
         sumsq = torch.zeros(1, dtype=torch.float32, device=device) if fused and corrections > 0 else None
         ts_host = torch.linspace(1, 0, steps + 1).tolist()
         iterator = range(steps)
@@ -146,6 +152,9 @@ class SDAPipeline:
                             sumsq.zero_()
                             ops.sumsq(eps, sumsq, n)
                             ops.sampler_correct(x, eps, z, sumsq, nan_flag, n, tau, sg_n)
+                    if pending is not None and ring.read_bits(*pending):  # the flag as it stood behind the PREVIOUS step
+                        raise ValueError("NaN detected in sample")
+                    pending = ring.publish(nan_flag)
                 else:
                     x = self._sample_step(score_fn, x, t, dt, proc_x0=proc_x0)
                     for _ in range(corrections):
@@ -160,7 +169,7 @@ class SDAPipeline:
                         del eps
                     if torch.isnan(x).any():
                         raise ValueError("NaN detected in sample")
-        if fused and int(nan_flag.item()) != 0:  # one host sync per trajectory instead of one per step
+        if fused and int(nan_flag.item()) != 0:  # the last step's flag: the trajectory's end is a synchronisation anyway
             raise ValueError("NaN detected in sample")
         total = time.time() - start
         print(f"Total sampling time: {total:.2f} s  = {total / 60:.3f} min = {total / 3600:.4f} h")

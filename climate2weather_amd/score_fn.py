@@ -258,9 +258,34 @@ class _WindowScore(AbstractScoreFunction):
     # exactly ``batch_size`` windows per network call.
     window_batch_floor = 256
 
+    # bytes of activations one window of 128 x 128 pixels keeps alive during an inference forward of the default network, per byte of
+    # element size (256 windows of bf16 ~ 5 GB: measured); the floor never raises a batch beyond what fits next to what is allocated
+    _ACT_BYTES_PER_WINDOW_PER_ESZ = 10 << 20
+
     def _window_floor(self, pixels: int) -> int:
         n = int(self.window_batch_floor)
-        return max(1, n * 128 * 128 // max(pixels, 1)) if n > 0 else 1
+        if n <= 0:
+            return 1
+        floor = max(1, n * 128 * 128 // max(pixels, 1))
+        configured = int(self.batch_size or 0)
+        if configured and floor > configured and self.device.type == "cuda":
+            # ``batch_size`` is the reference's bound on activation memory (src/thor/score.py:156-185): the floor overrides it only as far
+            # as the device's FREE memory allows (a user who lowered batch_size to fit next to other allocations keeps fitting), and
+            # says so once
+            try:
+                free, _ = torch.cuda.mem_get_info(self.device)
+            except RuntimeError:
+                free = None
+            if free is not None:
+                streams = max(1, int(self.num_streams))
+                per_window = self._ACT_BYTES_PER_WINDOW_PER_ESZ * 2 * max(pixels, 1) // (128 * 128)
+                fit = int(0.5 * free) // max(1, per_window * streams)
+                floor = max(configured, min(floor, fit))
+            if floor > configured and not self.__dict__.get("_floor_notice"):
+                self.__dict__["_floor_notice"] = True
+                print(f"BatchedScoreFunction: network calls carry {floor} windows (window_batch_floor; batch_size = {configured} is a lower "
+                      f"bound on this device, C2W_WINDOW_BATCH_FLOOR=0 restores the reference's meaning)", flush=True)
+        return floor
 
     def _side_streams(self, nbatches: int):
         n = min(int(self.num_streams), nbatches)

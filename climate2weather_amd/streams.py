@@ -2,7 +2,7 @@
 
 A HIP stream is bound to one of a few hardware queues when it is created (four per process and priority level on this stack,
 handed out in rotation), and two streams on one queue execute in order: the third, seventh, eleventh ... normal-priority stream
-a process creates shares the default stream's queue (tools/probes/early_item_probe.py: a 4-byte copy on such a stream returns
+a process creates shares the default stream's queue (lab/probes/early_item_probe.py: a 4-byte copy on such a stream returns
 after the 43-ms kernel on the default stream, on every other one after 0.3 ms).  The engine's gradient stream is usually the first
 stream of its process and lands elsewhere by luck; a process that has created streams before (a DDP communicator's pool, a
 sampler's window-batch streams, a test suite) may not be so lucky and would lose the whole two-stream backward without a sign.
@@ -18,9 +18,21 @@ import torch
 _PROBE_CYCLES = 8_000_000  # ~3.4 ms of torch.cuda._sleep on the stream that must NOT hold the candidate up
 
 
-def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None) -> bool:
+def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None, votes: int = 3) -> bool:
     """True if a launch on ``side`` completes while a kernel enqueued earlier on ``main`` (default: the current stream) is still
-    running, i.e. the two streams are on different hardware queues.  Costs one ~3.4-ms spin kernel on ``main``."""
+    running, i.e. the two streams are on different hardware queues.  One sample is one ~3.4-ms spin kernel on ``main``; a host hiccup
+    between the two queries of a sample flips it, so the verdict is the majority of up to ``votes`` samples (two agreeing end it)."""
+    yes = no = 0
+    need = votes // 2 + 1
+    while yes < need and no < need:
+        if _overtakes_once(side, main):
+            yes += 1
+        else:
+            no += 1
+    return yes >= need
+
+
+def _overtakes_once(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None) -> bool:
     main = main or torch.cuda.current_stream(side.device)
     flag = torch.zeros(1, dtype=torch.int32, device=side.device)
     main.synchronize()
@@ -61,6 +73,11 @@ def independent_stream(device, avoid=(), tries: int = 8, priority: int = 0) -> "
             if ok:
                 break
             rejected.append(s)
+        if not ok:
+            import warnings
+            warnings.warn(f"climate2weather_amd: none of {max(1, tries)} new HIP streams runs next to the current one (all share its hardware "
+                          "queue): launches meant to overlap (weight gradients beside input gradients, window batches) will serialise",
+                          RuntimeWarning, stacklevel=2)
         if os.environ.get("C2W_STREAM_DEBUG") == "1":
             print("independent_stream: %d rejected, %d to avoid, verdict %s" % (len(rejected), len(others), ok), flush=True)
         return s

@@ -28,7 +28,7 @@
 // counted vmcnt waits (seen as wrong weight rows at chunk boundaries with 40 spilled registers).
 #include <cstdlib>
 
-#include "conv_epilogue_lab.h"
+#include "conv_epilogue.h"
 
 #ifndef C2W_T3V
 #define C2W_T3V 10  // stage order / LDS-DMA placement / bias placement of conv_patch_t3_kernel (bits: see `stage` below); 10 = measured best

@@ -2,7 +2,7 @@
 // Each lane converts a fresh pair every iteration into a register that holds a marker, writes it to LDS (or global) with the next
 // instruction, reads it back and compares with the software conversion.  A stale read shows up as the marker (or the previous
 // iteration's value) in memory.  Run alone (one wave per SIMD issues back to back) and beside an MFMA-heavy kernel on a second stream.
-//   hipcc --offload-arch=gfx950 -O2 -o cvt_hazard tools/probes/cvt_hazard.hip && ./cvt_hazard
+//   hipcc --offload-arch=gfx950 -O2 -o cvt_hazard lab/probes/cvt_hazard.hip && ./cvt_hazard
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -1,7 +1,7 @@
 // Probe: how fast can the waves of a CU stream an L2-resident table into LDS -- by LDS-DMA (buffer_load ... lds) or through registers
 // (buffer_load_dwordx4 -> ds_write_b128) -- in the access pattern of conv_patch_t3's weight ring (8 waves, one 1 KiB piece per wave and
 // stage, 3 slots, one barrier per stage, two workgroups per CU)?  No MFMAs, no fragment reads: the fill path alone.
-//   hipcc --offload-arch=gfx950 -O3 -o fill_probe tools/probes/fill_probe.hip && ./fill_probe
+//   hipcc --offload-arch=gfx950 -O3 -o fill_probe lab/probes/fill_probe.hip && ./fill_probe
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

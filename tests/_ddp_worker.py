@@ -279,7 +279,7 @@ def run_five_strings_ddp(rank: int, world: int, port: int, golden_dir: str, out_
         optimizer.step()
         losses.append(loss.detach().item())
         ema.update()
-    res = dict(losses=losses, sd={k: v.detach().clone() for k, v in net.state_dict().items()}, flat=bool(optimizer._flat), fused=fused,
+    res = dict(losses=losses, sd={k: v.detach().clone() for k, v in net.state_dict().items()}, flat=optimizer.fused_path_active(), fused=fused,
                ema={k: v.detach().clone() for k, v in ema.emas[0].state_dict().items()})
     if rank == 0:  # single process, whole batch, torch's optimizer, the reference's tensor arithmetic
         torch.manual_seed(3)
@@ -349,7 +349,7 @@ def run_module_ddp_gpu(rank: int, world: int, port: int, out_dir: str):
                 h.remove()
         torch.cuda.synchronize()
         n_par = len(list(net.parameters()))
-        return dict(losses=losses, flat=net._get_engine().flat.detach().clone().cpu(), flat_path=bool(optimizer._flat),
+        return dict(losses=losses, flat=net._get_engine().flat.detach().clone().cpu(), flat_path=optimizer.fused_path_active(),
                     arrivals=arrivals[:n_par], launches=len(launches) // 3, ema=ema.emas[0]._get_engine().flat.detach().clone().cpu())
     res = dict(ddp=loop(True), world=world)
     if world == 1:

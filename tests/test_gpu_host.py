@@ -175,6 +175,25 @@ def test_nan_in_state_raises_on_the_device_path():
     noise[0, 0, 0, 0] = float("nan")
     with pytest.raises(ValueError, match="NaN detected"):
         pipe.sample(sf, noise, steps=2, show_progressbar=False)
+    # ... and it raises where the reference does (src/thor/pipelines.py:90-91: in the step that made the NaN), one step late, not at the
+    # end of the trajectory: the flag is published into pinned host memory behind every step and read one step later, no stream drained
+    calls = []
+
+    class Counting:
+        device_resident, device = True, sf.device
+
+        def __call__(self, x, t):
+            calls.append(float(t))
+            return sf(x, t)
+    for corrections in (0, 1):
+        calls.clear()
+        with pytest.raises(ValueError, match="NaN detected"):
+            pipe.sample(Counting(), noise, steps=64, corrections=corrections, show_progressbar=False)
+        assert len(calls) <= 2 * (1 + corrections), f"raised after {len(calls)} score evaluations of a 64-step run"
+    # a clean run publishes 64 flags and raises nothing
+    calls.clear()
+    out = pipe.sample(Counting(), torch.randn(5, 2, 16, 16), steps=64, show_progressbar=False)
+    assert len(calls) == 64 and bool(torch.isfinite(out).all())
 
 
 # ------------------------------------------------------------------------------------------------ csrc/sampler.hip kernels
@@ -429,7 +448,7 @@ def test_bf16_and_fp16_training_track_fp32_training():
     noise and times injected): losses fall, and the curves stay close to the fp32 one -- fp16 within 2 % (observed +0.2 %, the same
     from run to run), bf16 within 10 %: 60 steps of lr 2e-3 amplify the order of the fp32 atomics behind 8-bit significands, and
     the tail of the bf16 curve lands anywhere between -0.1 % and +4.6 % of the fp32 one from run to run
-    (tools/probes/flake_training_curves.py; a 5 % bound failed once in ten full-suite runs)."""
+    (lab/probes/flake_training_curves.py; a 5 % bound failed once in ten full-suite runs)."""
     cfg = dict(embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1], attention_levels=[1], kernel_size=3, padding_mode="zeros")
     curves = {}
     for prec in ("fp32", "bf16", "fp16"):
@@ -929,7 +948,7 @@ def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_
         # fold against direct module calls on whole batches of the evaluation (first, two middle ones, the ragged last: 8725 = 68 * 128 + 21).
         # With the full output rows scattered (use_center_conv off) every kept frame is bit-equal to the module's; with the centre
         # frames out of c2w_conv_center (the default: only the kept rows are computed, engine.py::_fold_output) they are the same
-        # convolution summed in another order: equal to one rounding step of bf16 (the bound below is 1.5 steps: one step is reached exactly, tools/probes/fold_margins.py), and
+        # convolution summed in another order: equal to one rounding step of bf16 (the bound below is 1.5 steps: one step is reached exactly, lab/probes/fold_margins.py), and
         # bit-equal for all but 0.015 % of the elements.
         for center in (False, True):
             eng.use_center_conv = center

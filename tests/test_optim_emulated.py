@@ -193,6 +193,50 @@ def test_foreign_parameters_and_partial_sets_take_the_per_tensor_path(emu):
         AdamW(lin_a.parameters(), amsgrad=True)
 
 
+def test_gradients_outside_the_flat_buffer_keep_the_fused_step_and_nothing_is_reallocated(emu):
+    """torch DDP with gradient_as_bucket_view=True (or any loop that leaves each ``p.grad`` a tensor of its own) hands the optimizer
+    gradients that do not lie in one flat buffer: they are gathered by one multi-tensor copy and the step stays the fused one.  A step
+    with a MISSING gradient goes per tensor on the same state and the next complete one re-enters the fused path -- the flat moment
+    buffers are never deleted or reallocated (round-4 advice: they were, every step), and the numbers are torch.optim.AdamW's."""
+    pipe = SDAPipeline()
+    pipe.fused_loss = "eps"
+    a, b = _tiny(), _tiny()
+    oa, ob = AdamW(a.parameters(), **HP), torch.optim.AdamW(b.parameters(), **HP)
+    skip_name = next(n for n, _ in a.named_parameters() if n.endswith("proj_out.bias"))
+    ptrs = None
+    for i in range(6):
+        oa.zero_grad()
+        torch.manual_seed(1000 + i)
+        pipe.loss(net=a, x=_batch(i)).mean().backward()
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            g = p.grad.detach().clone()
+            p.grad = g.clone() if i != 0 else p.grad  # from step 1 on: every gradient a foreign tensor ("bucket view")
+            q.grad = g
+            if i == 3 and n == skip_name:  # one step with a missing gradient: torch skips that parameter, so must we
+                p.grad = None
+                q.grad = None
+        oa.step()
+        ob.step()
+        st = oa._flat[0]
+        if ptrs is None:
+            ptrs = (st["m"].data_ptr(), st["v"].data_ptr())
+        assert (st["m"].data_ptr(), st["v"].data_ptr()) == ptrs, f"moment buffers reallocated at step {i}"
+        assert oa.fused_path_active() == (i != 3), f"step {i}"
+        for p in a.parameters():
+            assert oa.state[p]["exp_avg"].untyped_storage().data_ptr() == st["m"].untyped_storage().data_ptr()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        if n == skip_name:  # torch counts steps per parameter (this one is at 5), the fused path per group (6): bias corrections differ
+            assert torch.allclose(p, q, rtol=0, atol=1e-3), n
+            continue
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
+        sa, sb = oa.state[p], ob.state[q]
+        assert _close(sa["exp_avg"], sb["exp_avg"]) and _close(sa["exp_avg_sq"], sb["exp_avg_sq"]), n
+    # the checkpoint reports the group's counter (the reference never skips a parameter: training_loop.py:369-391)
+    sd = oa.state_dict()
+    assert {float(v["step"]) for v in sd["state"].values()} == {6.0}
+    assert oa.steps_taken() == 6
+
+
 def test_fused_loss_is_the_reference_loss_and_any_downstream_use_works(emu):
     """SDAPipeline.loss through the one-node path == the reference's tensor arithmetic (src/thor/pipelines.py:27-35) on the same
     draws: the unreduced tensor, .mean() (answered from the kernel's sum), and every gradient -- also when the caller does something

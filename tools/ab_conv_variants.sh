@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of kernel-variant builds on one box: tools/build_variant.sh <name> -D... first; then (on the GPU box)
+# A/B of kernel-variant builds on one box: lab/build_variant.sh <name> -D... first; then (on the GPU box)
 #   tools/ab_conv_variants.sh default t3v8 t3v9 ...        -> per-variant conv time at the three big levels, twice (noise check)
 cd "$(dirname "$0")/.."
 for rep in 1 2; do

@@ -44,7 +44,7 @@ for name, ac, use_scaler in (("module bf16 autocast", torch.bfloat16, False), ("
             print(f"{name} step {s + 1:4d}: loss {float(torch.stack(losses[-25:]).mean()):.4f}", flush=True)
     fin = all(bool(torch.isfinite(p).all()) for p in net.parameters())
     print(f"{name}: optimizer steps taken {optimizer.steps_taken()} of {N}, loss scale {scaler.get_scale() if scaler else 1:g}, finite {fin}, "
-          f"flat path {bool(optimizer._flat)}")
+          f"flat path {optimizer.fused_path_active()}")
     del net, optimizer, ema, f
 for prec in ("bf16",):
     torch.manual_seed(0)
