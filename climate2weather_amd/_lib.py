@@ -31,7 +31,12 @@ class ConvArgs(Structure):
         ("wrows", c_int32), ("mode", c_int32), ("act", c_int32), ("mulmode", c_int32),
         ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
         ("ln_eps", c_float), ("flags", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p), ("kvalid", c_int32),
+        ("lnf_rstd", c_void_p), ("ln_rstd", c_void_p),
     ]
+
+
+class WgradItem(Structure):  # C2wWgradItem
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("dbias", c_void_p)]
 
 
 # name -> argtypes (every function returns int status except c2w_target)
@@ -46,6 +51,9 @@ _PROTOS = {
     "c2w_upsample2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_conv_wgrad": [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_ulonglong, c_int, c_void_p],
     "c2w_conv_wgrad_workspace_bytes": [POINTER(ConvArgs), c_int],
+    "c2w_conv_wgrad_grouped_supported": [POINTER(ConvArgs), c_int, c_int],
+    "c2w_conv_wgrad_grouped_workspace_bytes": [POINTER(ConvArgs), c_int, c_int],
+    "c2w_conv_wgrad_grouped": [POINTER(ConvArgs), POINTER(WgradItem), c_int, c_void_p, c_ulonglong, c_int, c_void_p],
     "c2w_ln_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "c2w_ln_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_int,
                         c_int, c_void_p],

@@ -189,14 +189,22 @@ struct EpiStore {
     __device__ __forceinline__ void finish_ln(const C2wConvArgs& p, const char* O, int OS, int tid, int img, float* red) {
         LnColSums cs;
         cs.clear();
-        finish_ln_rows(p, O, OS, tid, img, cs);
+        if (p.ln_rstd != nullptr) finish_ln_rows<true>(p, O, OS, tid, img, cs);  // kernel argument: uniform
+        else finish_ln_rows<false>(p, O, OS, tid, img, cs);
         finish_ln_dm(p, tid, img, red, cs);
     }
-    // the rows of one pass; the column sums are carried in `acc` (a tile of several passes reduces them once: finish_ln_dm)
+    // the rows of one pass; the column sums are carried in `acc` (a tile of several passes reduces them once: finish_ln_dm).
+    // STORED: the forward kept the normalised rows and their 1/sigma (C2wConvArgs.ln_rstd) -- a template parameter, because the 16x16-tile
+    // kernel has no registers for both forms in one instantiation (with a uniform branch its LayerNorm-backward kernels spilled 24 registers)
+    template <bool STORED>
     __device__ __forceinline__ void finish_ln_rows(const C2wConvArgs& p, const char* O, int OS, int tid, int img, LnColSums& acc) {
         static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN backward: 16-bit tiles only");
         typedef ln_f2 f2;
         const int cs = tid & (SEGS - 1);
+        if constexpr (STORED) {
+            finish_ln_rows_stored(p, O, OS, tid, acc);
+            return;
+        }
         f2 m2[4];
         if (p.ln_m != nullptr) {
             const float* mr = p.ln_m + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + cs * PER16;
@@ -246,6 +254,55 @@ struct EpiStore {
             for (int k = 0; k < 4; ++k) {
                 o[k] = g[k] * rs - c0;
                 o[k] -= u[k] * c2;
+                am[k] += o[k];
+            }
+            if (p.res != nullptr) {
+                f2 r[4];
+                unpack2(rr[i], r);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += r[k];
+            }
+            u32x4_t out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = pack2<T>(o[k][0], o[k][1]);
+            if (ok(i)) epi_st((char*)p.y + off[i], out);
+        }
+    }
+    // mm[] = the normalised rows the forward kept, ln_rstd their 1/sigma:  rs * (g - mean(g) - xhat * sum(g * xhat) / den)
+    __device__ __forceinline__ void finish_ln_rows_stored(const C2wConvArgs& p, const char* O, int OS, int tid, LnColSums& acc) {
+        typedef ln_f2 f2;
+        const float inv_den = 1.0f / (float)(128 - (p.ln_unbiased ? 1 : 0));
+        f2 (&am)[4] = acc.am;
+        auto unpack2 = [](const u32x4_t& v, f2* f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo, hi;
+                ::unpack2<T>(v[k], lo, hi);
+                f[k] = (f2){lo, hi};
+            }
+        };
+        float rsv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) rsv[i] = p.ln_rstd[ok(i) ? off[i] >> 8 : 0];  // 16 lanes share a pixel row (256 B): one address
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            f2 g[4], xh[4];
+            unpack2(*(const u32x4_t*)lds_seg(O, OS, tid, i), g);
+            unpack2(mm[i], xh);
+            f2 sg2 = (f2){0.f, 0.f}, d2 = (f2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sg2 += g[k];
+                d2 += g[k] * xh[k];
+            }
+            const float rs = rsv[i];
+            const float c0 = sub16(sg2[0] + sg2[1]) * (1.0f / 128.0f) * rs;  // mean(g) / sigma
+            const float c2 = sub16(d2[0] + d2[1]) * inv_den * rs;             // sum(g * xhat) / den / sigma
+            f2 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = g[k] * rs - c0;
+                o[k] -= xh[k] * c2;
                 am[k] += o[k];
             }
             if (p.res != nullptr) {
@@ -337,6 +394,8 @@ struct EpiStore {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ln[k] = pack2<T>(u[k][0] * rs, u[k][1] * rs);
             if (ok(i)) epi_st((char*)p.lnf_y + off[i], ln);
+            // the row's 1/sigma for the backward (ln_rstd): one lane per pixel row (rows are 256 B: pixel = byte offset >> 8)
+            if (p.lnf_rstd != nullptr && cs == 0 && ok(i)) p.lnf_rstd[off[i] >> 8] = rs;
         }
     }
 

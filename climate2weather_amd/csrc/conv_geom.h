@@ -52,3 +52,7 @@ bool c2w_wgrad_patch_pair(const C2wConvArgs& a);  // 8-pixel-wide images: two pe
 // ws / ws_bytes: the caller's scratch buffer for the split-K partial sums (NULL / too small: fp32 atomics)
 int c2w_wgrad_patch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_bytes, int dtype, hipStream_t st);
 size_t c2w_wgrad_patch_ws_bytes(const C2wConvArgs& a, int dtype);
+// the weight gradients of n layers of one geometry as one launch (wgrad_patch.hip)
+bool c2w_wgrad_patch_group_eligible(const C2wConvArgs& a, int n, int dtype);
+int c2w_wgrad_patch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* ws, size_t ws_bytes, int dtype, hipStream_t st);
+size_t c2w_wgrad_patch_group_ws_bytes(const C2wConvArgs& a, int n, int dtype);

@@ -425,6 +425,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     hipStream_t st = (hipStream_t)stream;
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
+    if ((a->ln_rstd != nullptr && a->ln_x == nullptr) || (a->lnf_rstd != nullptr && a->lnf_y == nullptr)) return C2W_ERR_BAD_ARG;  // statistics of a LayerNorm that is not fused
     if ((a->flags & C2W_CONV_POOL2) != 0 && (naive != 0 || !c2w_conv_pool2_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if ((a->flags & C2W_CONV_WPACKED) != 0 && (naive != 0 || !c2w_conv_wpacked_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no other kernel reads that layout
     const bool patch = naive == 0 && !c2w_knobs().force_gather;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // 130).  Neither a spill nor a 129th register can ship: climate2weather_amd/build.py refuses to link this translation unit if any
     // kernel with hand-counted vmcnt waits uses scratch or if a conv_patch_t3 instantiation exceeds 128 VGPRs (isa_checks.py).
     auto offA_at = [&]() {
-        if constexpr (!(WPK && EPI == 3)) return offA_held;  // packed LayerNorm backward: recomputed per stage (held, it spills 2 registers)
+        if constexpr (!(WPK && (EPI == 3 || EPI == 6))) return offA_held;  // packed LayerNorm backward: recomputed per stage (held, it spills 2 registers)
         int l = lane;
         asm volatile("" : "+v"(l));
         const int li_ = l & 15;
@@ -329,21 +329,22 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // runs behind the first block's arithmetic and stores (the accumulators have left the registers, so both sets fit)
     if constexpr (CF::NPASS == 2 && EPI != 0) {  // the per-family instantiations; in the all-in-one kernel (EPI = 0) this spills 54 registers
         EpiStore<T, 128, T3_NTHR> est0, est1;
-        if (EPI == 3 && tid_e < 128) red[tid_e] = 0.f;
+        if ((EPI == 3 || EPI == 6) && tid_e < 128) red[tid_e] = 0.f;
         est0.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0) * W + ow0, W);
         est1.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8) * W + ow0, W);
         __syncthreads();
         typename EpiStore<T, 128, T3_NTHR>::LnColSums dmsum;  // LayerNorm backward: modulation-gradient column sums, carried over both blocks
-        if constexpr (EPI == 3) dmsum.clear();
+        if constexpr (EPI == 3 || EPI == 6) dmsum.clear();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             auto& est = h == 0 ? est0 : est1;
             const char* const Oh = O + h * 128 * T3_OS;
             if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
-            else if constexpr (EPI == 3) est.finish_ln_rows(p, Oh, T3_OS, tid_e, b, dmsum);
+            else if constexpr (EPI == 3) est.template finish_ln_rows<false>(p, Oh, T3_OS, tid_e, b, dmsum);
+            else if constexpr (EPI == 6) est.template finish_ln_rows<true>(p, Oh, T3_OS, tid_e, b, dmsum);
             else est.finish(p, Oh, T3_OS, tid_e);
         }
-        if constexpr (EPI == 3) est0.finish_ln_dm(p, tid_e, b, red, dmsum);  // one reduction per tile (was: per block, with two more barriers between)
+        if constexpr (EPI == 3 || EPI == 6) est0.finish_ln_dm(p, tid_e, b, red, dmsum);  // one reduction per tile (was: per block, with two more barriers between)
     } else {
 #pragma unroll
         for (int h = 0; h < CF::NPASS; ++h) {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         const char* const Oh = O + h * 128 * T3_OS;
         // EPI 2 / 3 / 4: instantiations that carry one epilogue only (picked by the launcher)
         if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
-        else if constexpr (EPI == 3) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
+        else if constexpr (EPI == 3 || EPI == 6) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
         else if constexpr (EPI == 4) est.finish(p, Oh, T3_OS, tid_e);
         else if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
         else if (p.ln_x != nullptr) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
@@ -388,7 +389,7 @@ template <int TR, typename T, int NW>
 int t3_launch(const C2wConvArgs& a, hipStream_t st) {
     if (TR == 16 && (a.flags & C2W_CONV_POOL2) == 0) {
         if (a.lnf_y != nullptr) return t3_launch_as<16, T, NW, 2>(a, st);
-        if (a.ln_x != nullptr) return t3_launch_as<16, T, NW, 3>(a, st);
+        if (a.ln_x != nullptr) return a.ln_rstd != nullptr ? t3_launch_as<16, T, NW, 6>(a, st) : t3_launch_as<16, T, NW, 3>(a, st);
         if (a.wrows <= 80 && a.Cout <= 128 && c2w_knobs().wgrad_narrow) return t3_launch_as<16, T, NW, 5>(a, st);  // the output conv: 65 weight rows
         return t3_launch_as<16, T, NW, 4>(a, st);
     }

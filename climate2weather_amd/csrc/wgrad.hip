@@ -438,6 +438,29 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, voi
     return launch_dtype<f16_t>(*a, dw, dbias, ws, wsb, st);
 }
 
+extern "C" int c2w_conv_wgrad_grouped_supported(const C2wConvArgs* a, int n, int dtype) {
+    if (wgrad_check(a, dtype) != 0) return 0;
+    return c2w_wgrad_patch_group_eligible(*a, n, dtype) && !c2w_knobs().force_gather ? 1 : 0;
+}
+
+extern "C" long long c2w_conv_wgrad_grouped_workspace_bytes(const C2wConvArgs* a, int n, int dtype) {
+    const int rc = wgrad_check(a, dtype);
+    if (rc != 0) return rc;
+    if (!c2w_conv_wgrad_grouped_supported(a, n, dtype)) return C2W_ERR_UNSUPPORTED;
+    return (long long)c2w_wgrad_patch_group_ws_bytes(*a, n, dtype);
+}
+
+extern "C" int c2w_conv_wgrad_grouped(const C2wConvArgs* a, const C2wWgradItem* items, int n, void* workspace, unsigned long long workspace_bytes,
+                                      int dtype, void* stream) {
+    const int rc = wgrad_check(a, dtype);
+    if (rc != 0) return rc;
+    if (items == nullptr || n < 1) return C2W_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i)
+        if (items[i].x == nullptr || items[i].dy == nullptr || items[i].dw == nullptr) return C2W_ERR_BAD_ARG;
+    if (!c2w_conv_wgrad_grouped_supported(a, n, dtype)) return C2W_ERR_UNSUPPORTED;
+    return c2w_wgrad_patch_group(*a, items, n, (float*)workspace, workspace == nullptr ? 0 : (size_t)workspace_bytes, dtype, (hipStream_t)stream);
+}
+
 extern "C" int c2w_conv_wgrad_dispatch(const C2wConvArgs* a, int dtype) {
     const int rc = wgrad_check(a, dtype);
     if (rc != 0) return rc;

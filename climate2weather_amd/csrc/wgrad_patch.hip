@@ -56,6 +56,27 @@ struct WpArgs {
     int up;                       // C2W_CONV_UP: X is the (H/2) x (W/2) source map of a nearest-neighbour x2 upsampling (patch pixel >> 1)
     int ktiles, ktiles_per_split;
     float* ws;  // optional workspace [split][tile][tap][COT][CIB] fp32: partial sums by plain stores, reduced by a second launch
+    int direct;  // no split (one workgroup per output tile): the tile is added onto dw by plain read-modify-write stores, no atomics
+};
+
+// Grouped launch: the weight gradients of up to WP_MAX_ITEMS layers of ONE geometry (the residual-block convs of a level: their output
+// gradients exist one after the other during the backward pass, their weight gradients are independent) as one grid.  A launch per layer
+// splits K over 256 / tilesMN workgroups to fill the chip (8 K tiles per workgroup at 8x8, each followed by 295 KB of partial sums);
+// together the layers fill it with a fraction of the splits.  The per-layer pointers ride in the kernel arguments and are read through the
+// kernarg segment with a workgroup-uniform index (scalar loads; a by-value array indexed dynamically would be copied to scratch).
+struct WpItem {
+    const void* dy;
+    const void* x;
+    float* dw;
+    float* db;
+};
+constexpr int WP_MAX_ITEMS = 16;
+struct WpGroupArgs {
+    WpArgs c;             // geometry, split plan, ws = base of the group's workspace; dy / x / dw / db unused
+    int n;                // layers
+    int blocks_per_item;  // tilesMN * nsplit rounded up to a multiple of 8 (so that blockIdx & 7 labels the XCD inside every layer's range too)
+    unsigned long long ws_item_floats;
+    WpItem item[WP_MAX_ITEMS];
 };
 
 
@@ -77,7 +98,7 @@ __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 
 // instead of even / odd waves -- every SIMD hosts one wave of each -- and waves 4-7 compute only their first co tile (channels 64-79):
 // 45 instead of 72 MFMAs per SIMD and K step; the dY rows past Cout were never fetched anyway (out-of-range lanes of the LDS-DMA).
 template <typename T, bool PAIR = false, bool NARROW = false>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p) {
+__device__ __forceinline__ void wgrad_patch_body(const WpArgs& p, const int bid, const int nblk) {
     constexpr int ESZ = sizeof(T);
     constexpr bool BF = ESZ == 2;
     constexpr int COT = 256 / ESZ;       // output channels per workgroup tile
@@ -98,7 +119,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     const int tilesMN = tilesM * ncib;
     int L;
     {
-        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int split = L / tilesMN, mn = L - split * tilesMN;
@@ -384,6 +405,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
         if (p.ws != nullptr) {  // partial sums: coalesced stores, no atomics (75 MB of atomics per launch otherwise)
             float* const dst = p.ws + (((size_t)split * tilesMN + mn) * 9 + tp) * (COT * CIB);
             for (int idx = tid; idx < COT * CIB; idx += NTHREADS) dst[idx] = O[(idx / CIB) * OS + (idx % CIB)];
+        } else if (p.direct) {  // this workgroup alone owns the tile (no split): launches on a stream are ordered, nobody else adds here
+            for (int idx = tid; idx < COT * CIB; idx += NTHREADS) {
+                const int row = idx / CIB, col = idx - row * CIB;
+                const int co = co0 + row;
+                if (co < p.Cout) {
+                    float* const d = p.dw + ((size_t)co * 9 + tp) * p.Cin + ci0 + col;
+                    *d = *d + O[row * OS + col];
+                }
+            }
         } else {
             for (int idx = tid; idx < COT * CIB; idx += NTHREADS) {
                 const int row = idx / CIB, col = idx - row * CIB;
@@ -394,6 +424,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
     }
 }
 
+template <typename T, bool PAIR = false, bool NARROW = false>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p) {
+    wgrad_patch_body<T, PAIR, NARROW>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+typedef __attribute__((address_space(4))) const char wp_kernarg_t;
+__device__ __forceinline__ WpItem wp_item(int it) {  // it: workgroup-uniform
+    const WpItem __attribute__((address_space(4)))* tab =
+        (const WpItem __attribute__((address_space(4)))*)((wp_kernarg_t*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WpGroupArgs, item));
+    WpItem r;
+    r.dy = tab[it].dy;
+    r.x = tab[it].x;
+    r.dw = tab[it].dw;
+    r.db = tab[it].db;
+    return r;
+}
+
+template <typename T, bool PAIR = false>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_group_kernel(const WpGroupArgs g) {
+    const int it = __builtin_amdgcn_readfirstlane((int)blockIdx.x / g.blocks_per_item);
+    const int bid = (int)blockIdx.x - it * g.blocks_per_item;
+    const WpItem e = wp_item(it);
+    WpArgs p = g.c;
+    p.dy = e.dy;
+    p.x = e.x;
+    p.dw = e.dw;
+    p.db = e.db;
+    p.ws = g.c.ws != nullptr ? g.c.ws + (size_t)it * g.ws_item_floats : nullptr;
+    wgrad_patch_body<T, PAIR, false>(p, bid, g.blocks_per_item);
+}
+
 // dw[co][tap][ci] += sum over splits of ws[split][tile][tap][row][col].  RC float4 columns x RG split groups per block (RC * RG =
 // 256 threads): every thread streams 1/RG of the splits with 16-B loads (8 in flight), the groups meet in LDS, group 0 updates dw
 // (no atomics: one thread per output vector, launches on a stream are ordered).  Block shapes 16 x 16, 32 x 8 and 64 x 4 (576 to
@@ -402,8 +463,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p
 #define C2W_RED_COLS 64
 #endif
 template <int COT, int CIB>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesMN, int ncib,
-                                                           int Cin, int Cout) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesMN, int ncib,
+                                                  int Cin, int Cout) {
     constexpr int RC = C2W_RED_COLS, RG = 256 / RC;
     __shared__ f32x4_t red[RG][RC];
     const size_t per4 = (size_t)tilesMN * 9 * COT * CIB / 4;  // float4 vectors per split
@@ -437,6 +498,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         __syncthreads();
     }
+}
+
+template <int COT, int CIB>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesMN, int ncib,
+                                                           int Cin, int Cout) {
+    wgrad_reduce_body<COT, CIB>(ws, dw, nsplit, tilesMN, ncib, Cin, Cout);
+}
+// the same for every layer of a grouped launch: blockIdx.y = layer
+template <int COT, int CIB>
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const WpGroupArgs g, int nsplit, int tilesMN, int ncib) {
+    const int it = (int)blockIdx.y;
+    const WpItem e = wp_item(it);
+    wgrad_reduce_body<COT, CIB>(g.c.ws + (size_t)it * g.ws_item_floats, e.dw, nsplit, tilesMN, ncib, g.c.Cin, g.c.Cout);
 }
 
 // split of the K (pixel-tile) range over workgroups: one resident workgroup per CU and ONE round: tilesMN * nsplit <= 256 (rounding
@@ -479,6 +553,7 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
     }
     const size_t need = (size_t)nsplit * tilesMN * 9 * COT * CIB * sizeof(float);
     p.ws = (ws != nullptr && need <= ws_bytes && nsplit > 1 && !c2w_knobs().wgrad_atomics) ? ws : nullptr;
+    p.direct = nsplit == 1 && !c2w_knobs().wgrad_atomics ? 1 : 0;
     wgrad_patch_kernel<T, PAIR, NARROW><<<tilesMN * nsplit, NTHREADS, LDS_BYTES, st>>>(p);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
@@ -488,7 +563,103 @@ int launch(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t ws_byte
     return (int)hipGetLastError();
 }
 
+// ---- grouped launches.  Split plan for n layers of one geometry (T = n * tilesMN output tiles, each `ktiles` K tiles deep): the number
+// of splits that minimises  rounds x (K tiles per workgroup x t_k + t_fixed) + reduction launch  over 1 ... 4 rounds of 256 workgroups,
+// with t_k = 4.1 us per K tile at the clock the chip holds under this kernel and t_fixed = 16 us (prologue + a 295-KB tile added onto dw)
+// or 28 us (partial sums stored and read again) -- the two constants reproduce the per-layer launches of the default network within 10 %
+// (71 / 116 / 169 / 169 / 563 us predicted at the 8x8 ... 128x128 levels against 68 / 105 / 153 / 162 / 568 measured, round 4).
+static void group_plan(int n, int tilesMN, int ktiles, int& nsplit, int& ktiles_per_split) {
+    const int T = n * tilesMN;
+    double best = 1e30;
+    nsplit = 1;
+    for (int r = 0; r <= 4; ++r) {  // r = 0: no split at all, whatever the number of rounds
+        int ns = r == 0 ? 1 : (256 * r) / T;
+        if (ns < 1) ns = 1;
+        if (ns > ktiles) ns = ktiles;
+        const int per = (ktiles + ns - 1) / ns;
+        ns = (ktiles + per - 1) / per;
+        const int rounds = (T * ns + 255) / 256;
+        const double cost = rounds * (per * 4.1 + (ns > 1 ? 28.0 : 16.0)) + (ns > 1 ? 10.0 : 0.0);
+        if (cost < best - 1e-9) {
+            best = cost;
+            nsplit = ns;
+        }
+    }
+    ktiles_per_split = (ktiles + nsplit - 1) / nsplit;
+}
+
+template <int ESZ, bool PAIR>
+static size_t group_ws_need(const C2wConvArgs& a, int n) {
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    int ktiles, tilesMN, ns1, per1, nsplit, per;
+    split_plan<ESZ, PAIR>(a, ktiles, tilesMN, ns1, per1);
+    group_plan(n, tilesMN, ktiles, nsplit, per);
+    return nsplit > 1 ? (size_t)n * nsplit * tilesMN * 9 * COT * CIB * sizeof(float) : 0;
+}
+
+template <typename T, bool PAIR>
+int launch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    WpGroupArgs g;
+    WpArgs& p = g.c;
+    p.dy = nullptr; p.x = nullptr; p.dw = nullptr; p.db = nullptr;
+    p.B = a.B; p.H = a.Hout; p.W = a.Wout; p.Cin = a.Cin; p.Cout = a.Cout; p.ldy = a.ldy;
+    p.up = a.mode == C2W_CONV_UP ? 1 : 0;
+    int tilesMN, ns1, per1, nsplit;
+    split_plan<ESZ, PAIR>(a, p.ktiles, tilesMN, ns1, per1);
+    group_plan(n, tilesMN, p.ktiles, nsplit, p.ktiles_per_split);
+    const size_t item_floats = (size_t)nsplit * tilesMN * 9 * COT * CIB;
+    if (nsplit > 1 && (ws == nullptr || (size_t)n * item_floats * sizeof(float) > ws_bytes)) return C2W_ERR_BAD_ARG;  // the caller sized it with c2w_conv_wgrad_grouped_workspace_bytes
+    p.ws = nsplit > 1 ? ws : nullptr;
+    p.direct = nsplit == 1 ? 1 : 0;
+    g.n = n;
+    g.blocks_per_item = (tilesMN * nsplit + 7) & ~7;
+    g.ws_item_floats = item_floats;
+    for (int i = 0; i < WP_MAX_ITEMS; ++i) {
+        const C2wWgradItem& e = items[i < n ? i : n - 1];
+        g.item[i].dy = e.dy; g.item[i].x = e.x; g.item[i].dw = e.dw; g.item[i].db = e.dbias;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_group_kernel<T, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    wgrad_patch_group_kernel<T, PAIR><<<g.blocks_per_item * n, NTHREADS, LDS_BYTES, st>>>(g);
+    if (p.ws != nullptr) {
+        const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
+        const int grid = (int)std::min<size_t>((per_split / 4 + C2W_RED_COLS - 1) / C2W_RED_COLS, 8192);
+        wgrad_reduce_group_kernel<COT, CIB><<<dim3(grid, n), 256, 0, st>>>(g, nsplit, tilesMN, a.Cin / CIB);
+    }
+    return (int)hipGetLastError();
+}
+
 }  // namespace
+
+// One grouped launch serves these layers: halo-patch geometry, 2 ... WP_MAX_ITEMS of them, not the narrow-M form of the output conv
+bool c2w_wgrad_patch_group_eligible(const C2wConvArgs& a, int n, int dtype) {
+    const bool narrow = dtype != C2W_DTYPE_F32 && !c2w_wgrad_patch_pair(a) && a.Cout <= 80 && c2w_knobs().wgrad_narrow;  // c2w_wgrad_patch's rule
+    return c2w_wgrad_patch_eligible(a) && n >= 2 && n <= WP_MAX_ITEMS && !narrow && !c2w_knobs().wgrad_atomics;
+}
+
+int c2w_wgrad_patch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* ws, size_t ws_bytes, int dtype, hipStream_t st) {
+    if (c2w_wgrad_patch_pair(a)) {
+        if (dtype == C2W_DTYPE_F32) return launch_group<float, true>(a, items, n, ws, ws_bytes, st);
+        if (dtype == C2W_DTYPE_BF16) return launch_group<bf16_t, true>(a, items, n, ws, ws_bytes, st);
+        if (dtype == C2W_DTYPE_F16) return launch_group<f16_t, true>(a, items, n, ws, ws_bytes, st);
+        return C2W_ERR_BAD_ARG;
+    }
+    if (dtype == C2W_DTYPE_F32) return launch_group<float, false>(a, items, n, ws, ws_bytes, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_group<bf16_t, false>(a, items, n, ws, ws_bytes, st);
+    if (dtype == C2W_DTYPE_F16) return launch_group<f16_t, false>(a, items, n, ws, ws_bytes, st);
+    return C2W_ERR_BAD_ARG;
+}
+
+size_t c2w_wgrad_patch_group_ws_bytes(const C2wConvArgs& a, int n, int dtype) {
+    const bool pair = c2w_wgrad_patch_pair(a);
+    if (dtype == C2W_DTYPE_F32) return pair ? group_ws_need<4, true>(a, n) : group_ws_need<4, false>(a, n);
+    return pair ? group_ws_need<2, true>(a, n) : group_ws_need<2, false>(a, n);
+}
 
 bool c2w_wgrad_patch_pair(const C2wConvArgs& a) {  // 8-pixel-wide images: two per K tile
     return c2w_knobs().conv_pair && a.mode == C2W_CONV_S1 && a.Win == 8 && a.Hin == 8;

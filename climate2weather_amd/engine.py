@@ -229,6 +229,20 @@ class Engine:
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
         self._wgrad_behind = os.environ.get("C2W_WGRAD_BEHIND") == "1"  # A/B knob: weight gradients one layer behind
         self._wg_pending = None
+        # Weight gradients of the residual-block convs are collected per geometry during the backward and launched together at the
+        # level boundaries (ops.conv_wgrad_grouped: the 6 or 12 layers of a level side share one shape).  C2W_WGRAD_GROUP=0: one
+        # launch per layer (rounds 1-4); =N: only levels whose grid is at most N pixels high (default 64); =1: every level.
+        # Measured at B = 128 (profiles/r05_experiments.md): 64 and 0 give the same step (48.2 ms) -- below 128x128 the per-layer
+        # launches were hidden beside the other stream's launches, the grouped ones need a third of the launches and of the partial
+        # sums; at 128x128 a group is 252 workgroups that hold their CUs (160 KB of LDS each) for 3 ms and starve the input-gradient
+        # stream: +3.0 ms per step.
+        self.keep_ln_stats = os.environ.get("C2W_NO_LN_STATS") != "1"  # A/B knob: fused LayerNorms hand their 1/sigma to the backward
+        _grp = os.environ.get("C2W_WGRAD_GROUP", "64")
+        self.group_wgrads = _grp != "0"
+        self.group_wgrads_max_side = int(_grp) if _grp.isdigit() and int(_grp) > 1 else 1 << 30
+        self._wg_groups: Dict[tuple, list] = {}  # (geometry, dtype) -> [(x, dY, record, geometry)] not launched yet
+        self._wg_group_ok: Dict[tuple, bool] = {}
+        self._done_release = None  # set by backward_steps: hands on the "done" offsets held back while a group was pending
         self._pub = None  # ops.HostRing of published scalars (publish / published)
         self._skip_dw = False  # inside backward(want_dw=False): weight-gradient launches are skipped
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
@@ -569,6 +583,7 @@ class Engine:
 
     def join_grad_stream(self) -> None:
         """Make the current stream wait for every gradient launch enqueued so far."""
+        self.flush_wgrad_groups()
         side = self.grad_stream()
         if side is not None:
             if self._wg_pending is not None:
@@ -576,23 +591,61 @@ class Engine:
                 self._issue_on(side, *pending)
             torch.cuda.current_stream().wait_stream(side)
 
-    def workspace(self) -> Optional[torch.Tensor]:
+    def workspace(self, min_bytes: int = 0) -> Optional[torch.Tensor]:
         """Split-K scratch for a weight-gradient launch on torch's CURRENT stream.  One buffer per (engine, stream): launches on one
         stream are ordered, so they can share it; two engines, or one engine's backward on two streams (training on the gradient
-        stream next to an exact-guidance backward elsewhere), never see each other's partial sums."""
+        stream next to an exact-guidance backward elsewhere), never see each other's partial sums.  ``min_bytes``: a grouped launch's
+        need (ops.conv_wgrad_grouped_workspace_bytes); a larger buffer replaces the stream's (the old one is freed behind the launches
+        that used it: same stream)."""
         if self.flat is None or not self.flat.is_cuda:
             return None
         key = torch.cuda.current_stream(self.flat.device).cuda_stream
         ws = self._ws.get(key)
-        if ws is None or ws.device != self.flat.device:
-            ws = self._ws[key] = ops.new_workspace(self.flat.device)
+        if ws is None or ws.device != self.flat.device or ws.numel() * 4 < min_bytes:
+            ws = self._ws[key] = ops.new_workspace(self.flat.device, max(ops.WORKSPACE_BYTES, (min_bytes + (1 << 20) - 1) >> 20 << 20))
         return ws
 
-    def _wg(self, x: torch.Tensor, gy: torch.Tensor, rec: ConvRec, g: dict, dt: int) -> None:
-        """dW, dbias of ``rec`` (dense operand) into the flat gradient buffer, on the gradient stream."""
+    def _wg(self, x: torch.Tensor, gy: torch.Tensor, rec: ConvRec, g: dict, dt: int, group: bool = False) -> None:
+        """dW, dbias of ``rec`` (dense operand) into the flat gradient buffer, on the gradient stream.  ``group``: the layer is one of
+        several with this geometry whose output gradients appear one after the other (the residual-block convs of a level side): it is
+        queued and launched with the others at the next flush_wgrad_groups()."""
         if self._skip_dw:
             return
+        if group and self.group_wgrads and g["Hout"] <= self.group_wgrads_max_side:
+            key = (g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"], g["mode"], dt, ops.KNOBS_GENERATION)
+            ok = self._wg_group_ok.get(key)
+            if ok is None:
+                ok = self._wg_group_ok[key] = bool(ops.conv_wgrad_grouped_supported(g, 2, dt))
+            if ok:
+                lst = self._wg_groups.setdefault(key, [])
+                lst.append((x, gy, rec, g))
+                if len(lst) >= 16:
+                    self._flush_group(key)
+                return
         self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
+
+    def _flush_group(self, key: tuple) -> None:
+        lst = self._wg_groups.pop(key, None)
+        if not lst:
+            return
+        g, dt = lst[0][3], key[9]
+        if len(lst) == 1 or not ops.conv_wgrad_grouped_supported(g, len(lst), dt):
+            for x, gy, rec, gi in lst:
+                self._on_grad_stream(lambda x=x, gy=gy, rec=rec, gi=gi: ops.conv_wgrad(x, gy, self._gw(rec), gi, dt, dbias=self._gb(rec),
+                                                                                    workspace=self.workspace()), x, gy)
+            return
+
+        def run():
+            ws = self.workspace(ops.conv_wgrad_grouped_workspace_bytes(g, len(lst), dt))
+            ops.conv_wgrad_grouped([(x, gy, self._gw(rec), self._gb(rec)) for x, gy, rec, _ in lst], g, dt, workspace=ws)
+        self._on_grad_stream(run, *[t for x, gy, _, _ in lst for t in (x, gy)])
+
+    def flush_wgrad_groups(self) -> None:
+        """Launch every queued weight gradient (one launch per geometry) and hand on the "done" offsets that were held back for them."""
+        for key in list(self._wg_groups):
+            self._flush_group(key)
+        if self._done_release is not None:
+            self._done_release()
 
     def _wgrad(self, rec: ConvRec, x: torch.Tensor, gy: torch.Tensor, g: dict, dt: int) -> None:
         """dW (+ dbias) of ``rec`` into the flat gradient buffer; a padded-operand layer goes through a padded scratch."""
@@ -769,6 +822,10 @@ class Engine:
             if want_ln is not None and act == ACT_NONE and y2 is None and ops.conv_lnfwd_supported(g, dt):
                 hn = torch.empty_like(y)
                 lnf = dict(y=hn, m=want_ln[1], ldm=ldm if want_ln[1] is not None else 0, eps=LN_EPS, unbiased=self.ln_unbiased)
+                if train and self.keep_ln_stats and want_ln[0] == "mod":
+                    # training: the epilogue also leaves every pixel row's 1/sigma; the block's backward then takes its LayerNorm
+                    # statistics from here and the normalised rows (kept anyway: conv1's input) instead of recomputing both (res_block)
+                    lnf["rstd"] = hn._c2w_rstd = torch.empty((B * Ho * Wo,), dtype=torch.float32, device=dev)
             # padded operand (network input at C = 65: rows of 128 channels): channels >= rec.cin are zero in x and in w -- a promise the
             # 16x16-tile kernel turns into fewer K steps
             wop, wpk = self._conv_weights("f", rec, dt, g)
@@ -803,6 +860,7 @@ class Engine:
             Cc = b.channels
             npix = B * Hc * Wc
             m = m_all.view(-1)[b.mod_offset:]
+            rstd0 = getattr(h0, "_c2w_rstd", None) if h0 is not None else None
             if h0 is None:
                 h0 = torch.empty((npix, Cc), dtype=T, device=dev)
                 ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
@@ -818,14 +876,17 @@ class Engine:
                 (out, g2, r2), hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin), None
             if train:
                 def bw(gy):
-                    self._wg(h1, gy, r2, g2, dt)
+                    self._wg(h1, gy, r2, g2, dt, group=True)
                     da1 = dgrad(r2, gy, Hc, Wc, Hc, Wc, CONV_S1, Cc, mul=d1, mulmode=mulmode)
-                    self._wg(h0, da1, r1, g1, dt)
+                    self._wg(h0, da1, r1, g1, dt, group=True)
                     dm = dm_all.view(-1)[b.mod_offset:]
                     # conv1's input gradient feeds LN's backward directly: fused into the conv epilogue where the kernel
                     # holds whole channel rows (128-channel levels in bf16), a separate pass otherwise
-                    dx = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc, res=gy,
-                               ln=dict(x=xin, m=m, dm=dm, ldm=ldm, eps=LN_EPS, unbiased=self.ln_unbiased))
+                    if rstd0 is not None:  # the producer's epilogue kept the statistics: h0 = the normalised rows, rstd0 their 1/sigma
+                        lnb = dict(x=h0, rstd=rstd0, m=None, dm=dm, ldm=ldm, eps=LN_EPS, unbiased=self.ln_unbiased)
+                    else:
+                        lnb = dict(x=xin, m=m, dm=dm, ldm=ldm, eps=LN_EPS, unbiased=self.ln_unbiased)
+                    dx = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc, res=gy, ln=lnb)
                     if dx is None:
                         dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                         dx = torch.empty_like(dh0)
@@ -886,6 +947,7 @@ class Engine:
             (cur, g_h0, r_h0), hn0 = conv3("unet." + lv0.head_key, x0, H, W, H, W, CONV_S1), None
         if train:
             def bw_head0(gy, x0=x0, g=g_h0, rec=r_h0):
+                self.flush_wgrad_groups()
                 self._wgrad(rec, x0, gy, g, dt)
                 dx0 = dgrad(rec, gy, H, W, H, W, CONV_S1, lay.cin_pad) if want_dx else None
                 tape.done(rec.w_off)
@@ -914,6 +976,7 @@ class Engine:
                 cur, g_h, r_h = conv3("unet." + lv.head_key, xin, Hp, Wp, Hc, Wc, CONV_S2)
                 if train:
                     def bw_head(gy, xin=xin, g=g_h, rec=r_h, Hp=Hp, Wp=Wp, Hc=Hc, Wc=Wc, lvl=i - 1):
+                        self.flush_wgrad_groups()  # the level below is complete: its residual-block weight gradients go out together
                         self._wg(xin, gy, rec, g, dt)
                         # dx of the stride-2 conv + the gradient that arrived through the skip connection (model/nn.py:238)
                         dxs = dgrad(rec, gy, Hc, Wc, Hp, Wp, CONV_TS2, rec.cin, res=tape.gskip.pop(lvl))
@@ -951,6 +1014,7 @@ class Engine:
                     cur, g_t, r_t = conv3("unet." + lv.tail_key, hl, Hl, Wl, Hc, Wc, CONV_UP, res=skips.pop())
                 if train:
                     def bw_tail(gy, xin=xin, hl=hl, g=g_t, rec=r_t, Hl=Hl, Wl=Wl, Hu=Hc, Wu=Wc, Cc=Cc, lvl=i - 1):
+                        self.flush_wgrad_groups()  # the ascent side of the level above is complete
                         tape.gskip[lvl] = gy  # the skip operand receives the same gradient
                         self._wg(hl, gy, rec, g, dt)
                         # gradient w.r.t. the low-resolution map = 2x2 sums of the gradient w.r.t. its upsampling (adjoint of Upsample):
@@ -1087,12 +1151,26 @@ class Engine:
         soon as its gradients have been delivered).  The generator's return value is dx (or None)."""
         low = [self.layout.numel]
         outer = tape.progress
+        held = [None]
 
-        def progress(off: int) -> None:
+        def emit(off: int) -> None:
             low[0] = min(low[0], off)
             if outer is not None:
                 outer(off)
+
+        def progress(off: int) -> None:
+            if self._wg_groups:  # a weight gradient at or above ``off`` is still queued (grouped launches): not final yet
+                held[0] = off if held[0] is None else min(held[0], off)
+                return
+            emit(off)
+
+        def release() -> None:
+            if held[0] is not None and not self._wg_groups:
+                off, held[0] = held[0], None
+                emit(off)
         tape.progress = progress
+        self._done_release = release
+        self._wg_groups.clear()  # (a backward that raised half-way may have left some behind)
         if self._dg_ready is not None:  # operands prefetched on the gradient stream: this stream reads them from here on
             torch.cuda.current_stream().wait_event(self._dg_ready)
             self._dg_ready = None
@@ -1110,6 +1188,7 @@ class Engine:
             g = bw(g)
             yield low[0]
         dx0 = g
+        self.flush_wgrad_groups()
         # modulation path: dm_all -> proj -> map_layer1 -> map_layer0 (parameter gradients only: t carries none)
         if want_dw:
             gm = tape.meta["dm_all"]
@@ -1117,6 +1196,7 @@ class Engine:
                 gm = bw(gm)
                 yield low[0]
         self.join_grad_stream()  # every gradient is in flat_grad for whoever runs next on this stream (optimizer, autograd)
+        self._done_release = None
         tape.steps = []
         tape.gskip.clear()
         tape.progress = outer

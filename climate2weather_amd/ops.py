@@ -41,8 +41,10 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
     if ln is not None:
         a.ln_x, a.ln_m, a.ln_dm = _p(ln["x"]), _p(ln.get("m")), _p(ln.get("dm"))
         a.ln_ldm, a.ln_unbiased, a.ln_eps = int(ln.get("ldm", 0)), int(ln["unbiased"]), float(ln["eps"])
+        a.ln_rstd = _p(ln.get("rstd"))  # with it, ln["x"] holds the normalised rows the forward kept (c2w_hip.h)
     if lnf is not None:
         a.lnf_y, a.lnf_m = _p(lnf["y"]), _p(lnf.get("m"))
+        a.lnf_rstd = _p(lnf.get("rstd"))
         a.ln_ldm, a.ln_unbiased, a.ln_eps = int(lnf.get("ldm", 0)), int(lnf["unbiased"]), float(lnf["eps"])
     return a
 
@@ -50,10 +52,11 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
          ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
-    ln = dict(x, m, dm, ldm, eps, unbiased): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
-    dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.
-    lnf = dict(y, m, ldm, eps, unbiased): also write y = LN(result + m), the consumer block's normalised input -- only where
-    conv_lnfwd_supported(g, dtype) says so."""
+    ln = dict(x, m, dm, ldm, eps, unbiased[, rstd]): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
+    dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.  With ``rstd`` (what the forward's lnf kept), ``x`` holds the
+    NORMALISED rows and ``m`` is not read.
+    lnf = dict(y, m, ldm, eps, unbiased[, rstd]): also write y = LN(result + m), the consumer block's normalised input (and, with
+    ``rstd``, every pixel row's 1/sigma) -- only where conv_lnfwd_supported(g, dtype) says so."""
     a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf)
     if pool2:  # y: [B][Hout/2][Wout/2][ldy] <- 2x2 sums of the result (only where conv_pool2_supported says so)
         a.flags |= _lib.CONV_POOL2
@@ -152,6 +155,34 @@ def conv_wgrad_workspace_bytes(g: dict, dtype: int) -> int:
     if n < 0:
         check(n, "c2w_conv_wgrad_workspace_bytes")
     return n
+
+
+def _geom_args(g: dict):
+    return ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
+                    g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
+
+
+def conv_wgrad_grouped_supported(g: dict, n: int, dtype: int) -> bool:
+    """Do ``n`` weight gradients of geometry ``g`` run as ONE launch (include/c2w_hip.h::c2w_conv_wgrad_grouped)?"""
+    return bool(_lib.load().c2w_conv_wgrad_grouped_supported(ctypes.byref(_geom_args(g)), n, dtype))
+
+
+def conv_wgrad_grouped_workspace_bytes(g: dict, n: int, dtype: int) -> int:
+    nb = int(_lib.load().c2w_conv_wgrad_grouped_workspace_bytes(ctypes.byref(_geom_args(g)), n, dtype))
+    if nb < 0:
+        check(nb, "c2w_conv_wgrad_grouped_workspace_bytes")
+    return nb
+
+
+def conv_wgrad_grouped(items, g: dict, dtype: int, workspace: Optional[torch.Tensor] = None):
+    """items: [(x, dy, dw, dbias or None)] of layers that share geometry ``g``: every dw += dY^T . patches(x), every dbias += column sums
+    of dY, by one launch (+ one reduction launch when the plan splits K)."""
+    arr = (_lib.WgradItem * len(items))()
+    for i, (x, dy, dw, db) in enumerate(items):
+        arr[i].x, arr[i].dy, arr[i].dw, arr[i].dbias = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+    nbytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    check(_lib.load().c2w_conv_wgrad_grouped(ctypes.byref(_geom_args(g)), arr, len(items), _p(workspace), nbytes, dtype, _stream()),
+          "c2w_conv_wgrad_grouped")
 
 
 WORKSPACE_BYTES = 96 << 20  # covers every layer of the default network at any batch (75.5 MB per launch, independent of the batch size)

@@ -86,6 +86,14 @@ typedef struct C2wConvArgs {
      * gradient of the output conv reads a gradient whose padding channels are zero, :194).  Kernels may skip the multiplications
      * the promise makes void (conv_patch_t3_kernel: whole 32-channel half chunks); results are unchanged. */
     int32_t kvalid;
+    /* Optional per-pixel statistics of the fused LayerNorms (16-bit launches; both NULL: rounds 1-4 behaviour):
+     *   lnf_rstd (with lnf_y): the forward also writes 1/sqrt(var + eps) of every pixel row it normalises, [B*Hout*Wout] fp32;
+     *   ln_rstd (with ln_x): the backward is handed what the forward kept -- ln_x then holds the NORMALISED rows (the lnf_y the
+     *   forward wrote = the conv input of model/nn.py:155, which training keeps anyway) and ln_rstd their 1/sigma; ln_m is not
+     *   read.  dLN = rstd * (g - mean(g) - xhat * sum(g * xhat) / den) needs neither the mean nor the variance again: two of the
+     *   four 16-lane reductions per pixel row and the modulation add leave the epilogue (model/nn.py:28,154 backward). */
+    float* lnf_rstd;
+    const float* ln_rstd;
 } C2wConvArgs;
 
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
@@ -130,6 +138,27 @@ int c2w_conv_wgrad(const C2wConvArgs* args, float* dw, float* dbias, void* works
                    void* stream);
 /* Scratch bytes c2w_conv_wgrad uses for this geometry and dtype (0: no split), or a negative C2W_ERR_* status. */
 long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* args, int dtype);
+
+/* The weight gradients of n layers that share ONE geometry (`args`: the forward block of any of them; x / y are ignored) as one launch:
+ * items[i] = {x, dy, dw, dbias} of layer i, each with the meaning c2w_conv_wgrad gives them (dw, dbias accumulated into).  The
+ * residual-block convs of a UNet level (model/nn.py:146-159: 6 or 12 layers of one shape) have their output gradients one after the
+ * other during the backward pass and independent weight gradients; a launch per layer must split its pixel reduction over the whole
+ * chip (at 8x8: 8 K tiles per workgroup, each followed by 295 KB of partial sums), together the layers fill it with a fraction of
+ * the splits.  `items` is a HOST array, copied into the kernel arguments (nothing is kept).  Results are deterministic (a fixed
+ * reduction order) but differ in rounding from n single calls (another split of the same sum).
+ * c2w_conv_wgrad_grouped_supported: 1 when the n layers run as one launch (halo-patch geometry, 2 <= n <= 16); otherwise the call
+ * returns C2W_ERR_UNSUPPORTED and the caller issues n c2w_conv_wgrad calls.  workspace must hold
+ * c2w_conv_wgrad_grouped_workspace_bytes(args, n, dtype) bytes (0 when the plan does not split). */
+typedef struct C2wWgradItem {
+    const void* x;
+    const void* dy;
+    float* dw;
+    float* dbias; /* may be NULL */
+} C2wWgradItem;
+int c2w_conv_wgrad_grouped_supported(const C2wConvArgs* args, int n, int dtype);
+long long c2w_conv_wgrad_grouped_workspace_bytes(const C2wConvArgs* args, int n, int dtype);
+int c2w_conv_wgrad_grouped(const C2wConvArgs* args, const C2wWgradItem* items, int n, void* workspace, unsigned long long workspace_bytes,
+                           int dtype, void* stream);
 
 /* y = LN_C(x + m[b]): parameter-free channel LayerNorm (zuko.nn.LayerNorm at model/nn.py:44,154,183) fused with
  * the time-modulation add of model/nn.py:28.  x,y: [npix][C]; m: fp32 rows of C (row b = pixel / HW, stride ldm;

@@ -104,12 +104,32 @@ def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_
         conv(x, w, bias, y, g, dtype, res=res)
         npix = g["B"] * g["Hout"] * g["Wout"]
         ln_forward(y, lnf.get("m"), lnf["y"], npix, g["Hout"] * g["Wout"], g["Cout"], lnf.get("ldm", 0), lnf["eps"], lnf["unbiased"], dtype)
+        if lnf.get("rstd") is not None:  # every pixel row's 1/sigma, as the normalisation used it
+            xm = _rows(y, npix, g["ldy"])[:, : g["Cout"]].float() + _mrows(lnf.get("m"), npix, g["Hout"] * g["Wout"], g["Cout"], lnf.get("ldm", 0))
+            var = xm.var(dim=1, unbiased=bool(lnf["unbiased"]))
+            lnf["rstd"].reshape(-1)[:npix] = (var + lnf["eps"]).rsqrt()
         return
     if ln is not None:  # y = res + dLN(conv(x); ln.x + ln.m), the conv result rounded to the storage type in between
         assert mul is None and y2 is None and act == ACT_NONE
         tmp = torch.zeros_like(y)
         conv(x, w, bias, tmp, g, dtype)
         npix = g["B"] * g["Hout"] * g["Wout"]
+        if ln.get("rstd") is not None:  # ln["x"] = the normalised rows the forward kept, ln["rstd"] their 1/sigma
+            C = g["Cout"]
+            gq = _rows(tmp, npix, g["ldy"])[:, :C].float()
+            xh = _rows(ln["x"], npix, g["ldy"])[:, :C].float()
+            rs = ln["rstd"].reshape(-1)[:npix].float().unsqueeze(1)
+            den = C - (1 if ln["unbiased"] else 0)
+            part = rs * (gq - gq.mean(dim=1, keepdim=True) - xh * (gq * xh).sum(dim=1, keepdim=True) / den)
+            if ln.get("dm") is not None:
+                HW, ldm = g["Hout"] * g["Wout"], ln.get("ldm", 0)
+                if ldm:
+                    torch.as_strided(ln["dm"].reshape(-1), (npix // HW, C), (ldm, 1)).add_(part.view(-1, HW, C).sum(1))
+                else:
+                    ln["dm"].reshape(-1)[:C] += part.sum(0)
+            out = part + (_rows(res, npix, g["ldy"])[:, :C].float() if res is not None else 0)
+            _rows(y, npix, g["ldy"])[:, :C] = out.to(TD[dtype])
+            return
         ln_backward(tmp, ln["x"], ln.get("m"), res, y, ln.get("dm"), npix, g["Hout"] * g["Wout"], g["Cout"], ln.get("ldm", 0), ln["eps"],
                     ln["unbiased"], dtype)
         return
@@ -173,6 +193,23 @@ def conv_wgrad(x, dy, dw, g, dtype, dbias=None, workspace=None):
     dw.reshape(-1)[: Cout * taps * Cin] += gw.reshape(-1)
     if dbias is not None:
         dbias.reshape(-1)[:Cout] += _rows(dy, B * Hout * Wout, ldy)[:, :Cout].float().sum(0)
+
+
+def conv_wgrad_grouped_supported(g, n, dtype):
+    return conv_patch_supported(g, dtype) and 2 <= n <= 16  # (the library also excludes the narrow-M form, Cout <= 80: a speed choice)
+
+
+def conv_wgrad_grouped_workspace_bytes(g, n, dtype):
+    return 0
+
+
+GROUPED_LAUNCHES = []  # (geometry side, layers) of every grouped launch: tests look at how the engine batches them
+
+
+def conv_wgrad_grouped(items, g, dtype, workspace=None):
+    GROUPED_LAUNCHES.append((g["Hout"], len(items)))
+    for x, dy, dw, db in items:
+        conv_wgrad(x, dy, dw, g, dtype, dbias=db, workspace=workspace)
 
 
 def _ln(xm, unbiased, eps):

@@ -335,3 +335,39 @@ def test_relu_network_matches_the_reference(emu, golden_dir):
         assert torch.allclose(p.grad, ref, atol=1e-5 + 2e-4 * ref.abs().max().item()), (n, (p.grad - ref).abs().max().item())
     with pytest.raises(NotImplementedError):
         ScoreUNet(channels=6, spatial=2, activation=torch.nn.GELU, **TINY)
+
+
+def test_weight_gradients_of_a_level_go_out_together_and_done_waits_for_them(emu, golden_dir):
+    """The residual-block convs of a level side share one geometry: their weight gradients are queued during the backward and launched
+    as ONE grouped call at the level boundary (model/nn.py:146-159; ops.conv_wgrad_grouped).  A "done" offset (Tape.progress: the
+    trainer may all-reduce and update everything at or above it) is handed on only once every weight gradient at or above it has
+    been launched -- checked by comparing, at every notification, the finished suffix of the gradient buffer with its final value."""
+    from climate2weather_amd.engine import Tape
+    from climate2weather_amd.ops import DTYPE_F32
+    net = _tiny()
+    eng = net._get_engine()
+    eng.ensure_grad_buffer()
+    x = torch.randn(2, 6, 32, 32, generator=torch.Generator().manual_seed(5))
+    t = torch.rand(2, generator=torch.Generator().manual_seed(6))
+
+    def run(group):
+        eng.group_wgrads = group
+        eng.flat_grad.zero_()
+        emu_ops.GROUPED_LAUNCHES.clear()
+        tape = Tape()
+        y = eng.forward(x, t, DTYPE_F32, tape=tape, nhwc_out=True)
+        seen = []
+        tape.progress = lambda off: seen.append((off, eng.flat_grad[off:].clone()))
+        eng.backward(tape, torch.ones_like(y) / y.numel())
+        return eng.flat_grad.clone(), seen, list(emu_ops.GROUPED_LAUNCHES)
+
+    g1, seen1, launches1 = run(True)
+    g0, seen0, launches0 = run(False)
+    assert launches0 == [] and launches1 == [(32, 2), (16, 4), (32, 2)], launches1  # ascent 0 | both sides of level 1 | descent 0
+    assert torch.equal(g0, g1)  # the emulation adds the same numbers in the same order either way
+    for seen, final in ((seen1, g1), (seen0, g0)):
+        offs = [o for o, _ in seen]
+        assert offs == sorted(offs, reverse=True) and offs[-1] == 0 or min(offs) >= 0
+        for off, suffix in seen:
+            assert torch.equal(suffix, final[off:]), f"gradients at or above offset {off} were still being written when it was reported done"
+    assert len(seen1) < len(seen0)  # grouped: fewer, larger notifications

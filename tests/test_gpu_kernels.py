@@ -265,6 +265,16 @@ def test_conv_with_fused_ln_forward_output(B, H, W, Cin, per_sample, use_res, un
         torch.cuda.synchronize()
         close(y, y_ref, dt, "conv output next to the fused LN")
         close(hn, hn_ref, dt, "fused LN forward output")
+        # ... and, asked for, every pixel row's 1/sigma (C2wConvArgs.lnf_rstd), with the other outputs unchanged bit for bit
+        rstd = torch.full((npix + 8,), -1.0, dtype=torch.float32, device=dev())
+        rstd_ref = rstd.clone()
+        y2_, hn2_ = torch.empty_like(y), torch.empty_like(hn)
+        ops.conv(x, w, bias, y2_, g, dt, res=res, lnf=dict(lnf, y=hn2_, rstd=rstd))
+        E.conv(x, w, bias, y_ref, g, dt, res=res, lnf=dict(lnf, y=hn_ref, rstd=rstd_ref))
+        torch.cuda.synchronize()
+        assert torch.equal(y2_, y) and torch.equal(hn2_, hn)
+        close(rstd[:npix], rstd_ref[:npix], dt, "per-pixel 1/sigma of the fused LN", tol=2e-3)
+        assert (rstd[npix:] == -1.0).all()
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
@@ -295,6 +305,19 @@ def test_conv_with_fused_ln_backward(B, H, W, Cin, per_sample, unbiased, dt):
     torch.cuda.synchronize()
     close(y, y_ref, dt, "fused ln bwd dx")
     close(dm, dm_ref, dt, "fused ln bwd dm", tol=1e-2)
+    # the same with the statistics the forward kept (C2wConvArgs.ln_rstd): ln_x = the normalised rows, ln_rstd their 1/sigma
+    xm = lnx.float() + E._mrows(m.view(-1)[32:], npix, H * W, C, ldm)
+    rs = (xm.var(dim=1, unbiased=unbiased) + 1e-5).rsqrt()
+    xhat = ((xm - xm.mean(dim=1, keepdim=True)) * rs.unsqueeze(1)).to(TD[dt])
+    dm2, dm2_ref = torch.zeros_like(m), torch.zeros_like(m)
+    y_s, y_s_ref = torch.full_like(y, 7.0), torch.full_like(y, 7.0)
+    lns = dict(x=xhat, rstd=rs.contiguous(), m=None, dm=dm2.view(-1)[32:], ldm=ldm, eps=1e-5, unbiased=unbiased)
+    ops.conv(x, w, None, y_s, g, dt, res=res, ln=lns)
+    E.conv(x, w, None, y_s_ref, g, dt, res=res, ln=dict(lns, dm=dm2_ref.view(-1)[32:]))
+    torch.cuda.synchronize()
+    close(y_s, y_s_ref, dt, "fused ln bwd dx from kept statistics")
+    close(dm2, dm2_ref, dt, "fused ln bwd dm from kept statistics", tol=1e-2)
+    close(y_s, y_ref, dt, "kept statistics vs recomputed (xhat rounded to the storage type)", tol=2 * TOL[dt])
     # without modulation / residual / dm
     ops.conv(x, w, None, y, g, dt, ln=dict(x=lnx, eps=1e-5, unbiased=unbiased))
     E.conv(x, w, None, y_ref, g, dt, ln=dict(x=lnx, eps=1e-5, unbiased=unbiased))
@@ -341,6 +364,62 @@ def test_conv_wgrad(case, dt, force_gather, monkeypatch):
         dw2 = torch.zeros_like(dw)
         ops.conv_wgrad(x, dy, dw2, g, dt, workspace=small)
         close(dw2, dw_ref, dt, "wgrad with an undersized workspace", tol=1e-4 if dt == F32 else 1e-2)
+
+
+GROUP_CASES = [
+    # (mode, B, H, W, Cin, Cout, layers)            split plan of the grouped launch (256 workgroups per round)
+    (ops.CONV_S1, 4, 8, 8, 128, 256, 6),            # 8x8 images in pairs, 2 K tiles: no split, tiles added straight onto dw
+    (ops.CONV_S1, 16, 8, 8, 256, 256, 12),          # pairs, 8 K tiles, 96 output tiles: two splits
+    (ops.CONV_S1, 6, 16, 16, 128, 128, 3),          # 12 K tiles, 6 output tiles: split 12 ways
+    (ops.CONV_S1, 2, 32, 32, 128, 192, 2),          # partial second channel tile
+    (ops.CONV_S1, 2, 16, 32, 64, 128, 16),          # the most layers one launch takes
+    (ops.CONV_UP, 2, 8, 16, 128, 128, 2),           # upsampling folded into the patch load
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("case", GROUP_CASES)
+def test_conv_wgrad_grouped(case, dt):
+    """c2w_conv_wgrad_grouped: the weight gradients of n layers of one geometry in one launch == n c2w_conv_wgrad calls (another split of
+    the same pixel sum: equal to rounding), accumulates onto dw / dbias like them, writes nothing else, and is bit-reproducible."""
+    mode, B, Hin, Win, Cin, Cout, n = case
+    if dt == F32:
+        Cin, Cout = Cin // 2 if Cin > 64 else Cin, Cout // 2  # fp32 tiles are half as wide: same number of tiles
+    Hout, Wout = _out_hw(mode, Hin, Win)
+    g = geom(B, Hin, Win, Cin, Hout, Wout, Cout, Cout, Cout, mode)
+    assert ops.conv_wgrad_grouped_supported(g, n, dt)
+    assert not ops.conv_wgrad_grouped_supported(g, 1, dt) and not ops.conv_wgrad_grouped_supported(g, 17, dt)
+    xs = [rnd((B * Hin * Win, Cin), dt, 10 + i) for i in range(n)]
+    dys = [rnd((B * Hout * Wout, Cout), dt, 40 + i) for i in range(n)]
+    pre = [rnd((Cout * 9 * Cin + 64,), F32, 70 + i, 0.1) for i in range(n)]  # dw holds a value already: the call accumulates
+    for t in pre:
+        t[-64:] = 0
+    dws = [t.clone() for t in pre]
+    dbs = [torch.zeros(Cout + 8, dtype=torch.float32, device=dev()) for _ in range(n)]
+    need = ops.conv_wgrad_grouped_workspace_bytes(g, n, dt)
+    ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev())
+    ops.conv_wgrad_grouped([(xs[i], dys[i], dws[i], dbs[i] if i % 2 == 0 else None) for i in range(n)], g, dt, workspace=ws)
+    one_ws = ops.new_workspace(dev())
+    for i in range(n):
+        dw_ref, db_ref = pre[i].clone(), torch.zeros_like(dbs[i])
+        ops.conv_wgrad(xs[i], dys[i], dw_ref, g, dt, dbias=db_ref, workspace=one_ws)
+        emu = pre[i].clone()
+        E.conv_wgrad(xs[i], dys[i], emu, g, dt)
+        close(dws[i], emu, dt, f"grouped wgrad layer {i} vs restatement", tol=1e-4 if dt == F32 else 1e-2)
+        close(dws[i], dw_ref, dt, f"grouped wgrad layer {i} vs single launch", tol=1e-5 if dt == F32 else 2e-3)
+        if i % 2 == 0:
+            close(dbs[i], db_ref, dt, f"grouped wgrad bias {i}", tol=1e-4 if dt == F32 else 1e-2)
+        else:
+            assert dbs[i].abs().max().item() == 0.0
+        assert dws[i][-64:].abs().max().item() == 0.0 and dbs[i][Cout:].abs().max().item() == 0.0
+    again = [t.clone() for t in pre]
+    ops.conv_wgrad_grouped([(xs[i], dys[i], again[i], None) for i in range(n)], g, dt, workspace=ws)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(again[i], dws[i]), f"layer {i}: two grouped launches of the same inputs differ"
+    if need > 0:  # a workspace smaller than the plan needs is refused (the caller sizes it with ..._workspace_bytes), nothing is written
+        with pytest.raises(_lib.C2wError):
+            ops.conv_wgrad_grouped([(xs[i], dys[i], again[i], None) for i in range(n)], g, dt, workspace=ws[: need // 4 - 4])
 
 
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
