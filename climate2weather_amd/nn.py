@@ -28,7 +28,9 @@ class AttentionBlock(torch.nn.Module):
     def __init__(self, channels: int, num_heads: int = 1):
         super().__init__()
         if num_heads != 1:
-            raise NotImplementedError("the reference only ever builds num_heads=1 (model/nn.py:203-204)")
+            raise NotImplementedError("climate2weather_amd: attention with num_heads != 1 is not built (the reference's UNet only ever constructs "
+                                      "AttentionBlock(channels) with the default single head, model/nn.py:203-204; its multi-head reshape is "
+                                      "model/nn.py:62-85).  INTEGRATION.md section 'What raises' lists every such fence.")
         self.channels = channels
         self.num_heads = num_heads
         self.qkv = torch.nn.Conv1d(channels, channels * 3, kernel_size=1)
@@ -73,16 +75,23 @@ class UNet(torch.nn.Module):
         ks = [kernel_size] * spatial if isinstance(kernel_size, int) else list(kernel_size)
         st = [stride] * spatial if isinstance(stride, int) else list(stride)
         if spatial != 2 or ks != [3, 3] or st != [2, 2]:
-            raise NotImplementedError("MI355X engine covers the shipped configuration: spatial=2, kernel_size=3, stride=2")
+            raise NotImplementedError(f"climate2weather_amd: spatial={spatial}, kernel_size={ks}, stride={st} -- the kernels cover what every shipped "
+                                      "config builds (configs/sda_unet.yml, train.py:164-173: spatial=2, kernel_size=3, stride=2); the reference's "
+                                      "generic N-d / any-kernel construction (model/nn.py:126-143) has no MI355X path.  Use the reference module "
+                                      "for such a network (INTEGRATION.md, 'What raises').")
         if kwargs.get("padding_mode", "zeros") != "zeros":
-            raise NotImplementedError("only padding_mode='zeros' (configs/sda_unet.yml:14)")
+            raise NotImplementedError("climate2weather_amd: only padding_mode='zeros' (configs/sda_unet.yml:14; the halo-patch kernels realise the "
+                                      "padding as out-of-range buffer loads); other modes of model/nn.py:126-143 need the reference module "
+                                      "(INTEGRATION.md, 'What raises').")
         act = activation()
         if isinstance(act, torch.nn.SiLU):
             self.activation_kind = "silu"   # what train.py:171 passes
         elif isinstance(act, torch.nn.ReLU):
             self.activation_kind = "relu"   # the reference's own default (model/nn.py:118)
         else:
-            raise NotImplementedError("the HIP epilogues implement SiLU (train.py:171) and ReLU (the default of model/nn.py:118)")
+            raise NotImplementedError(f"climate2weather_amd: activation {type(act).__name__} -- the conv epilogues implement SiLU (train.py:171) and "
+                                      "ReLU (the default of model/nn.py:118); any other `activation` of model/nn.py:118,156 needs the "
+                                      "reference module (INTEGRATION.md, 'What raises').")
         self.in_channels, self.out_channels, self.mod_features, self.spatial = in_channels, out_channels, mod_features, spatial
         self.hidden_channels = list(hidden_channels)
         self.hidden_blocks = list(hidden_blocks)
