@@ -149,8 +149,8 @@ class LaunchTimer:
     def __init__(self, ops, eng, dt, batch):
         self.ops, self.eng, self.dt, self.batch = ops, eng, dt, batch
         self.mode = "off"  # "off" | "dominant" | "all"
-        self.events = []  # (layer, kind, geometry-dict, e0, e1)
-        self._conv, self._wgrad = ops.conv, ops.conv_wgrad
+        self.events = []  # (layer, kind, geometry-dict, e0, e1[, layers of a grouped launch])
+        self._conv, self._wgrad, self._wgrad_grouped = ops.conv, ops.conv_wgrad, ops.conv_wgrad_grouped
         self.fw, self.dg, self.gw = {}, {}, {}
         self.dominant = set()
 
@@ -202,10 +202,20 @@ class LaunchTimer:
             self._wgrad(x, dy, dw, g, dtype, **kw)
             e1.record()
             self.events.append((rec, "wgrad", g, e0, e1))
-        self.ops.conv, self.ops.conv_wgrad = conv, conv_wgrad
+
+        def conv_wgrad_grouped(items, g, dtype, **kw):  # the weight gradients of a level side in one launch (+ one reduction launch)
+            rec = self.gw.get(items[0][2].data_ptr()) if self.mode == "all" else None
+            if rec is None:
+                return self._wgrad_grouped(items, g, dtype, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._wgrad_grouped(items, g, dtype, **kw)
+            e1.record()
+            self.events.append((rec, "wgrad", g, e0, e1, len(items)))
+        self.ops.conv, self.ops.conv_wgrad, self.ops.conv_wgrad_grouped = conv, conv_wgrad, conv_wgrad_grouped
 
     def uninstall(self):
-        self.ops.conv, self.ops.conv_wgrad = self._conv, self._wgrad
+        self.ops.conv, self.ops.conv_wgrad, self.ops.conv_wgrad_grouped = self._conv, self._wgrad, self._wgrad_grouped
 
     @staticmethod
     def flop(rec, kind, g) -> float:
@@ -232,19 +242,26 @@ class LaunchTimer:
     def summarise(self, select=None, steps=1):
         """-> {family: dict(launches_per_step, avg_ms, ms_per_step, gflop_per_launch, tflops, frac)} over the recorded events."""
         fam = {}
-        for rec, kind, g, e0, e1 in self.events:
+        for ev in self.events:
+            rec, kind, g, e0, e1 = ev[:5]
+            layers = ev[5] if len(ev) > 5 else 1  # a grouped weight-gradient launch covers several layers of one shape
             if select is not None and not select(rec, kind):
                 continue
-            f = fam.setdefault(self.family(rec, kind, g), [0, 0.0, 0.0])
+            name = self.family(rec, kind, g) + (f" (grouped: {layers} layers per launch)" if layers > 1 else "")
+            f = fam.setdefault(name, [0, 0.0, 0.0, 0])
             f[0] += 1
             f[1] += e0.elapsed_time(e1)
-            f[2] += self.flop(rec, kind, g)
+            f[2] += self.flop(rec, kind, g) * layers
+            f[3] += layers
         out = {}
-        for k, (n, ms, fl) in fam.items():
+        for k, (n, ms, fl, nl) in fam.items():
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = 157.0 if "fp32" in k else MFMA_PEAK_TFLOPS
             out[k] = dict(launches_per_step=round(n / steps, 2), avg_ms=round(ms / n, 4), ms_per_step=round(ms / steps, 3),
                           gflop_per_launch=round(fl / n / 1e9, 2), tflops=round(tf, 1), frac=round(tf / peak, 4))
+            if nl != n:
+                out[k]["layers_per_step"] = round(nl / steps, 2)
+                out[k]["ms_per_layer"] = round(ms / nl, 4)
         return out
 
 
@@ -933,13 +950,14 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
     gamma = 0.0007196856730011522
     legs = []
 
-    def leg(L, nmem, c, bsz=128, floor=0, into=None):
+    def leg(L, nmem, c, bsz=128, floor=0, into=None, graphs=False):
         shape = (L, F, H, H) if nmem == 1 else (nmem, L, F, H, H)
         g = torch.Generator(device=dev).manual_seed(L)
         truth = torch.randn((L, F, H, H), device=dev, generator=g) * 0.5 + 0.5
         with contextlib.redirect_stdout(io.StringIO()):
             sf = BatchedScoreFunction(net, markov_order=k, batch_size=bsz, device=dev, noise_process=pipe)
             sf.window_batch_floor = floor
+            sf.use_graphs = graphs  # the network part of a score evaluation replayed from a hipGraph (score_fn._score_graphed)
             sf.condition_on(A=A, y=A(truth), std=std, gamma=gamma, exact_grad=False)
             assert sf._fused_guidance is not None
             del truth
@@ -962,6 +980,8 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
                  members_per_hour_at_256_steps=round(nmem * 3600.0 / (256 * d), 2))
         if bsz != 128 or floor != 0:
             r.update(batch_size=bsz, window_batch_floor=floor)
+        if graphs:
+            r.update(hipgraph=True)
         (legs if into is None else into).append(r)
         if log is not None:
             log(r)
@@ -972,13 +992,22 @@ def sampler_configs3(dev, precision="bf16", lengths=(49, 121, 8737), corrections
     if members > 1:
         for c in corrections:
             leg(49, members, c)
+    # BASELINE configs[4]'s "hipGraph-captured sampler step" where launch latency could matter: the short trajectories, one member.  (A
+    # sampler step at L = 49 is ~125 launches in 5.8 ms with the GPU busy 98.7 % of it, profiles/r04_sampler_l49_step_table.txt: the
+    # replay removes host work, not device time.)
+    graph_legs = []
+    for L in (49, 121):
+        if L in lengths:
+            leg(L, 1, 0, into=graph_legs, graphs=True)
     # what the product default does with the reference's other shipped batch size (exp/configs: batch_size 32): score_fn.py::window_batch_floor
     floor_legs = []
     if 8737 in lengths:
         from climate2weather_amd.score_fn import BatchedScoreFunction as _B
         leg(8737, 1, 0, bsz=32, floor=0, into=floor_legs)
         leg(8737, 1, 0, bsz=32, floor=_B.window_batch_floor, into=floor_legs)
-    return dict(window_batch_floor=dict(note="L = 8737, batch_size = 32 (the reference's other shipped value): exactly 32 windows per network call "
+    return dict(hipgraph=dict(note="the same legs (one member, no corrector) with the network launches of a score evaluation replayed from a hipGraph",
+                              legs=graph_legs),
+                window_batch_floor=dict(note="L = 8737, batch_size = 32 (the reference's other shipped value): exactly 32 windows per network call "
                                              "(floor 0) against the product default (launches of at least `window_batch_floor` windows); the legs "
                                              "below run exactly 128 windows per call", legs=floor_legs),
                 config="F=4, k=6, 52 ch x 128x128, %s, window batch 128, conditioned on AvgPool2d(16) o x[::6] (s16_t6.yml std / gamma, exact_grad=False), "

@@ -473,7 +473,21 @@ def test_bf16_and_fp16_training_track_fp32_training():
     a = torch.tensor(curves["fp32"][-20:]).mean().item()
     for prec, bound in (("bf16", 0.10), ("fp16", 0.02)):
         b = torch.tensor(curves[prec][-20:]).mean().item()
+        _MARGINS[f"curve_{prec}"] = abs(a - b) / a
         assert abs(a - b) <= bound * a, (prec, a, b)
+
+
+_MARGINS = {}  # measured distances the tests above were GIVEN ROOM for; the margin tests below hold them against the tight bounds
+
+
+@pytest.mark.xfail(strict=False, reason="margin watch, not a gate: the bf16 curve's tail lands -0.1 ... +4.6 % off the fp32 one from run to run "
+                                        "(fp32 atomics order amplified over 60 steps; lab/probes/flake_training_curves.py); the gate is 10 %")
+def test_margin_bf16_training_curve_within_5_percent():
+    """The bound test_bf16_and_fp16_training_track_fp32_training had before round 4 widened it (5 % -> 10 %), kept in the suite so that a
+    drift of the margin shows up as XFAIL counts in the record instead of a silently wider tolerance."""
+    if "curve_bf16" not in _MARGINS:
+        pytest.skip("the curve test did not run")
+    assert _MARGINS["curve_bf16"] <= 0.05, _MARGINS["curve_bf16"]
 
 
 def test_training_step_with_regenerated_noise_equals_the_step_on_the_written_noise_tensor():
@@ -963,6 +977,7 @@ def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_
                     assert torch.equal(got, want), f"centre frames of windows {b0}..{b0 + nb - 1}"
                 else:
                     d = (got - want).abs()
+                    _MARGINS["fold_steps"] = max(_MARGINS.get("fold_steps", 0.0), float((d / (2.0 ** -7 * want.abs().clamp_min(2.0 ** -10))).max()))
                     assert bool((d <= 1.5 * 2.0 ** -7 * want.abs().clamp_min(2.0 ** -10)).all()), f"centre frames of windows {b0}..: max |d| {d.max().item():.3e}"
                     assert float((d != 0).float().mean()) < 0.02
                 # the first / last window's other frames: out of the full output rows -- of the whole batch (bit-equal to the module's),
@@ -1003,3 +1018,13 @@ def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_
             J = F.interpolate((err / var)[None], scale_factor=16, mode="nearest")[0] / 256.0 / mu
             want = eps_u[i] - sigma * J
             assert (eps_c[i] - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+
+@pytest.mark.xfail(strict=False, reason="margin watch, not a gate: the centre conv sums in another order than the full output conv; one bf16 rounding "
+                                        "step is reached exactly (lab/probes/fold_margins.py); the gate is 1.5 steps")
+def test_margin_fold_within_one_rounding_step():
+    """The bound the fold test had before round 4 widened it (1 -> 1.5 bf16 rounding steps), kept as a watched margin."""
+    if "fold_steps" not in _MARGINS:
+        pytest.skip("the full-length fold test did not run")
+    assert _MARGINS["fold_steps"] < 1.0, _MARGINS["fold_steps"]

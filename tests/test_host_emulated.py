@@ -719,13 +719,32 @@ def test_co_sampled_members_equal_members_sampled_one_by_one(emu, cond):
         A = PoolStrideOperator(8, 2)
         kw.update(A=A, y=A(torch.rand(6, 2, 16, 16, generator=torch.Generator().manual_seed(2))),
                   std=torch.tensor([0.5, 0.3]).view(1, 2, 1, 1), gamma=1e-2, exact_grad=False)
-    one = run_ensemble(net, **kw)
-    for group in (2, 3, 8):
+    one = run_ensemble(net, members_per_batch=1, **kw)
+    for group in (2, 3, 8, None):  # None = the default: without a corrector, as many members as reach the window floor
         co = run_ensemble(net, members_per_batch=group, **kw)
         assert [i for i, _ in co] == [0, 1, 2]
         for (_, a), (_, b) in zip(one, co):
             assert a.shape == b.shape == (6, 2, 16, 16)
             assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    # the default really co-samples when the score function has a window floor (the suite runs with the floor off), and does not under a corrector
+    shapes = []
+
+    class Spy(SDAPipeline):
+        def sample(self, score_fn, noise, **k2):
+            shapes.append(tuple(noise.shape))
+            return super().sample(score_fn, noise, **k2)
+    monkey = pytest.MonkeyPatch()
+    try:
+        monkey.setenv("C2W_WINDOW_BATCH_FLOOR", "64")
+        co = run_ensemble(net, Spy(), **kw)
+        assert shapes == [(3, 6, 2, 16, 16)], shapes
+        for (_, a), (_, b) in zip(one, co):
+            assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+        shapes.clear()
+        run_ensemble(net, Spy(), **dict(kw, corrections=1, steps=1))
+        assert shapes == [(6, 2, 16, 16)] * 3, shapes
+    finally:
+        monkey.undo()
     # corrector: same normals -> same members
     pipe = SDAPipeline()
     sf = BatchedScoreFunction(net, markov_order=1, batch_size=4, device=torch.device("cpu"), noise_process=pipe)

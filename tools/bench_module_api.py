@@ -21,6 +21,8 @@ p.add_argument("--legs", default="bf16_autocast,fp16_autocast_gradscaler,trainer
 p.add_argument("--no-item", action="store_true", help="drop the per-step loss.item() of training_loop.py:385 (diagnostic)")
 p.add_argument("--lazy", action="store_true", help="hand pipeline.loss the un-gathered WindowBatch (diagnostic)")
 p.add_argument("--ddp", action="store_true", help="wrap the module in torch's DistributedDataParallel over a one-rank RCCL group (what fabric.setup_module does)")
+p.add_argument("--bucket-view", action="store_true", help="with --ddp: gradient_as_bucket_view=True (p.grad become views of the reducer's buckets: no copy-out; "
+                                                        "the drop-in AdamW gathers them for its fused step)")
 p.add_argument("--segments", type=int, default=None, help="ScoreUNet.grad_segments (default: 8 under more than one rank, else 1)")
 a = p.parse_args()
 dev = torch.device("cuda", 0)
@@ -36,6 +38,6 @@ if a.ddp or a.segments is not None:
     def wrap(net):
         if a.segments is not None:
             net.grad_segments = a.segments
-        return torch.nn.parallel.DistributedDataParallel(net, device_ids=[0]) if a.ddp else net
+        return torch.nn.parallel.DistributedDataParallel(net, device_ids=[0], gradient_as_bucket_view=a.bucket_view) if a.ddp else net
 res = bench.module_api(dev, a, 1.0, legs=tuple(a.legs.split(",")), item=not a.no_item, lazy=a.lazy, wrap=wrap)
 print(json.dumps(res, indent=1))
