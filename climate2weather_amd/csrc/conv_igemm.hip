@@ -361,6 +361,7 @@ C2wKnobs read_knobs() {
     k.up_patch = getenv("C2W_NO_UP_PATCH") == nullptr;
     k.wgrad_narrow = getenv("C2W_NO_NARROW") == nullptr;
     k.wpacked = getenv("C2W_NO_WPACKED") == nullptr;
+    k.wgrad_wgs = getenv("C2W_WGRAD_WGS") && atoi(getenv("C2W_WGRAD_WGS")) > 0 ? atoi(getenv("C2W_WGRAD_WGS")) : 256;
     k.pool2 = getenv("C2W_NO_POOL2") == nullptr;
     k.ln_fusion = getenv("C2W_NO_LN_FUSION") == nullptr;
     k.lnf = getenv("C2W_NO_LNF") == nullptr;

@@ -17,6 +17,7 @@ struct C2wKnobs {
     bool attn_valu;       // C2W_ATTN_VALU=1      attention on the fp32 VALU kernels instead of the matrix-core ones
     bool wgrad_narrow;    // C2W_NO_NARROW=1      edge convs (<= 80 output channels) NOT on the narrow forms of the halo-patch kernels
     bool wpacked;         // C2W_NO_WPACKED=1     c2w_conv_wpacked_supported answers 0 (callers hand over the plain [rows][9][Cin] weights)
+    int wgrad_wgs;        // C2W_WGRAD_WGS=N      workgroups a halo-patch weight-gradient launch splits its K range into (default 256: one per CU)
 };
 
 const C2wKnobs& c2w_knobs();

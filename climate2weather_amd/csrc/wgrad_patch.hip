@@ -75,6 +75,9 @@ struct WpGroupArgs {
     WpArgs c;             // geometry, split plan, ws = base of the group's workspace; dy / x / dw / db unused
     int n;                // layers
     int blocks_per_item;  // tilesMN * nsplit rounded up to a multiple of 8 (so that blockIdx & 7 labels the XCD inside every layer's range too)
+    int live_per_item;    // tilesMN * nsplit: blocks past it exit.  The tile order is derived from THIS count: derived from the padded one,
+                          // all padding blocks of every layer fall on the last XCD (round 5, first version: the 64x64 group ran 252
+                          // workgroups on 7 of the 8 XCDs = two rounds, 1476 us instead of ~800)
     unsigned long long ws_item_floats;
     WpItem item[WP_MAX_ITEMS];
 };
@@ -445,6 +448,7 @@ template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_group_kernel(const WpGroupArgs g) {
     const int it = __builtin_amdgcn_readfirstlane((int)blockIdx.x / g.blocks_per_item);
     const int bid = (int)blockIdx.x - it * g.blocks_per_item;
+    if (bid >= g.live_per_item) return;
     const WpItem e = wp_item(it);
     WpArgs p = g.c;
     p.dy = e.dy;
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_group_kernel(const Wp
     p.dw = e.dw;
     p.db = e.db;
     p.ws = g.c.ws != nullptr ? g.c.ws + (size_t)it * g.ws_item_floats : nullptr;
-    wgrad_patch_body<T, PAIR, false>(p, bid, g.blocks_per_item);
+    wgrad_patch_body<T, PAIR, false>(p, bid, g.live_per_item);
 }
 
 // dw[co][tap][ci] += sum over splits of ws[split][tile][tap][row][col].  RC float4 columns x RG split groups per block (RC * RG =
@@ -521,7 +525,7 @@ static void split_plan(const C2wConvArgs& a, int& ktiles, int& tilesMN, int& nsp
     constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
     ktiles = PAIR ? ((a.B + 1) >> 1) * (a.Hout >> 3) : a.B * (a.Hout >> 3) * (a.Wout >> 4);
     tilesMN = ((a.Cout + COT - 1) / COT) * (a.Cin / CIB);
-    nsplit = 256 / tilesMN;
+    nsplit = c2w_knobs().wgrad_wgs / tilesMN;
     if (nsplit > ktiles) nsplit = ktiles;
     if (nsplit < 1) nsplit = 1;
     ktiles_per_split = (ktiles + nsplit - 1) / nsplit;
@@ -614,7 +618,8 @@ int launch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* 
     p.ws = nsplit > 1 ? ws : nullptr;
     p.direct = nsplit == 1 ? 1 : 0;
     g.n = n;
-    g.blocks_per_item = (tilesMN * nsplit + 7) & ~7;
+    g.live_per_item = tilesMN * nsplit;
+    g.blocks_per_item = (g.live_per_item + 7) & ~7;
     g.ws_item_floats = item_floats;
     for (int i = 0; i < WP_MAX_ITEMS; ++i) {
         const C2wWgradItem& e = items[i < n ? i : n - 1];

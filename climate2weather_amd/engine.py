@@ -240,6 +240,8 @@ class Engine:
         _grp = os.environ.get("C2W_WGRAD_GROUP", "64")
         self.group_wgrads = _grp != "0"
         self.group_wgrads_max_side = int(_grp) if _grp.isdigit() and int(_grp) > 1 else 1 << 30
+        # above that side: groups of at most this many layers (1 = one launch per layer); C2W_WGRAD_GROUP_TOP (A/B)
+        self.group_wgrads_top = max(1, int(os.environ.get("C2W_WGRAD_GROUP_TOP", "1")))
         self._wg_groups: Dict[tuple, list] = {}  # (geometry, dtype) -> [(x, dY, record, geometry)] not launched yet
         self._wg_group_ok: Dict[tuple, bool] = {}
         self._done_release = None  # set by backward_steps: hands on the "done" offsets held back while a group was pending
@@ -611,7 +613,8 @@ class Engine:
         queued and launched with the others at the next flush_wgrad_groups()."""
         if self._skip_dw:
             return
-        if group and self.group_wgrads and g["Hout"] <= self.group_wgrads_max_side:
+        cap = 16 if g["Hout"] <= self.group_wgrads_max_side else self.group_wgrads_top
+        if group and self.group_wgrads and cap > 1:
             key = (g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"], g["mode"], dt, ops.KNOBS_GENERATION)
             ok = self._wg_group_ok.get(key)
             if ok is None:
@@ -619,8 +622,10 @@ class Engine:
             if ok:
                 lst = self._wg_groups.setdefault(key, [])
                 lst.append((x, gy, rec, g))
-                if len(lst) >= 16:
+                if len(lst) >= cap:
                     self._flush_group(key)
+                    if not self._wg_groups and self._done_release is not None:
+                        self._done_release()
                 return
         self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
 

@@ -185,7 +185,9 @@ def conv_wgrad_grouped(items, g: dict, dtype: int, workspace: Optional[torch.Ten
           "c2w_conv_wgrad_grouped")
 
 
-WORKSPACE_BYTES = 96 << 20  # covers every layer of the default network at any batch (75.5 MB per launch, independent of the batch size)
+# covers every layer of the default network at any batch (75.5 MB per launch, independent of the batch size); C2W_WORKSPACE_MB: A/B runs
+# that raise the number of splits (C2W_WGRAD_WGS)
+WORKSPACE_BYTES = int(__import__("os").environ.get("C2W_WORKSPACE_MB", "96")) << 20
 
 
 def new_workspace(device, nbytes: int = WORKSPACE_BYTES) -> torch.Tensor:
