@@ -376,6 +376,19 @@ def cpu_baseline(C, size, cfg):
                 cpu_model=_cpu_model(), logical_cpus=ncpu, thread_sweep_forward_windows_per_s=sweep, legs=legs)
 
 
+def _leg(out, name, fn):
+    """Run one extra leg (everything outside the timed headline region).  A leg that raises must not cost the run its record: the
+    exception goes into `errors` (extras file + a count in the compact line) and the headline line is still printed."""
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001 -- any failure of an extra leg is reported, never fatal
+        import traceback
+        sys.stderr.write(f"bench.py: extra leg {name!r} failed:\n{traceback.format_exc()}\n")
+        if out is not None:
+            out.setdefault("errors", {})[name] = f"{type(e).__name__}: {e}"[:400]
+        return None
+
+
 def _empty_cache():
     """Between the extra legs of this process the allocator's cached blocks go back to the driver (C2W_BENCH_KEEP_CACHE=1: keep them).
     Either way a leg that runs late in a long-lived process is 2-6 % slower than the same leg in a process of its own (round 4:
@@ -456,6 +469,8 @@ def compact_line(full: dict, extras_file=None) -> str:
     short = {f"L{l['L']}_m{l['members']}_c{l['corrections']}": l.get("window_forwards_per_s") for l in legs if isinstance(l, dict) and "L" in l}
     if short:
         line["sampler_conditioned_window_forwards_per_s"] = short
+    if full.get("errors"):
+        line["extra_legs_failed"] = sorted(full["errors"])
     line["extras_file"] = extras_file
     text = json.dumps(line)
     if len(text) >= COMPACT_LIMIT:  # cannot happen with the fields above; if a string grew, the optional scalars go first
@@ -602,7 +617,7 @@ def run_rank(a):
     extras = not a.no_extras
     # ---- what a plain dense GEMM of the vendor library reaches on THIS chip in THIS run (outside the headline region): the clock the
     # power governor holds under matrix load caps every bf16 kernel well below the 2.5 PFLOP/s spec peak `roofline.frac` is priced at
-    if extras and out is not None and out.get("roofline") and a.precision in ("bf16", "fp16"):
+    def vendor_gemm():
         td = torch.bfloat16 if a.precision == "bf16" else torch.float16
         n = 8192
         ga, gb = torch.randn(n, n, device=dev).to(td), torch.randn(n, n, device=dev).to(td)
@@ -621,8 +636,10 @@ def run_rank(a):
             tflops=round(gemm_tf, 1), frac_of_spec_peak=round(gemm_tf / MFMA_PEAK_TFLOPS, 4),
             dominant_kernel_vs_vendor_gemm=round(out["roofline"]["achieved"] / gemm_tf, 4))
         del ga, gb
+    if extras and out is not None and out.get("roofline") and a.precision in ("bf16", "fp16"):
+        _leg(out, "vendor_gemm", vendor_gemm)
     # ---- by_kernel (outside the headline region): every implicit-GEMM launch of `kernel_steps` more steps, streams serialised
-    if extras and a.kernel_steps > 0:
+    def by_kernel():
         timer.events.clear()
         prev = trainer.eng.use_grad_stream
         trainer.eng.use_grad_stream = False  # weight gradients on the caller's stream: every kernel alone on the chip
@@ -646,9 +663,12 @@ def run_rank(a):
                 serialised_step_ms=round(ser_ms, 2), implicit_gemm_ms_per_step=round(gemm_ms, 2), everything_else_ms_per_step=round(ser_ms - gemm_ms, 2),
                 kernels=[dict(kernel=k, **v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])])
         timer.events.clear()
+    if extras and a.kernel_steps > 0:
+        _leg(out, "by_kernel", by_kernel)
+        timer.mode = "off"
 
     # ---- sampler legs (outside the headline region): window-forwards/s inside the device-resident sampler
-    if extras and a.sample_steps > 0 and a.size == 128:
+    def sampler_legs():
         net.precision = a.precision
         L = 128 + w - 1
         import contextlib, io
@@ -694,6 +714,8 @@ def run_rank(a):
                 n_gpus=world, members_total=members * world, scaling="weak",
                 window_forwards_per_s=round(world * members * (Ls - w + 1) * nst / dts_job, 1),
                 members_per_hour_at_256_steps=round(world * members * 3600.0 / (256 * dts_job / nst), 1))
+    if extras and a.sample_steps > 0 and a.size == 128:
+        _leg(out, "sampler_legs", sampler_legs)
 
     # ---- BASELINE configs[4] (outside the headline region): deep variant, 80 ch x 256x256, fp16 MFMA, hipGraph-replayed sampler step
     if extras and a.size == 128 and world == 1 and not a.light_extras:
@@ -701,17 +723,17 @@ def run_rank(a):
         del trainer, feed, ds, timer
         _empty_cache()
         import gc
-        out["deep_variant"] = deep_variant(dev)
+        out["deep_variant"] = _leg(out, "deep_variant", lambda: deep_variant(dev))
         gc.collect()
         _empty_cache()
-        out["module_api"] = module_api_child(a, out["value"])
+        out["module_api"] = _leg(out, "module_api", lambda: module_api_child(a, out["value"]))
         gc.collect()
         _empty_cache()
-        out["sampler_configs3"] = sampler_configs3(dev, a.precision if a.precision != "fp32" else "bf16")
+        out["sampler_configs3"] = _leg(out, "sampler_configs3", lambda: sampler_configs3(dev, a.precision if a.precision != "fp32" else "bf16"))
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C, a.size, DEFAULT_CFG)
+            out["cpu_baseline"] = _leg(out, "cpu_baseline", lambda: cpu_baseline(C, a.size, DEFAULT_CFG))
         else:
             out["cpu_baseline"] = None
         emit(json_fd, out)

@@ -215,3 +215,20 @@ def test_emit_writes_extras_to_a_file_and_one_line_to_the_descriptor(tmp_path, m
     assert data.count(b"\n") == 1 and len(data) < 6144
     assert json.loads(data)["roofline"]["frac"] == full["roofline"]["frac"]
     assert json.load(open(tmp_path / "x" / "extras.json"))["by_kernel"] == full["by_kernel"]
+
+
+def test_a_failing_extra_leg_is_reported_and_the_record_survives(capsys):
+    import json
+    out = dict(value=1.0)
+
+    def boom():
+        raise RuntimeError("out of memory in an extra leg")
+    assert bench._leg(out, "deep_variant", boom) is None
+    assert bench._leg(out, "fine", lambda: 7) == 7
+    assert out["errors"] == {"deep_variant": "RuntimeError: out of memory in an extra leg"}
+    assert "extra leg 'deep_variant' failed" in capsys.readouterr().err
+    full = _fake_full_result()
+    full["errors"] = out["errors"]
+    full["deep_variant"] = None
+    d = json.loads(bench.compact_line(full, "x.json"))
+    assert d["extra_legs_failed"] == ["deep_variant"] and d["value"] == full["value"] and d["roofline"]["frac"]
