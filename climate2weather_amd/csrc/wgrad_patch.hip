@@ -64,6 +64,7 @@ struct WpArgs {
 // splits K over 256 / tilesMN workgroups to fill the chip (8 K tiles per workgroup at 8x8, each followed by 295 KB of partial sums);
 // together the layers fill it with a fraction of the splits.  The per-layer pointers ride in the kernel arguments and are read through the
 // kernarg segment with a workgroup-uniform index (scalar loads; a by-value array indexed dynamically would be copied to scratch).
+// Layer = position in the grid-wide XCD-contiguous order / workgroups per layer.
 struct WpItem {
     const void* dy;
     const void* x;
@@ -74,10 +75,7 @@ constexpr int WP_MAX_ITEMS = 16;
 struct WpGroupArgs {
     WpArgs c;             // geometry, split plan, ws = base of the group's workspace; dy / x / dw / db unused
     int n;                // layers
-    int blocks_per_item;  // tilesMN * nsplit rounded up to a multiple of 8 (so that blockIdx & 7 labels the XCD inside every layer's range too)
-    int live_per_item;    // tilesMN * nsplit: blocks past it exit.  The tile order is derived from THIS count: derived from the padded one,
-                          // all padding blocks of every layer fall on the last XCD (round 5, first version: the 64x64 group ran 252
-                          // workgroups on 7 of the 8 XCDs = two rounds, 1476 us instead of ~800)
+    int live_per_item;    // workgroups per layer = tilesMN * nsplit; the grid is n * live_per_item
     unsigned long long ws_item_floats;
     WpItem item[WP_MAX_ITEMS];
 };
@@ -100,8 +98,14 @@ __device__ __forceinline__ uint32_t swzP(int pix) { return (uint32_t)((((pix >> 
 // NARROW (16-bit only): at most 80 output channels (the network's output conv, 65).  The co-tile halves then go to waves 0-3 / 4-7
 // instead of even / odd waves -- every SIMD hosts one wave of each -- and waves 4-7 compute only their first co tile (channels 64-79):
 // 45 instead of 72 MFMAs per SIMD and K step; the dY rows past Cout were never fetched anyway (out-of-range lanes of the LDS-DMA).
+__device__ __forceinline__ int wp_xcd_order(int bid, int nblk) {  // block -> position in an order that is contiguous per XCD (blocks b, b + 8, ... share one)
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// L: the workgroup's position in the (split, output tile) order of ONE layer
 template <typename T, bool PAIR = false, bool NARROW = false>
-__device__ __forceinline__ void wgrad_patch_body(const WpArgs& p, const int bid, const int nblk) {
+__device__ __forceinline__ void wgrad_patch_body(const WpArgs& p, const int L) {
     constexpr int ESZ = sizeof(T);
     constexpr bool BF = ESZ == 2;
     constexpr int COT = 256 / ESZ;       // output channels per workgroup tile
@@ -120,11 +124,6 @@ __device__ __forceinline__ void wgrad_patch_body(const WpArgs& p, const int bid,
     const int ncib = p.Cin / CIB;
     const int tilesM = (p.Cout + COT - 1) / COT;
     const int tilesMN = tilesM * ncib;
-    int L;
-    {
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     const int split = L / tilesMN, mn = L - split * tilesMN;
     const int tm = mn / ncib, cb = mn - tm * ncib;
     const int co0 = tm * COT, ci0 = cb * CIB;
@@ -429,7 +428,7 @@ __device__ __forceinline__ void wgrad_patch_body(const WpArgs& p, const int bid,
 
 template <typename T, bool PAIR = false, bool NARROW = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_kernel(const WpArgs p) {
-    wgrad_patch_body<T, PAIR, NARROW>(p, (int)blockIdx.x, (int)gridDim.x);
+    wgrad_patch_body<T, PAIR, NARROW>(p, wp_xcd_order((int)blockIdx.x, (int)gridDim.x));
 }
 
 typedef __attribute__((address_space(4))) const char wp_kernarg_t;
@@ -446,9 +445,11 @@ __device__ __forceinline__ WpItem wp_item(int it) {  // it: workgroup-uniform
 
 template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_group_kernel(const WpGroupArgs g) {
-    const int it = __builtin_amdgcn_readfirstlane((int)blockIdx.x / g.blocks_per_item);
-    const int bid = (int)blockIdx.x - it * g.blocks_per_item;
-    if (bid >= g.live_per_item) return;
+    // the XCD-contiguous order runs over the WHOLE grid: per-layer orders (first version) left the remainder blocks of every layer on
+    // the same one or two XCDs -- 36 workgroups on 32 CUs there, 30 elsewhere: two rounds for the 64x64 group (1350 us instead of ~750)
+    const int Lg = wp_xcd_order((int)blockIdx.x, (int)gridDim.x);
+    const int it = __builtin_amdgcn_readfirstlane(Lg / g.live_per_item);
+    const int L = Lg - it * g.live_per_item;
     const WpItem e = wp_item(it);
     WpArgs p = g.c;
     p.dy = e.dy;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_patch_group_kernel(const Wp
     p.dw = e.dw;
     p.db = e.db;
     p.ws = g.c.ws != nullptr ? g.c.ws + (size_t)it * g.ws_item_floats : nullptr;
-    wgrad_patch_body<T, PAIR, false>(p, bid, g.live_per_item);
+    wgrad_patch_body<T, PAIR, false>(p, L);
 }
 
 // dw[co][tap][ci] += sum over splits of ws[split][tile][tap][row][col].  RC float4 columns x RG split groups per block (RC * RG =
@@ -619,7 +620,6 @@ int launch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* 
     p.direct = nsplit == 1 ? 1 : 0;
     g.n = n;
     g.live_per_item = tilesMN * nsplit;
-    g.blocks_per_item = (g.live_per_item + 7) & ~7;
     g.ws_item_floats = item_floats;
     for (int i = 0; i < WP_MAX_ITEMS; ++i) {
         const C2wWgradItem& e = items[i < n ? i : n - 1];
@@ -630,7 +630,7 @@ int launch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* 
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_patch_group_kernel<T, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    wgrad_patch_group_kernel<T, PAIR><<<g.blocks_per_item * n, NTHREADS, LDS_BYTES, st>>>(g);
+    wgrad_patch_group_kernel<T, PAIR><<<g.live_per_item * n, NTHREADS, LDS_BYTES, st>>>(g);
     if (p.ws != nullptr) {
         const size_t per_split = (size_t)tilesMN * 9 * COT * CIB;
         const int grid = (int)std::min<size_t>((per_split / 4 + C2W_RED_COLS - 1) / C2W_RED_COLS, 8192);

@@ -232,11 +232,10 @@ class Engine:
         # Weight gradients of the residual-block convs are collected per geometry during the backward and launched together at the
         # level boundaries (ops.conv_wgrad_grouped: the 6 or 12 layers of a level side share one shape).  C2W_WGRAD_GROUP=0: one
         # launch per layer (rounds 1-4); =N: only levels whose grid is at most N pixels high (default 64); =1: every level.
-        # Measured at B = 128 (profiles/r05_experiments.md): 64 and 0 give the same step (48.2 ms) -- below 128x128 the per-layer
-        # launches were hidden beside the other stream's launches, the grouped ones need a third of the launches and of the partial
-        # sums; at 128x128 a group is 252 workgroups that hold their CUs (160 KB of LDS each) for 3 ms and starve the input-gradient
-        # stream: +3.0 ms per step.
-        self.keep_ln_stats = os.environ.get("C2W_NO_LN_STATS") != "1"  # A/B knob: fused LayerNorms hand their 1/sigma to the backward
+        # Measured at B = 128 (profiles/r05_experiments.md section 2): 64 is 0.13 ms per step ahead of 0 -- below 128x128 the per-layer
+        # launches were mostly hidden beside the other queue's; grouped, they need a third of the launches and of the partial sums.
+        # At 128x128 a group is neutral when it is launched at the level boundary and costs 0.9 ms when it is enqueued in front of
+        # the side's last input gradient (252 workgroups that hold their CUs for 3 ms).
         _grp = os.environ.get("C2W_WGRAD_GROUP", "64")
         self.group_wgrads = _grp != "0"
         self.group_wgrads_max_side = int(_grp) if _grp.isdigit() and int(_grp) > 1 else 1 << 30
