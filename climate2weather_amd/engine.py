@@ -236,6 +236,7 @@ class Engine:
         # launches were mostly hidden beside the other queue's; grouped, they need a third of the launches and of the partial sums.
         # At 128x128 a group is neutral when it is launched at the level boundary and costs 0.9 ms when it is enqueued in front of
         # the side's last input gradient (252 workgroups that hold their CUs for 3 ms).
+        self.keep_ln_stats = os.environ.get("C2W_NO_LN_STATS") != "1"  # A/B knob: fused LayerNorms hand their 1/sigma to the backward
         _grp = os.environ.get("C2W_WGRAD_GROUP", "64")
         self.group_wgrads = _grp != "0"
         self.group_wgrads_max_side = int(_grp) if _grp.isdigit() and int(_grp) > 1 else 1 << 30
