@@ -227,8 +227,10 @@ class Engine:
         # C2W_WGRAD_STREAM=0 (read once, here; or set the attribute): weight gradients on the caller's stream, every kernel alone on the
         # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
         self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
-        self._wgrad_behind = os.environ.get("C2W_WGRAD_BEHIND") == "1"  # A/B knob: weight gradients one layer behind
-        self._wg_pending = None
+        # A/B knob: gradient-stream launches are enqueued N calls late (1: behind the layer's own input gradient; 2: a
+        # residual block's two weight gradients during the next block; ...)
+        self._wgrad_behind = max(0, int(os.environ.get("C2W_WGRAD_BEHIND", "0") or 0))
+        self._wg_pending = []
         # Weight gradients of the residual-block convs are collected per geometry during the backward and launched together at the
         # level boundaries (ops.conv_wgrad_grouped: the 6 or 12 layers of a level side share one shape).  C2W_WGRAD_GROUP=0: one
         # launch per layer (rounds 1-4); =N: only levels whose grid is at most N pixels high (default 64); =1: every level.
@@ -543,7 +545,9 @@ class Engine:
             return None
         if self._wg_stream is None or self._wg_stream.device != self.flat.device:
             from .streams import independent_stream
-            self._wg_stream = independent_stream(self.flat.device)  # on another hardware queue than the caller's stream (streams.py)
+            # on another hardware queue than the caller's stream (streams.py); C2W_GRAD_STREAM_PRIORITY: A/B knob (HIP: -1 high, 0 normal,
+            # 1 low where the runtime offers it)
+            self._wg_stream = independent_stream(self.flat.device, priority=int(os.environ.get("C2W_GRAD_STREAM_PRIORITY", "0")))
         return self._wg_stream
 
     def publish(self, scalar: torch.Tensor):
@@ -568,10 +572,10 @@ class Engine:
         if side is None:
             fn()
             return
-        if self._wgrad_behind:  # experiment knob: this launch is enqueued at the NEXT call, i.e. behind the input gradient issued in between
-            pending, self._wg_pending = self._wg_pending, (fn, tensors)
-            if pending is not None:
-                self._issue_on(side, *pending)
+        if self._wgrad_behind:  # experiment knob: this launch is enqueued N calls later, i.e. behind the input gradients issued in between
+            self._wg_pending.append((fn, tensors))
+            while len(self._wg_pending) > self._wgrad_behind:
+                self._issue_on(side, *self._wg_pending.pop(0))
             return
         self._issue_on(side, fn, tensors)
 
@@ -588,9 +592,8 @@ class Engine:
         self.flush_wgrad_groups()
         side = self.grad_stream()
         if side is not None:
-            if self._wg_pending is not None:
-                pending, self._wg_pending = self._wg_pending, None
-                self._issue_on(side, *pending)
+            while self._wg_pending:
+                self._issue_on(side, *self._wg_pending.pop(0))
             torch.cuda.current_stream().wait_stream(side)
 
     def workspace(self, min_bytes: int = 0) -> Optional[torch.Tensor]:

@@ -163,6 +163,21 @@ class Trainer:
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, batches, t: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimizer step (``_step``).  C2W_MAIN_PRIORITY=-1 (A/B knob, read per call): the whole step runs on a high-priority HIP
+        stream of the trainer's own, so that the forward / input-gradient chain wins CUs over the weight-gradient stream."""
+        if os.environ.get("C2W_MAIN_PRIORITY") == "-1" and self.eng.flat.is_cuda:
+            hp = self.__dict__.get("_hp_stream")
+            if hp is None:
+                hp = self.__dict__["_hp_stream"] = torch.cuda.Stream(device=self.eng.flat.device, priority=-1)
+            cur = torch.cuda.current_stream()
+            hp.wait_stream(cur)
+            with torch.cuda.stream(hp):
+                loss = self._step(batches, t, eps)
+            cur.wait_stream(hp)
+            return loss
+        return self._step(batches, t, eps)
+
+    def _step(self, batches, t: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``batches``: one (B,C,H,W) fp32 GPU tensor (or data.WindowBatch), or a list of them = gradient-accumulation rounds
         (training_loop.py:373-378: gradients of the rounds are summed, only the last round synchronises).
         ``t`` (B,) and ``eps`` (B,C,H,W) may be injected (tests); otherwise drawn as src/thor/pipelines.py:29-31 does.
