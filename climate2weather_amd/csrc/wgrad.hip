@@ -39,8 +39,32 @@ struct WgradArgs {
 
 __device__ __forceinline__ uint32_t swz(int row) { return (uint32_t)(((row & 3) << 2) | ((row >> 2) & 3)); }
 
+// Grouped launch (round 5): the weight gradients of up to WG_MAX_ITEMS layers of ONE geometry as one grid -- the six qkv / six proj_out
+// 1x1 convs of the attention level (model/nn.py:45,47), whose per-layer launches split 128 K stages over 10-20 workgroups each and run at
+// 0.05-0.11 of peak.  Same scheme as wgrad_patch_group_kernel: per-layer pointers in the kernel arguments, read through the kernarg
+// segment with a workgroup-uniform index; layer = position in the grid-wide XCD-contiguous order / workgroups per layer.
+struct WgItem {
+    const void* dy;
+    const void* x;
+    float* dw;
+    float* db;
+};
+constexpr int WG_MAX_ITEMS = 16;
+struct WgradGroupArgs {
+    WgradArgs c;  // geometry, split plan, ws = base of the group's workspace
+    int n, live_per_item;
+    unsigned long long ws_item_floats;
+    WgItem item[WG_MAX_ITEMS];
+};
+
+__device__ __forceinline__ int wg_xcd_order(int bid, int nblk) {
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// L: the workgroup's position in the (split, output tile) order of one layer
 template <typename T, int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int L) {
     constexpr int ESZ = sizeof(T);
     constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
     constexpr int COT = 256 / ESZ;  // output channels per block tile
@@ -61,11 +85,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
     const int tilesN = (nb_total + 3) / 4;
     const int tilesM = (p.Cout + COT - 1) / COT;
     const int tilesMN = tilesM * tilesN;
-    int L;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     const int split = L / tilesMN, mn = L - split * tilesMN;
     const int tm = mn / tilesN, tn = mn - tm * tilesN;
     const int co0 = tm * COT;
@@ -287,10 +306,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs p) {
+    wgrad_body<T, MODE>(p, wg_xcd_order((int)blockIdx.x, (int)gridDim.x));
+}
+
+__device__ __forceinline__ WgItem wg_item(int it) {  // it: workgroup-uniform
+    typedef __attribute__((address_space(4))) const char karg_t;
+    const WgItem __attribute__((address_space(4)))* tab =
+        (const WgItem __attribute__((address_space(4)))*)((karg_t*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgradGroupArgs, item));
+    WgItem r;
+    r.dy = tab[it].dy;
+    r.x = tab[it].x;
+    r.dw = tab[it].dw;
+    r.db = tab[it].db;
+    return r;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgradGroupArgs g) {
+    const int Lg = wg_xcd_order((int)blockIdx.x, (int)gridDim.x);
+    const int it = __builtin_amdgcn_readfirstlane(Lg / g.live_per_item);
+    const WgItem e = wg_item(it);
+    WgradArgs p = g.c;
+    p.dy = e.dy;
+    p.x = e.x;
+    p.dw = e.dw;
+    p.db = e.db;
+    p.ws = g.c.ws != nullptr ? g.c.ws + (size_t)it * g.ws_item_floats : nullptr;
+    wgrad_body<T, MODE>(p, Lg - it * g.live_per_item);
+}
+
 // dw += sum over splits of the partial tiles (same 64 x 4 layout of a block as wgrad_reduce_kernel in wgrad_patch.hip)
 template <int COT, int CIB, int NT>
-__global__ __launch_bounds__(256) void wgrad_gather_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesM,
-                                                                  int tilesN, int Cin, int Cout) {
+__device__ __forceinline__ void wgrad_gather_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesM,
+                                                         int tilesN, int Cin, int Cout) {
     constexpr int NCOL = 4 * CIB;
     __shared__ f32x4_t red[4][64];
     const size_t per4 = (size_t)tilesM * tilesN * COT * NCOL / 4;
@@ -326,6 +376,18 @@ __global__ __launch_bounds__(256) void wgrad_gather_reduce_kernel(const float* _
         }
         __syncthreads();
     }
+}
+
+template <int COT, int CIB, int NT>
+__global__ __launch_bounds__(256) void wgrad_gather_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int tilesM,
+                                                                  int tilesN, int Cin, int Cout) {
+    wgrad_gather_reduce_body<COT, CIB, NT>(ws, dw, nsplit, tilesM, tilesN, Cin, Cout);
+}
+template <int COT, int CIB, int NT>
+__global__ __launch_bounds__(256) void wgrad_gather_reduce_group_kernel(const WgradGroupArgs g, int nsplit, int tilesM, int tilesN) {
+    const int it = (int)blockIdx.y;
+    const WgItem e = wg_item(it);
+    wgrad_gather_reduce_body<COT, CIB, NT>(g.c.ws + (size_t)it * g.ws_item_floats, e.dw, nsplit, tilesM, tilesN, g.c.Cin, g.c.Cout);
 }
 
 FastDiv make_div(uint32_t d) {
@@ -407,6 +469,68 @@ int launch_dtype(const C2wConvArgs& a, float* dw, float* db, float* ws, size_t w
     return C2W_ERR_BAD_ARG;
 }
 
+// Split plan of a group: as many splits as bring the whole grid to ~one resident round (2 workgroups per CU), never more than the K stages
+static void gather_group_plan(int n, int tilesMN, int nkt, int& nsplit, int& per) {
+    nsplit = 480 / (n * tilesMN);
+    if (nsplit > nkt) nsplit = nkt;
+    if (nsplit < 1) nsplit = 1;
+    per = (nkt + nsplit - 1) / nsplit;
+    nsplit = (nkt + per - 1) / per;
+}
+
+template <int ESZ, int NT>
+static size_t gather_group_ws_need(const C2wConvArgs& a, int n) {
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    int tilesM, tilesN, ns1, per1, nsplit, per;
+    split_plan<ESZ, NT>(a, tilesM, tilesN, ns1, per1);
+    const long long npix = (long long)a.B * a.Hout * a.Wout;
+    gather_group_plan(n, tilesM * tilesN, (int)((npix + KT - 1) / KT), nsplit, per);
+    return nsplit > 1 ? (size_t)n * nsplit * tilesM * tilesN * COT * 4 * CIB * sizeof(float) : 0;
+}
+
+template <typename T, int MODE>
+int launch_group(const C2wConvArgs& a, const C2wWgradItem* items, int n, float* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int NT = (MODE == C2W_CONV_1X1) ? 1 : 9;
+    constexpr int COT = 256 / ESZ, CIB = 128 / ESZ;
+    WgradGroupArgs g;
+    WgradArgs& p = g.c;
+    p.dy = nullptr; p.x = nullptr; p.dw = nullptr; p.db = nullptr;
+    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Cin = a.Cin; p.Hout = a.Hout; p.Wout = a.Wout; p.Cout = a.Cout; p.ldy = a.ldy;
+    int tilesM, tilesN, ns1, per1;
+    split_plan<ESZ, NT>(a, tilesM, tilesN, ns1, per1);
+    const int tilesMN = tilesM * tilesN;
+    const long long npix = (long long)a.B * a.Hout * a.Wout;
+    gather_group_plan(n, tilesMN, (int)((npix + KT - 1) / KT), p.nsplit, p.ktiles_per_split);
+    p.div_hw = make_div((uint32_t)(a.Hout * a.Wout));
+    p.div_w = make_div((uint32_t)a.Wout);
+    const size_t item_floats = (size_t)p.nsplit * tilesMN * COT * 4 * CIB;
+    if (p.nsplit > 1 && (ws == nullptr || (size_t)n * item_floats * sizeof(float) > ws_bytes)) return C2W_ERR_BAD_ARG;
+    p.ws = p.nsplit > 1 ? ws : nullptr;  // no split: one workgroup per output tile, its atomics onto dw have no partner (deterministic)
+    g.n = n;
+    g.live_per_item = tilesMN * p.nsplit;
+    g.ws_item_floats = item_floats;
+    for (int i = 0; i < WG_MAX_ITEMS; ++i) {
+        const C2wWgradItem& e = items[i < n ? i : n - 1];
+        g.item[i].dy = e.dy; g.item[i].x = e.x; g.item[i].dw = e.dw; g.item[i].db = e.dbias;
+    }
+    constexpr int lds_main = NSLOT * (ABYTES + BBYTES);
+    constexpr int lds_epi = COT * (4 * CIB + 4) * 4;
+    constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)wgrad_group_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    wgrad_group_kernel<T, MODE><<<g.live_per_item * n, NTHREADS, lds, st>>>(g);
+    if (p.ws != nullptr) {
+        const size_t per4 = (size_t)tilesMN * COT * 4 * CIB / 4;
+        const int grid = (int)((per4 + 63) / 64 < 4096 ? (per4 + 63) / 64 : 4096);
+        wgrad_gather_reduce_group_kernel<COT, CIB, NT><<<dim3(grid, n), 256, 0, st>>>(g, p.nsplit, tilesM, tilesN);
+    }
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // Geometry is passed with the forward call's argument block: x = the forward input, y = dY (gradient w.r.t. the forward
@@ -438,16 +562,23 @@ extern "C" int c2w_conv_wgrad(const C2wConvArgs* a, float* dw, float* dbias, voi
     return launch_dtype<f16_t>(*a, dw, dbias, ws, wsb, st);
 }
 
+// the 1x1 layers (Conv1d(k = 1) / Linear: model/nn.py:45,47) group on the gather kernel
+static bool gather_group_eligible(const C2wConvArgs& a, int n) {
+    return a.mode == C2W_CONV_1X1 && n >= 2 && n <= WG_MAX_ITEMS && !c2w_knobs().wgrad_atomics;
+}
+
 extern "C" int c2w_conv_wgrad_grouped_supported(const C2wConvArgs* a, int n, int dtype) {
     if (wgrad_check(a, dtype) != 0) return 0;
-    return c2w_wgrad_patch_group_eligible(*a, n, dtype) && !c2w_knobs().force_gather ? 1 : 0;
+    if (c2w_wgrad_patch_group_eligible(*a, n, dtype) && !c2w_knobs().force_gather) return 1;
+    return gather_group_eligible(*a, n) ? 1 : 0;
 }
 
 extern "C" long long c2w_conv_wgrad_grouped_workspace_bytes(const C2wConvArgs* a, int n, int dtype) {
     const int rc = wgrad_check(a, dtype);
     if (rc != 0) return rc;
     if (!c2w_conv_wgrad_grouped_supported(a, n, dtype)) return C2W_ERR_UNSUPPORTED;
-    return (long long)c2w_wgrad_patch_group_ws_bytes(*a, n, dtype);
+    if (c2w_wgrad_patch_group_eligible(*a, n, dtype) && !c2w_knobs().force_gather) return (long long)c2w_wgrad_patch_group_ws_bytes(*a, n, dtype);
+    return (long long)(dtype == C2W_DTYPE_F32 ? gather_group_ws_need<4, 1>(*a, n) : gather_group_ws_need<2, 1>(*a, n));
 }
 
 extern "C" int c2w_conv_wgrad_grouped(const C2wConvArgs* a, const C2wWgradItem* items, int n, void* workspace, unsigned long long workspace_bytes,
@@ -458,7 +589,13 @@ extern "C" int c2w_conv_wgrad_grouped(const C2wConvArgs* a, const C2wWgradItem* 
     for (int i = 0; i < n; ++i)
         if (items[i].x == nullptr || items[i].dy == nullptr || items[i].dw == nullptr) return C2W_ERR_BAD_ARG;
     if (!c2w_conv_wgrad_grouped_supported(a, n, dtype)) return C2W_ERR_UNSUPPORTED;
-    return c2w_wgrad_patch_group(*a, items, n, (float*)workspace, workspace == nullptr ? 0 : (size_t)workspace_bytes, dtype, (hipStream_t)stream);
+    float* const ws = (float*)workspace;
+    const size_t wsb = workspace == nullptr ? 0 : (size_t)workspace_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    if (c2w_wgrad_patch_group_eligible(*a, n, dtype) && !c2w_knobs().force_gather) return c2w_wgrad_patch_group(*a, items, n, ws, wsb, dtype, st);
+    if (dtype == C2W_DTYPE_F32) return launch_group<float, C2W_CONV_1X1>(*a, items, n, ws, wsb, st);
+    if (dtype == C2W_DTYPE_BF16) return launch_group<bf16_t, C2W_CONV_1X1>(*a, items, n, ws, wsb, st);
+    return launch_group<f16_t, C2W_CONV_1X1>(*a, items, n, ws, wsb, st);
 }
 
 extern "C" int c2w_conv_wgrad_dispatch(const C2wConvArgs* a, int dtype) {

@@ -234,7 +234,7 @@ class Engine:
         # Weight gradients of the residual-block convs are collected per geometry during the backward and launched together at the
         # level boundaries (ops.conv_wgrad_grouped: the 6 or 12 layers of a level side share one shape).  C2W_WGRAD_GROUP=0: one
         # launch per layer (rounds 1-4); =N: only levels whose grid is at most N pixels high (default 64); =1: every level.
-        # Measured at B = 128 (profiles/r05_experiments.md section 2): 64 is 0.13 ms per step ahead of 0 -- below 128x128 the per-layer
+        # Measured at B = 128 (profiles/r05_experiments.md section 2): 64 is 0.32 ms per step ahead of 0 -- below 128x128 the per-layer
         # launches were mostly hidden beside the other queue's; grouped, they need a third of the launches and of the partial sums.
         # At 128x128 a group is neutral when it is launched at the level boundary and costs 0.9 ms when it is enqueued in front of
         # the side's last input gradient (252 workgroups that hold their CUs for 3 ms).
@@ -616,7 +616,10 @@ class Engine:
         queued and launched with the others at the next flush_wgrad_groups()."""
         if self._skip_dw:
             return
-        cap = 16 if g["Hout"] <= self.group_wgrads_max_side else self.group_wgrads_top
+        # "up to N x N grids" is meant at the reference's batch of 128 per GPU: what decides is the layer's K extent (B x H x W pixels;
+        # the deep variant's 128x128 level at B = 32 is the default network's 64x64 level at B = 128)
+        small = g["B"] * g["Hout"] * g["Wout"] <= 128 * self.group_wgrads_max_side ** 2
+        cap = 16 if small else self.group_wgrads_top
         if group and self.group_wgrads and cap > 1:
             key = (g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"], g["mode"], dt, ops.KNOBS_GENERATION)
             ok = self._wg_group_ok.get(key)
@@ -925,13 +928,13 @@ class Engine:
             ops.conv(o, self._w(rp, dt), self._b(rp), out, gp, dt, res=xin)
             if train:
                 def bw(gy):
-                    self._wg(o, gy, rp, gp, dt)
+                    self._wg(o, gy, rp, gp, dt, group=True)  # the six proj_out / six qkv weight gradients of the level: one launch each
                     do = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(gy, self._wT(rp, dt), None, do, self._geom(npix, 1, 1, Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
                     dqkv = torch.empty_like(qkv)
                     delta = torch.empty((npix,), dtype=torch.float32, device=dev)
                     ops.attention_backward(qkv, o, do, lse, delta, dqkv, B, Tn, Cc, dt)
-                    self._wg(hl, dqkv, rq, gq, dt)
+                    self._wg(hl, dqkv, rq, gq, dt, group=True)
                     dhl = torch.empty((npix, Cc), dtype=T, device=dev)
                     ops.conv(dqkv, self._wT(rq, dt), None, dhl, self._geom(npix, 1, 1, 3 * Cc, 1, 1, Cc, Cc, Cc, CONV_1X1), dt)
                     tape.done(rq.w_off)

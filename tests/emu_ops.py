@@ -196,7 +196,7 @@ def conv_wgrad(x, dy, dw, g, dtype, dbias=None, workspace=None):
 
 
 def conv_wgrad_grouped_supported(g, n, dtype):
-    return conv_patch_supported(g, dtype) and 2 <= n <= 16  # (the library also excludes the narrow-M form, Cout <= 80: a speed choice)
+    return (conv_patch_supported(g, dtype) or g["mode"] == CONV_1X1) and 2 <= n <= 16  # (the library also excludes the narrow-M form, Cout <= 80)
 
 
 def conv_wgrad_grouped_workspace_bytes(g, n, dtype):

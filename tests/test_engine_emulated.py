@@ -363,7 +363,9 @@ def test_weight_gradients_of_a_level_go_out_together_and_done_waits_for_them(emu
 
     g1, seen1, launches1 = run(True)
     g0, seen0, launches0 = run(False)
-    assert launches0 == [] and launches1 == [(32, 2), (16, 4), (32, 2)], launches1  # ascent 0 | both sides of level 1 | descent 0
+    # ascent 0 | level 1, both sides: its two attention blocks' proj_out and qkv 1x1 weight gradients (side "1": a 1x1 conv's pixels are rows), then
+    # the four 3x3 convs | descent 0
+    assert launches0 == [] and launches1 == [(32, 2), (1, 2), (1, 2), (16, 4), (32, 2)], launches1
     assert torch.equal(g0, g1)  # the emulation adds the same numbers in the same order either way
     for seen, final in ((seen1, g1), (seen0, g0)):
         offs = [o for o, _ in seen]

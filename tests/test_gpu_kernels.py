@@ -374,6 +374,8 @@ GROUP_CASES = [
     (ops.CONV_S1, 2, 32, 32, 128, 192, 2),          # partial second channel tile
     (ops.CONV_S1, 2, 16, 32, 64, 128, 16),          # the most layers one launch takes
     (ops.CONV_UP, 2, 8, 16, 128, 128, 2),           # upsampling folded into the patch load
+    (ops.CONV_1X1, 640, 1, 1, 128, 384, 6),         # attention qkv (model/nn.py:45) on the gather kernel: 10 K stages, 3 x 1 tiles, split
+    (ops.CONV_1X1, 96, 1, 1, 256, 256, 3),          # 2 K stages: no split (tiles added onto dw by single-adder atomics)
 ]
 
 
@@ -391,7 +393,8 @@ def test_conv_wgrad_grouped(case, dt):
     assert not ops.conv_wgrad_grouped_supported(g, 1, dt) and not ops.conv_wgrad_grouped_supported(g, 17, dt)
     xs = [rnd((B * Hin * Win, Cin), dt, 10 + i) for i in range(n)]
     dys = [rnd((B * Hout * Wout, Cout), dt, 40 + i) for i in range(n)]
-    pre = [rnd((Cout * 9 * Cin + 64,), F32, 70 + i, 0.1) for i in range(n)]  # dw holds a value already: the call accumulates
+    taps = 1 if mode == ops.CONV_1X1 else 9
+    pre = [rnd((Cout * taps * Cin + 64,), F32, 70 + i, 0.1) for i in range(n)]  # dw holds a value already: the call accumulates
     for t in pre:
         t[-64:] = 0
     dws = [t.clone() for t in pre]
