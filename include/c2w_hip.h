@@ -146,8 +146,9 @@ long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* args, int dtype);
  * chip (at 8x8: 8 K tiles per workgroup, each followed by 295 KB of partial sums), together the layers fill it with a fraction of
  * the splits.  `items` is a HOST array, copied into the kernel arguments (nothing is kept).  Results are deterministic (a fixed
  * reduction order) but differ in rounding from n single calls (another split of the same sum).
- * c2w_conv_wgrad_grouped_supported: 1 when the n layers run as one launch (halo-patch geometry, 2 <= n <= 16); otherwise the call
- * returns C2W_ERR_UNSUPPORTED and the caller issues n c2w_conv_wgrad calls.  workspace must hold
+ * c2w_conv_wgrad_grouped_supported: 1 when the n layers run as one launch (2 <= n <= 16; the halo-patch geometries on
+ * wgrad_patch_group_kernel, 1x1 layers -- the attention level's qkv / proj_out, model/nn.py:45,47 -- on wgrad_group_kernel); otherwise
+ * the call returns C2W_ERR_UNSUPPORTED and the caller issues n c2w_conv_wgrad calls.  workspace must hold
  * c2w_conv_wgrad_grouped_workspace_bytes(args, n, dtype) bytes (0 when the plan does not split). */
 typedef struct C2wWgradItem {
     const void* x;

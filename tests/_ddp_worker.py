@@ -223,7 +223,7 @@ def run_module_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: s
     dist.destroy_process_group()
 
 
-def run_five_strings_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: str):
+def run_five_strings_ddp(rank: int, world: int, port: int, golden_dir: str, out_dir: str, bucket_view: bool = False):
     """The reference's configuration: the module wrapped in torch DDP (fabric.setup_module, training_loop.py:116), the loop of
     training_loop.py:369-391, and all five seams pointing at this package -- in particular climate2weather_amd.optim.AdamW over the
     DDP-averaged gradients and SDAPipeline.loss as one autograd node called THROUGH the DDP wrapper.  Three steps; rank r sees item r
@@ -266,7 +266,8 @@ def run_five_strings_ddp(rank: int, world: int, port: int, golden_dir: str, out_
 
     torch.manual_seed(3)
     net = ScoreUNet(**cfg)
-    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    # bucket_view: p.grad become views of the reducer's buckets after the first step -- the drop-in AdamW gathers them and keeps its fused step
+    ddp = torch.nn.parallel.DistributedDataParallel(net, gradient_as_bucket_view=bucket_view)
     pipeline, optimizer, ema = Injected(), AdamW(params=net.parameters(), lr=1e-3, weight_decay=1e-3, betas=[0.9, 0.999]), StandardEMA(net=net)
     losses, fused = [], []
     for i in range(3):

@@ -939,14 +939,16 @@ def test_module_under_torch_ddp_matches_golden_gradients(golden_dir, tmp_path):
         assert not torch.equal(v, torch.from_numpy(g["sd." + k])) or v.numel() == 0  # the optimizer moved the weights
 
 
-def test_five_strings_under_torch_ddp_two_ranks(golden_dir, tmp_path):
+@pytest.mark.parametrize("bucket_view", [False, True])
+def test_five_strings_under_torch_ddp_two_ranks(golden_dir, tmp_path, bucket_view):
     """The reference's own configuration end to end on two gloo ranks: DDP-wrapped module, the loop of training_loop.py:369-391, fused
     SDAPipeline.loss called through the wrapper, climate2weather_amd.optim.AdamW on the DDP-averaged gradients (flat path), EMA.  The
     ranks stay identical and follow a single process that trains on the whole batch with torch.optim.AdamW and the reference's loss
-    arithmetic (mean over the batch of 2 = DDP's average of the per-rank means)."""
+    arithmetic (mean over the batch of 2 = DDP's average of the per-rank means).  bucket_view: DDP(gradient_as_bucket_view=True) -- the
+    gradients are then views of the reducer's buckets, not of one flat buffer, and the optimizer must still take its fused step."""
     import torch.multiprocessing as mp
     from _ddp_worker import run_five_strings_ddp
-    mp.spawn(run_five_strings_ddp, args=(2, _free_port(), golden_dir, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(run_five_strings_ddp, args=(2, _free_port(), golden_dir, str(tmp_path), bucket_view), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"five{r}.pt", weights_only=False) for r in (0, 1))
     assert r0["flat"] and r1["flat"] and all(r0["fused"]) and all(r1["fused"])
     assert np.allclose(0.5 * (np.array(r0["losses"]) + np.array(r1["losses"])), r0["ref_losses"], rtol=2e-5)
