@@ -222,11 +222,19 @@ class Engine:
         self._gwpad: Dict[str, torch.Tensor] = {}  # name -> padded fp32 weight-gradient scratch
         self._manual_ver = 0
         self._wg_stream = None  # second HIP stream for the weight-gradient launches (see _wg)
-        self.prefetch_dgrad = os.environ.get("C2W_NO_DG_PREFETCH") is None  # A/B knob, read once (here)
+        # Input-gradient operands rebuilt on the side stream beside the next forward: part of the two-stream mode (C2W_WGRAD_STREAM=1; round
+        # 4: -0.2 ms there).  On one stream -- the default -- a second active queue costs more than the 0.18 ms of passes it hides
+        # (46.74-46.83 against 46.91-47.01 ms per step): off unless C2W_DG_PREFETCH=1; C2W_NO_DG_PREFETCH=1 switches it off in either mode.
+        self.prefetch_dgrad = os.environ.get("C2W_NO_DG_PREFETCH") is None and \
+            (os.environ.get("C2W_WGRAD_STREAM", "0") == "1" or os.environ.get("C2W_DG_PREFETCH") == "1")
         self._dg_ready = None  # event behind input-gradient operands that were rebuilt on the gradient stream (prefetch_backward_operands)
         # C2W_WGRAD_STREAM=0 (read once, here; or set the attribute): weight gradients on the caller's stream, every kernel alone on the
         # chip -- what bench.py's by_kernel pass and the serialised rocprof runs use
-        self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM") != "0"
+        # Round 5: OFF by default.  With the weight gradients of a level grouped into one launch (below) every kernel fills the chip on its
+        # own, and two queues whose kernels cannot share a CU only cost each other (B = 128: 46.2 against 46.7 ms; B = 16 ... 64, 52
+        # channels, fp16 and the 256x256 variant: 0.1-0.45 ms per step, profiles/r05_experiments.md section 8).  Rounds 1-4 (per-layer
+        # launches) gained 2.4 ms from the second queue.  C2W_WGRAD_STREAM=1 restores it.
+        self.use_grad_stream = os.environ.get("C2W_WGRAD_STREAM", "0") == "1"
         # A/B knob: gradient-stream launches are enqueued N calls late (1: behind the layer's own input gradient; 2: a
         # residual block's two weight gradients during the next block; ...)
         self._wgrad_behind = max(0, int(os.environ.get("C2W_WGRAD_BEHIND", "0") or 0))
@@ -244,6 +252,7 @@ class Engine:
         self.group_wgrads_max_side = int(_grp) if _grp.isdigit() and int(_grp) > 1 else 1 << 30
         # above that side: groups of at most this many layers (1 = one launch per layer); C2W_WGRAD_GROUP_TOP (A/B)
         self.group_wgrads_top = max(1, int(os.environ.get("C2W_WGRAD_GROUP_TOP", "1")))
+        self._wg_serial_from = int(os.environ.get("C2W_WGRAD_SERIAL_FROM", "0") or 0)
         self._wg_groups: Dict[tuple, list] = {}  # (geometry, dtype) -> [(x, dY, record, geometry)] not launched yet
         self._wg_group_ok: Dict[tuple, bool] = {}
         self._done_release = None  # set by backward_steps: hands on the "done" offsets held back while a group was pending
@@ -496,7 +505,7 @@ class Engine:
         asked for) NOW, on the gradient stream, behind everything enqueued so far on the current stream (= the optimizer's update):
         0.18 ms of HBM-bound passes that then run next to the following forward's matrix-core launches instead of in front of the
         backward.  ``backward`` waits for them (``_dg_ready``); without a gradient stream nothing happens and backward builds them itself."""
-        side = self.grad_stream() if self.prefetch_dgrad else None
+        side = self.side_stream() if self.prefetch_dgrad else None
         if side is None:
             return
         self.refresh_version()
@@ -536,12 +545,20 @@ class Engine:
 
     # ------------------------------------------------------------------ weight gradients on a second stream
     def grad_stream(self):
-        """The stream every write into ``flat_grad`` is enqueued on, or None (CPU tensors / ``use_grad_stream`` off: the current
-        stream).  A layer's weight gradient and its input gradient both depend only on the layer's output gradient; on one
-        stream they run back to back and the chip idles through every kernel's last round of workgroups, the 27-us split-K
-        reduction launches and the launch gaps.  On two streams the hardware dispatcher fills those holes with the other
-        stream's workgroups (the LDS footprints forbid real co-residency: 127 KB + 2 x 70.7 KB > 160 KB)."""
+        """The stream every write into ``flat_grad`` is enqueued on, or None (CPU tensors / ``use_grad_stream`` off, the default since
+        round 5: the current stream).  A layer's weight gradient and its input gradient both depend only on the layer's output
+        gradient; with one launch per layer (rounds 1-4) the chip idled through every kernel's last round of workgroups, the split-K
+        reduction launches and the launch gaps on one stream, and a second stream filled those holes (the LDS footprints forbid real
+        co-residency: 160 KB + 2 x 71.7 KB > 160 KB).  Grouped launches leave no such holes."""
         if self.flat is None or not self.flat.is_cuda or not self.use_grad_stream:
+            return None
+        return self.side_stream()
+
+    def side_stream(self):
+        """A second HIP stream on another hardware queue than the caller's (streams.py), or None on the CPU: the gradient stream when
+        ``use_grad_stream`` is on, and in any case where the next backward's operands are rebuilt beside the forward
+        (prefetch_backward_operands)."""
+        if self.flat is None or not self.flat.is_cuda:
             return None
         if self._wg_stream is None or self._wg_stream.device != self.flat.device:
             from .streams import independent_stream
@@ -633,6 +650,11 @@ class Engine:
                     if not self._wg_groups and self._done_release is not None:
                         self._done_release()
                 return
+        if self._wg_serial_from and g["B"] * g["Hout"] * g["Wout"] >= 128 * self._wg_serial_from ** 2:
+            # A/B knob C2W_WGRAD_SERIAL_FROM=N: weight gradients of levels from N x N (at B = 128) on the CALLER's stream, i.e. strictly
+            # between the input gradients; only the smaller levels go to the gradient stream
+            ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace())
+            return
         self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
 
     def _flush_group(self, key: tuple) -> None:

@@ -375,7 +375,7 @@ def test_two_stream_backward_reproduces_every_conv_weight_gradient_bit_for_bit()
     t = torch.rand(B, generator=gen).cuda()
     eps = torch.randn(B, C, H, H, generator=gen).cuda()
     tr = Trainer(net, precision="bf16", ema_rates=())
-    assert tr.eng.use_grad_stream
+    tr.eng.use_grad_stream = True  # both forms: the second queue (the default of rounds 1-4) is where a race between the streams would show
     convs = [(n, p) for n, p in net.named_parameters() if p.dim() == 4]
     assert len(convs) == 70
     ref = None
