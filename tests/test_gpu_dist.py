@@ -99,7 +99,7 @@ def test_bf16_wire_format_of_the_gradient_all_reduce_over_rccl(golden_dir, tmp_p
 @pytest.mark.parametrize("world", [1, pytest.param(2, marks=two_gpus)])
 def test_full_size_bf16_steps_through_an_rccl_communicator(tmp_path, world):
     """The bench's network and precision through RCCL (one rank on every box, two where two GPUs are visible): 12 buckets of 25 MB
-    all-reduced from the gradient stream per step, next to the real wgrad_patch / conv_patch launches; the weights follow the same
+    all-reduced from inside the backward per step, next to the real wgrad_patch / conv_patch launches; the weights follow the same
     steps taken without a process group."""
     import torch.multiprocessing as mp
     from _ddp_worker import run_full_size
@@ -107,7 +107,9 @@ def test_full_size_bf16_steps_through_an_rccl_communicator(tmp_path, world):
     outs = [torch.load(tmp_path / f"full{r}.pt", weights_only=False) for r in range(world)]
     for o in outs:
         d, p = o["dist"], o["plain"]
-        assert d["nb"] == 12 and d["all_reduces"] == 3 * 12 and d["on_side_stream"]
+        # since round 5 the backward runs on one stream by default: the collectives are issued from it (RCCL runs them on its own stream,
+        # beside the rest of the backward); C2W_WGRAD_STREAM=1 issues them from the gradient stream as rounds 1-4 did
+        assert d["nb"] == 12 and d["all_reduces"] == 3 * 12 and d["on_side_stream"] == (os.environ.get("C2W_WGRAD_STREAM") == "1")
         assert all(np.isfinite(d["losses"])) and all(np.isfinite(p["losses"]))
     if world == 1:  # a one-rank sum is the identity: the communicator must not change the step
         d, p = outs[0]["dist"], outs[0]["plain"]

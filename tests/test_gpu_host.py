@@ -627,12 +627,13 @@ def test_independent_stream_is_on_another_hardware_queue():
     if all(verdicts):
         pytest.skip("no plain stream shared the default stream's queue on this runtime: the premise could not be shown (the helper still works)")
     assert 1 <= verdicts.count(False) <= 8, verdicts  # some slots of the rotation, not a broken probe
-    # the engine's gradient stream is such a stream
+    # the engine's side stream (the gradient stream of the two-stream mode) is such a stream
     torch.manual_seed(0)
     net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
                     attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev)
     eng = net._get_engine()
-    assert overtakes(eng.grad_stream())
+    assert eng.grad_stream() is None  # one stream by default (round 5)
+    assert overtakes(eng.side_stream())
     torch.cuda.synchronize()
 
 
