@@ -252,7 +252,6 @@ class Engine:
         self.group_wgrads_max_side = int(_grp) if _grp.isdigit() and int(_grp) > 1 else 1 << 30
         # above that side: groups of at most this many layers (1 = one launch per layer); C2W_WGRAD_GROUP_TOP (A/B)
         self.group_wgrads_top = max(1, int(os.environ.get("C2W_WGRAD_GROUP_TOP", "1")))
-        self._wg_serial_from = int(os.environ.get("C2W_WGRAD_SERIAL_FROM", "0") or 0)
         self._wg_groups: Dict[tuple, list] = {}  # (geometry, dtype) -> [(x, dY, record, geometry)] not launched yet
         self._wg_group_ok: Dict[tuple, bool] = {}
         self._done_release = None  # set by backward_steps: hands on the "done" offsets held back while a group was pending
@@ -650,11 +649,6 @@ class Engine:
                     if not self._wg_groups and self._done_release is not None:
                         self._done_release()
                 return
-        if self._wg_serial_from and g["B"] * g["Hout"] * g["Wout"] >= 128 * self._wg_serial_from ** 2:
-            # A/B knob C2W_WGRAD_SERIAL_FROM=N: weight gradients of levels from N x N (at B = 128) on the CALLER's stream, i.e. strictly
-            # between the input gradients; only the smaller levels go to the gradient stream
-            ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace())
-            return
         self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
 
     def _flush_group(self, key: tuple) -> None:
