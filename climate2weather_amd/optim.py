@@ -164,7 +164,11 @@ class AdamW(torch.optim.Optimizer):
             return None
         flat = eng.ensure_grad_buffer()
         views = [torch.as_strided(flat, shape, strides, off) for off, shape, strides in eng.layout.views.values()]
-        torch._foreach_copy_(views, grads)
+        if hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_(views, grads)
+        else:  # older torch (the reference pins 2.1.2): per-tensor copies, still one fused step behind them
+            for v, g in zip(views, grads):
+                v.copy_(g)
         return flat
 
     def fused_path_active(self, gi: int = 0) -> bool:
