@@ -8,8 +8,11 @@ the API:
     eps is a counter-based (Philox) stream that the input-conversion and the loss kernels each regenerate from a per-step seed,
     so the (B, C, H, W) noise tensor is never written or read (``fused_noise=False`` or an injected ``eps`` restore the tensor);
   * gradients live in ONE flat fp32 buffer laid out in reverse finalisation order; while backward is still running,
-    finished buckets of it are all-reduced over xGMI on RCCL's stream (replaces Lightning Fabric's DDP wrapper,
-    training_loop.py:116,375-378) -- a sum; the 1/world_size mean is folded into the optimizer kernel;
+    finished buckets of it are all-reduced over xGMI (replaces Lightning Fabric's DDP wrapper, training_loop.py:116,375-378)
+    -- a sum; the 1/world_size mean is folded into the optimizer kernel.  Everything a bucket needs (the optional cast to the
+    bf16 wire format, the collective, the stream-side wait for it, the cast back, the optional chased update) is enqueued on a
+    COMMUNICATION stream of the trainer's own, ordered behind the bucket's last weight-gradient launch by an event; the compute
+    stream never waits for a collective before the end of the backward (``_on_progress`` / ``_finish_allreduce``);
   * AdamW (train.py:176-181) + EMA (src/thor/ema.py:23-27) + the 16-bit weight shadow refresh are one fused kernel;
   * precision "fp16" (the reference's own: Fabric "16-mixed", train.py:98) trains under a dynamic loss scale with
     torch.cuda.amp.GradScaler's rule (init 2^16, x2 every 2000 clean steps, /2 and skip the step on inf/nan) -- kept in
@@ -29,6 +32,15 @@ from . import ops
 from .engine import Tape
 from .ops import DTYPE_BF16, DTYPE_F16, DTYPE_F32, TORCH_DTYPE
 from .pipelines import SDAPipeline
+
+
+def _current_stream(device):
+    """(indirection: the emulated stream test swaps the two stream accessors)"""
+    return torch.cuda.current_stream(device)
+
+
+def _stream_ctx(stream):
+    return torch.cuda.stream(stream)
 
 
 class Trainer:
@@ -114,41 +126,65 @@ class Trainer:
 
     # ------------------------------------------------------------------ all-reduce and optimizer, both chasing the backward
     # The flat gradient buffer is laid out in reverse finalisation order, so what backward has finished is a growing SUFFIX.  Per
-    # 25-MB bucket of it, as soon as it is final: (multi-GPU) sum it over the ranks with RCCL, then run the fused AdamW + EMA + 16-bit
-    # shadow kernel on exactly that range -- both on the gradient stream, i.e. next to the rest of the backward instead of behind it
-    # (the update is a pure HBM stream of 7 arrays: 0.53 ms per step that the MFMA-bound input-gradient chain hides).  The rest of the
-    # backward never reads the flat parameters again (engine.Tape.progress), only its own copies of them.
+    # 25-MB bucket of it, as soon as it is final: (multi-GPU) sum it over the ranks with RCCL, then (opt-in) run the fused AdamW + EMA
+    # + 16-bit shadow kernel on exactly that range.  The rest of the backward never reads the flat parameters again
+    # (engine.Tape.progress), only its own copies of them.
+    #
+    # Streams.  The backward runs on ONE stream since round 5 (engine.use_grad_stream off): the weight gradients are written by the
+    # compute stream itself.  Nothing a bucket needs may be enqueued there -- with the bf16 wire format or the chased update the
+    # sequence contains a stream-side wait for the collective (work.wait()), and on the compute stream that wait would put every
+    # bucket's all-reduce (25 MB over xGMI: ~0.1-0.2 ms at 8 GPUs) on the input-gradient chain's critical path.  So the whole
+    # sequence goes to the communication stream (``_comm_stream``: the engine's side stream, on another hardware queue), which waits
+    # for an event the compute stream records behind the bucket's last weight-gradient launch (comm.wait_stream(compute)); the compute
+    # stream waits for the communication stream ONCE, behind the last bucket (``_finish_allreduce``).  With C2W_WGRAD_STREAM=1 (rounds
+    # 1-4) the gradient stream the weight gradients are written on IS the communication stream and stream order is the dependency.
+    def _comm_stream(self):
+        """The stream bucket collectives (and what surrounds them) are enqueued on; None: the caller's (CPU tensors, or no collective
+        and no second stream)."""
+        if not self.eng.flat.is_cuda:
+            return None
+        gs = self.eng.grad_stream()
+        if gs is not None:
+            return gs
+        return self.eng.side_stream() if self.sync_grads else None
+
     def _on_progress(self, off: int) -> None:
-        while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off:
-            s, e = self.buckets[self._next_bucket]
-            # issued from the stream the gradients are written on (engine.grad_stream): RCCL orders the collective behind the
-            # weight-gradient launches of this bucket without stalling the input-gradient chain on the main stream
-            # (every write into the flat gradient buffer is enqueued on that stream, so stream order IS the dependency; no wait on the
-            # main stream: the rest of the backward reads copies of the weights, never the flat buffer the update writes)
-            side = self.eng.grad_stream()
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        if not (self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off):
+            return
+        comm = self._comm_stream()
+        if comm is not None and self.eng.grad_stream() is None:
+            # one-stream backward: the buckets below are final at THIS point of the compute stream
+            comm.wait_stream(_current_stream(self.eng.flat.device))
+        with (_stream_ctx(comm) if comm is not None else contextlib.nullcontext()):
+            while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off:
+                s, e = self.buckets[self._next_bucket]
                 work = None
                 if self.sync_grads and self.wire is None:
                     work = dist.all_reduce(self.eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                elif self.sync_grads:  # bf16 on the wire: cast, sum, cast back -- all ordered on this (the gradient) stream
+                elif self.sync_grads:  # bf16 on the wire: cast, sum, cast back -- all ordered on the communication stream
                     wb = self.wire[s:e]
                     wb.copy_(self.eng.flat_grad[s:e])
                     work = dist.all_reduce(wb, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                    work.wait()  # stream-side wait (RCCL); the copy back must see the reduced values
+                    work.wait()  # the COMMUNICATION stream waits for RCCL's (a stream-side wait; gloo: the host); the copy back must see the sum
                     self.eng.flat_grad[s:e].copy_(wb)
                     work = None
                 if self._chase is not None:
                     if work is not None:
-                        work.wait()  # the gradient stream waits for the collective, not the host
+                        work.wait()  # again the communication stream, never the compute stream
                     self._update_range(s, e, *self._chase)
                 elif work is not None:
                     self._works.append(work)
-            self._next_bucket += 1
+                self._next_bucket += 1
 
     def _finish_allreduce(self) -> None:
+        """Behind the backward: the remaining buckets, then the ONE point where the compute stream waits for the collectives."""
         self._on_progress(0)
-        for w in self._works:
-            w.wait()
+        comm = self._comm_stream()
+        with (_stream_ctx(comm) if comm is not None else contextlib.nullcontext()):
+            for w in self._works:
+                w.wait()
+        if comm is not None:
+            _current_stream(self.eng.flat.device).wait_stream(comm)
         self._works.clear()
         self._next_bucket = 0
 

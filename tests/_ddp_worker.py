@@ -166,7 +166,7 @@ def run_full_size(rank: int, world: int, port: int, out_dir: str, steps: int = 3
             dist.all_reduce = orig
         torch.cuda.synchronize()
         res[mode] = dict(losses=losses, flat=tr.eng.flat.detach().cpu().clone(), nb=len(tr.buckets), all_reduces=n_ar[0],
-                         on_side_stream=tr.eng.grad_stream() is not None)
+                         on_side_stream=tr._comm_stream() is not None)
         del tr, net
         torch.cuda.empty_cache()
     torch.save(res, os.path.join(out_dir, f"full{rank}.pt"))

@@ -320,7 +320,7 @@ def full_net_gradients():
     """Backward of the default network pinned to the imported reference (training_loop.py:376-378 over src/thor/pipelines.py:27-35 with
     the draws injected): B = 2 at C = 52 (the reference's recipe) and C = 65 (north-star, the benchmarked channel count: exercises the
     65 -> 128 channel padding of the network-input / output convs).  72 M gradients are too many to ship: per tensor the absolute sum
-    and the L2 norm (float64) of ALL 228 gradients, strided slices of the tensors in FULL_GRAD_SLICES, every bias gradient of those in
+    and the L2 norm (float64) of ALL 228 gradients, strided slices of the tensors in FULL_GRAD_SLICES and of every modulation projection, every bias gradient in
     full, plus the loss and a strided output slice.  Inputs are regenerated by the tests from the seeds below."""
     cfg = yaml.full_load(open(f"{REF}/configs/sda_unet.yml"))
     pipe = pipelines.SDAPipeline()
@@ -344,8 +344,16 @@ def full_net_gradients():
         for k, (s0, s1) in FULL_GRAD_SLICES.items():
             out["slice." + k] = grads[k][::s0, ::s1].contiguous().numpy()
             out["step." + k] = np.array([s0, s1])
-            kb = k[: -len("weight")] + "bias"
-            out["full." + kb] = grads[kb].numpy()
+        # round 6 (parity instrumentation of the 16-bit modes: relative L2 and cosine per tensor need the tensors, not their norms):
+        # EVERY bias gradient in full (114 small tensors, 31 k values) and a (4, 8)-strided slice of every modulation projection's
+        # weight gradient (30 tensors; these and the biases are sums over all pixels of small per-pixel terms -- the tensors where
+        # an error concentrated in small-magnitude entries would show)
+        for k in names:
+            if k.endswith(".bias"):
+                out["full." + k] = grads[k].numpy()
+            elif k.endswith("project.0.weight") and k not in FULL_GRAD_SLICES:
+                out["slice." + k] = grads[k][::4, ::8].contiguous().numpy()
+                out["step." + k] = np.array([4, 8])
         np.savez_compressed(os.path.join(HERE, f"full_net_grads_c{C}.npz"), **out)
         print(f"C={C}: loss {loss.item():.6f}")
 

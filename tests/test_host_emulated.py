@@ -210,6 +210,86 @@ def test_optimizer_chasing_the_backward_equals_the_update_behind_it_two_ranks_gl
         assert torch.equal(v, r1[True]["sd"][k]), k  # ranks in lock step
 
 
+@pytest.mark.parametrize("wire,chase", [(None, False), ("bf16", False), (None, True), ("bf16", True)])
+def test_bucket_collectives_never_make_the_compute_stream_wait(emu, golden_dir, monkeypatch, wire, chase):
+    """training_loop.py:116,373-378 on one backward stream (the default since round 5): every bucket's cast / all-reduce / stream-side
+    wait / cast back / chased update is enqueued on the COMMUNICATION stream, ordered behind the bucket's weight gradients by
+    comm.wait_stream(compute); the compute stream waits for the communication stream exactly once, behind the last bucket.  Streams
+    and the collective are recording stand-ins (no GPU here); the step's numbers must equal the step without a process group."""
+    import torch.distributed as dist
+    from climate2weather_amd import training as tmod
+    g = _golden(golden_dir, "tiny_net.npz")
+    x, t, eps = (torch.from_numpy(g[k]) for k in ("x", "t", "eps"))
+    log = []
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_stream(self, other):
+            log.append(("wait_stream", self.name, other.name))
+
+    main, comm = FakeStream("compute"), FakeStream("comm")
+    stack = [main]
+
+    class Ctx:
+        def __init__(self, st):
+            self.st = st
+
+        def __enter__(self):
+            stack.append(self.st)
+
+        def __exit__(self, *a):
+            stack.pop()
+
+    class FakeWork:
+        def wait(self):
+            log.append(("work.wait", stack[-1].name))
+
+    def fake_all_reduce(tensor, op=None, group=None, async_op=False):
+        log.append(("all_reduce", stack[-1].name, str(tensor.dtype)))
+        return FakeWork()
+
+    ref = Trainer(_tiny(), lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=0.05)
+    ref.step(x, t=t.reshape(-1), eps=eps)
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        monkeypatch.setenv("C2W_FORCE_DIST", "1")
+        tr = Trainer(_tiny(), lr=1e-3, precision="fp32", ema_rates=[0.9], bucket_mb=0.05, allreduce_dtype=wire)
+        assert tr.sync_grads and len(tr.buckets) > 4
+        tr.chase_optimizer = chase
+        monkeypatch.setattr(tmod, "_current_stream", lambda dev: stack[-1])
+        monkeypatch.setattr(tmod, "_stream_ctx", Ctx)
+        monkeypatch.setattr(Trainer, "_comm_stream", lambda self: comm)
+        monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+        updates = []
+        orig_update = Trainer._update_range
+        monkeypatch.setattr(Trainer, "_update_range", lambda self, s, e, *a: (updates.append(stack[-1].name), orig_update(self, s, e, *a))[1])
+        tr.step(x, t=t.reshape(-1), eps=eps)
+    finally:
+        dist.destroy_process_group()
+    nb = len(tr.buckets)
+    ars = [i for i, ev in enumerate(log) if ev[0] == "all_reduce"]
+    assert len(ars) == nb and all(log[i][1] == "comm" for i in ars)
+    assert {log[i][2] for i in ars} == {"torch.bfloat16" if wire else "torch.float32"}
+    waits = [ev for ev in log if ev[0] == "work.wait"]
+    assert len(waits) == nb and all(w[1] == "comm" for w in waits)  # never the compute stream
+    joins = [i for i, ev in enumerate(log) if ev == ("wait_stream", "compute", "comm")]
+    assert len(joins) == 1 and joins[0] > ars[-1]  # the one join sits behind the last bucket's collective
+    orders = [i for i, ev in enumerate(log) if ev == ("wait_stream", "comm", "compute")]
+    assert len(orders) > 4 and orders[0] < ars[0]  # buckets were handed over during the backward, each behind an event of the compute stream
+    for a in ars:  # every collective is preceded by a hand-over newer than the previous progress call's
+        assert any(o < a for o in orders)
+    if wire or chase:  # the waits are issued next to their collectives (inside the backward), not collected at the end
+        assert [i for i, ev in enumerate(log) if ev[0] == "work.wait"][0] < ars[-1]
+    assert (len(updates) == nb and set(updates) == {"comm"}) if chase else updates == ["compute"]
+    if wire is None:
+        assert torch.equal(tr.eng.flat, ref.eng.flat) and torch.equal(tr.ema_flats[0], ref.ema_flats[0])
+    else:  # the gradients went through 8 mantissa bits: one Adam step of lr 1e-3 moves a weight by at most a flipped sign
+        assert not torch.equal(tr.eng.flat_grad, ref.eng.flat_grad) and (tr.eng.flat - ref.eng.flat).abs().max().item() <= 2.1e-3
+
+
 def _check_wire(outs):
     """bf16 wire vs fp32 wire of the gradient all-reduce (tests/_ddp_worker.py::run_wire): per-bucket bf16 collectives, summed gradients
     within bf16's resolution of the fp32 sum (scale-relative per 4096-element block of the flat buffer), untouched loss, ranks in lock step."""
