@@ -32,6 +32,7 @@ class ConvArgs(Structure):
         ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
         ("ln_eps", c_float), ("flags", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p), ("kvalid", c_int32),
         ("lnf_rstd", c_void_p), ("ln_rstd", c_void_p),
+        ("loss_sum", c_void_p), ("loss_scaler", c_void_p), ("loss_seed", c_ulonglong), ("loss_gscale", c_float), ("loss_C", c_int32),
     ]
 
 
@@ -44,6 +45,7 @@ _PROTOS = {
     "c2w_conv_forward": [POINTER(ConvArgs), c_int, c_int, c_void_p],
     "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_loss_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_pool2_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_dispatch": [POINTER(ConvArgs), c_int],

@@ -31,6 +31,7 @@
 
 #include "conv_epilogue.h"
 #include "knobs.h"
+#include "philox.h"
 
 namespace {
 
@@ -102,7 +103,10 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // waves 0-3 / 4-7 instead of even / odd waves -- every SIMD hosts one of each -- and waves 4-7 (`light`) compute only their first
     // 16-channel block; the weight pieces of channels 80-127 (waves 5-7) are not fetched: 20 instead of 32 MFMAs per SIMD and stage,
     // 5 of 8 KiB of weights per stage.
-    constexpr bool NARROW = EPI == 5;
+    // EPI = 7 (round 6): EPI 5 with the training loss fused -- the tile a = conv + bias (rounded to the storage type, in LDS) becomes
+    // dY = (a - eps) * gscale in place, eps regenerated from the step's Philox stream, sum (a - eps)^2 added to loss_sum
+    // (C2wConvArgs.loss_*): the prediction is never written and c2w_mse_loss_grad_noise's pass over it (0.36 ms per step) is gone.
+    constexpr bool NARROW = EPI == 5 || EPI == 7;
     const int wm = NARROW ? wid >> 2 : wid & 1, wn = NARROW ? wid & 3 : wid >> 1;
     const bool light = NARROW && wid >= 4;
 
@@ -325,6 +329,39 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
 #pragma unroll
     for (int j = 0; j < NB; ++j)
         epi_acc_to_lds<T>(O, T3_OS, acc[j], bv, p.act, wm * 64, (wn * NB + j) * 64, li_e, lg_e);
+    if constexpr (EPI == 7) {
+        // items = (channel c < loss_C) x (64 quads of four consecutive pixels of a tile row): one Philox counter each (the stream's
+        // element index is the NCHW linear index, four consecutive pixels of a channel plane = one block).  Lanes take consecutive
+        // channels of one quad: 2-byte LDS accesses of neighbouring lanes share a dword (2-way conflicts at most).
+        __syncthreads();  // the whole 256-row tile is in LDS
+        float gs = p.loss_gscale;
+        if (p.loss_scaler != nullptr) gs *= p.loss_scaler[0];
+        const uint32_t k0 = (uint32_t)p.loss_seed, k1 = (uint32_t)(p.loss_seed >> 32);
+        const int LC = p.loss_C, nitem = 64 * LC;
+        const unsigned long long HWl = (unsigned long long)H * W;
+        float local = 0.f;
+        for (int it = tid_e; it < nitem; it += T3_NTHR) {
+            const int quad = it / LC, c = it - quad * LC;
+            const int r = quad >> 2, q4 = quad & 3;
+            const unsigned long long e = ((unsigned long long)b * LC + c) * HWl + (unsigned long long)(oh0 + r) * W + ow0 + 4 * q4;
+            const f32x4_t ep = philox_normal4(k0, k1, e >> 2);
+            // eps as VALUES before the subtraction (pointwise.hip, sq_err_tiled_kernel): hipcc would contract the Box-Muller product
+            // with the difference -- one rounding less than the unfused kernel, which reads a materialised eps tile
+            float e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+            asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+            const float ev[4] = {e0, e1, e2, e3};
+            char* const q = O + (quad * 4) * T3_OS + c * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T* const cell = (T*)(q + j * T3_OS);
+                const float d = Elem<T>::ld(cell) - ev[j];
+                local += d * d;
+                Elem<T>::st(cell, d * gs);
+            }
+        }
+        local = wave_sum(local);
+        if (lane_e == 0) atomicAdd(p.loss_sum, local);
+    }
     // both 8-row blocks' residual / multiplier rows are requested before the first block is finished: the second block's HBM latency
     // runs behind the first block's arithmetic and stores (the accumulators have left the registers, so both sets fit)
     if constexpr (CF::NPASS == 2 && EPI != 0) {  // the per-family instantiations; in the all-in-one kernel (EPI = 0) this spills 54 registers
@@ -390,6 +427,7 @@ int t3_launch(const C2wConvArgs& a, hipStream_t st) {
     if (TR == 16 && (a.flags & C2W_CONV_POOL2) == 0) {
         if (a.lnf_y != nullptr) return t3_launch_as<16, T, NW, 2>(a, st);
         if (a.ln_x != nullptr) return a.ln_rstd != nullptr ? t3_launch_as<16, T, NW, 6>(a, st) : t3_launch_as<16, T, NW, 3>(a, st);
+        if (a.loss_sum != nullptr) return t3_launch_as<16, T, NW, 7>(a, st);  // (c2w_conv_loss_supported: the narrow form's conditions)
         if (a.wrows <= 80 && a.Cout <= 128 && c2w_knobs().wgrad_narrow) return t3_launch_as<16, T, NW, 5>(a, st);  // the output conv: 65 weight rows
         return t3_launch_as<16, T, NW, 4>(a, st);
     }
@@ -405,7 +443,7 @@ bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype) {
     const int mode = c2w_knobs().conv_t3;
     if ((dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16) || mode == 0 || (a.Hout & 15) != 0 || (a.Wout & 15) != 0) return false;
     const long long wgs = (long long)a.B * (a.Hout >> 4) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
-    return mode == 16 || wgs >= 1024;
+    return mode == 16 || wgs >= c2w_knobs().conv_t3_min_wgs;
 }
 
 int c2w_conv_patch3(const C2wConvArgs& a, int dtype, hipStream_t st) {

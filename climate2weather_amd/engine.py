@@ -745,7 +745,7 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, dt: int, tape: Optional[Tape] = None, noise: Optional[Tuple] = None,
                 want_dx: bool = False, nhwc_out: bool = False, x_nhwc: Optional[torch.Tensor] = None, shape=None,
-                forcing: Optional[torch.Tensor] = None, fold: Optional[dict] = None):
+                forcing: Optional[torch.Tensor] = None, fold: Optional[dict] = None, loss: Optional[dict] = None):
         """eps_pred = ScoreUNet(x, t).  x: (B,C,H,W) fp32 on the GPU; t: numel 1 or B.
         ``fold`` (inference, with ``nhwc_out``): dict(segs=[(eps trajectory (L,F,H,W) fp32, first window, count, first batch row)], k, F,
         nwin) -- the batch rows are windows of trajectories and only what src/thor/score.py:76-88 keeps of them is wanted: where the
@@ -754,6 +754,9 @@ class Engine:
         None is returned; otherwise the NHWC output rows are returned and the caller scatters them.
         noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion; eps may be an int
         seed instead of a tensor: the kernel regenerates the Philox stream of that seed (ops.philox_normal) and eps never exists.
+        ``loss`` (training, with ``nhwc_out``): dict(sum, seed, gscale[, scaler]) -- fuse the loss tail of src/thor/pipelines.py:35 into
+        the output convolution where the kernel exists (ops.conv_loss_supported): the returned rows are then dY = (prediction - eps) *
+        gscale, ``sum`` has received sum (prediction - eps)^2 and ``tape.meta["loss_fused"]`` is True; otherwise nothing changes.
         With ``tape`` every op records its backward closure (training / exact guidance)."""
         lay = self.layout
         self.refresh_version()
@@ -837,7 +840,7 @@ class Engine:
             else:
                 ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
 
-        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None, want_ln=None):
+        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None, want_ln=None, loss=None):
             """want_ln: None, or the consumer's LayerNorm to emit from this conv's epilogue: ("mod", modulation rows) for a
             residual block, ("plain", None) for an up-block.  Returns (y, geometry, record[, LN output or None])."""
             rec = lay.convs[name]
@@ -857,7 +860,7 @@ class Engine:
             # 16x16-tile kernel turns into fewer K steps
             wop, wpk = self._conv_weights("f", rec, dt, g)
             ops.conv(xin, wop, self._b(rec), y, g, dt, act=act, res=res, y2=y2, lnf=lnf,
-                     kvalid=rec.cin if rec.kstride != rec.cin else 0, wpacked=wpk)
+                     kvalid=rec.cin if rec.kstride != rec.cin else 0, wpacked=wpk, loss=loss)
             if self.debug_trace is not None:
                 self.debug_trace.append((name, y, dict(x=xin, w=self._w(rec, dt), g=g, act=act, res=res)))
                 if hn is not None:
@@ -1064,7 +1067,15 @@ class Engine:
                 xin = cur
                 if fold is not None and not train and nhwc_out and self._fold_output(fold, "unet." + lv.tail_key, xin, B, Hc, Wc, dt):
                     return None
-                cur, g_t, r_t = conv3("unet." + lv.tail_key, xin, Hc, Wc, Hc, Wc, CONV_S1, ldy=lay.cout_pad, cout=lay.cout_pad)
+                lfuse = None
+                if loss is not None and train and nhwc_out and self.fuse_loss:
+                    rec_o = lay.convs["unet." + lv.tail_key]
+                    g_o = self._geom(B, Hc, Wc, rec_o.kstride, Hc, Wc, lay.cout_pad, lay.cout_pad, rec_o.rows, CONV_S1)
+                    if ops.conv_loss_supported(g_o, dt):
+                        lfuse = dict(loss, C=lay.out_channels)
+                cur, g_t, r_t = conv3("unet." + lv.tail_key, xin, Hc, Wc, Hc, Wc, CONV_S1, ldy=lay.cout_pad, cout=lay.cout_pad, loss=lfuse)
+                if train:
+                    tape.meta["loss_fused"] = lfuse is not None
                 if train:
                     def bw_tail0(gy, xin=xin, g=g_t, rec=r_t, Hc=Hc, Wc=Wc, Cc=lv.channels):
                         gw = dict(g)
@@ -1083,6 +1094,7 @@ class Engine:
         return y
 
     use_center_conv = os.environ.get("C2W_NO_CENTER_CONV") != "1"  # A/B knob
+    fuse_loss = os.environ.get("C2W_NO_LOSS_FUSION") is None  # A/B knob: the loss tail as its own pass (rounds 1-5); the library reads the same variable
     use_gemv = os.environ.get("C2W_NO_GEMV") != "1"  # A/B knob: one-row Linear layers as matrix-vector products
 
     def _fold_output(self, fold: dict, name: str, xin: torch.Tensor, B: int, H: int, W: int, dt: int) -> bool:

@@ -50,7 +50,7 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
 
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
-         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False):
+         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False, loss: Optional[dict] = None):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased[, rstd]): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
     dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.  With ``rstd`` (what the forward's lnf kept), ``x`` holds the
@@ -63,6 +63,9 @@ def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=
     if wpacked:  # w: the stage-major copy made by pack_conv_weights_batched (only where conv_wpacked_supported says so)
         a.flags |= _lib.CONV_WPACKED
     a.kvalid = int(kvalid)  # promise: input channels >= kvalid are all zero in x or in w (0: no promise)
+    if loss is not None:  # dict(sum, seed, gscale, C[, scaler]): y receives (result - eps(seed)) * gscale, sum += sum of squares -- only
+        a.loss_sum, a.loss_scaler = _p(loss["sum"]), _p(loss.get("scaler"))  # where conv_loss_supported(g, dtype) says so
+        a.loss_seed, a.loss_gscale, a.loss_C = int(loss["seed"]), float(loss["gscale"]), int(loss["C"])
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
@@ -110,6 +113,11 @@ def conv_lnfwd_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
     return bool(_lib.load().c2w_conv_lnfwd_supported(ctypes.byref(a), dtype))
+
+
+def conv_loss_supported(g: dict, dtype: int) -> bool:
+    """True when c2w_conv_forward can fuse the training loss into this launch (include/c2w_hip.h::c2w_conv_loss_supported)."""
+    return bool(_lib.load().c2w_conv_loss_supported(ctypes.byref(_geom_args(g)), dtype))
 
 
 def conv_lnbwd_supported(g: dict, dtype: int) -> bool:

@@ -138,6 +138,7 @@ class Trainer:
     # for an event the compute stream records behind the bucket's last weight-gradient launch (comm.wait_stream(compute)); the compute
     # stream waits for the communication stream ONCE, behind the last bucket (``_finish_allreduce``).  With C2W_WGRAD_STREAM=1 (rounds
     # 1-4) the gradient stream the weight gradients are written on IS the communication stream and stream order is the dependency.
+    # The plain fp32 wire has no wait inside the backward (async collectives, waited for at the end) and stays on the compute stream.
     def _comm_stream(self):
         """The stream bucket collectives (and what surrounds them) are enqueued on; None: the caller's (CPU tensors, or no collective
         and no second stream)."""
@@ -146,7 +147,18 @@ class Trainer:
         gs = self.eng.grad_stream()
         if gs is not None:
             return gs
-        return self.eng.side_stream() if self.sync_grads else None
+        if os.environ.get("C2W_COMM_ON_COMPUTE") == "1":  # A/B knob: round 5's behaviour (everything issued from the compute stream)
+            return None
+        # fp32 wire without the chased update: the collectives are asynchronous (RCCL runs them on its own stream behind an event of
+        # the issuing stream) and nothing waits for them before _finish_allreduce -- issued from the compute stream itself they cost
+        # no stream hop (one rank, same box: 46.70 against 46.81 ms per step through the communication stream).  Anything with a
+        # stream-side wait inside the backward (bf16 wire: cast -> sum -> WAIT -> cast back; chased update: WAIT -> AdamW) goes to the
+        # communication stream.  C2W_COMM_STREAM=1 sends the fp32 wire there as well.
+        return self.eng.side_stream() if self._wants_comm_stream() else None
+
+    def _wants_comm_stream(self) -> bool:
+        """Does the per-bucket sequence of this step contain a stream-side wait (see _comm_stream)?"""
+        return self.sync_grads and (self.wire is not None or self._chase is not None or os.environ.get("C2W_COMM_STREAM") == "1")
 
     def _on_progress(self, off: int) -> None:
         if not (self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= off):
@@ -280,11 +292,17 @@ class Trainer:
         tape = Tape()
         if sync:
             tape.progress = self._on_progress
-        y = eng.forward(x, t, self.dt, tape=tape, noise=(seed if seed is not None else eps, musig), nhwc_out=True)
-        dy = torch.empty_like(y)
         self.loss_sum.zero_()
         n = B * C * H * W
         gs = 2.0 * self.loss_scaling / n
+        # regenerated noise: the loss tail rides the output convolution's epilogue where that kernel exists (the prediction is then never
+        # written; round 6) -- eng.forward returns dY and says so in tape.meta
+        lf = dict(sum=self.loss_sum, seed=seed, gscale=gs, scaler=self.scaler) if (seed is not None and H * W % 4 == 0) else None
+        y = eng.forward(x, t, self.dt, tape=tape, noise=(seed if seed is not None else eps, musig), nhwc_out=True, loss=lf)
+        if tape.meta.get("loss_fused"):
+            eng.backward(tape, y)
+            return self.loss_sum[0] * (self.loss_scaling / n)
+        dy = torch.empty_like(y)
         if seed is None or not ops.mse_loss_grad_noise(y, seed, dy, self.loss_sum, B, C, H * W, lay.cout_pad, gs, self.dt, scaler=self.scaler):
             if eps is None:  # shape outside the fused kernel: materialise the same stream
                 eps = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)

@@ -94,6 +94,17 @@ typedef struct C2wConvArgs {
      *   four 16-lane reductions per pixel row and the modulation add leave the epilogue (model/nn.py:28,154 backward). */
     float* lnf_rstd;
     const float* ln_rstd;
+    /* Optional fused training loss (round 6; see c2w_conv_loss_supported): with loss_sum != NULL the conv result itself is not
+     * stored.  Instead, with eps = the Philox stream of loss_seed (c2w_philox_normal; element index = NCHW linear index over
+     * [B][loss_C][Hout][Wout]) and a = the result rounded to the storage type, loss_sum += sum (a - eps)^2 over the loss_C real
+     * channels and y = (a - eps) * loss_gscale [* loss_scaler[0]] (channels >= loss_C: zero) -- c2w_mse_loss_grad_noise applied to
+     * the network-output conv's tile while it is still on chip (src/thor/pipelines.py:35, training_loop.py:376-377: the loss and
+     * the gradient the backward pass starts from; the prediction is used by nothing else in a training step). */
+    float* loss_sum;          /* one fp32, accumulated (atomics), or NULL = no fusion */
+    const float* loss_scaler; /* device-resident loss scale (fp16 training, c2w_grad_scaler_*) or NULL */
+    unsigned long long loss_seed;
+    float loss_gscale;
+    int32_t loss_C;
 } C2wConvArgs;
 
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
@@ -108,6 +119,11 @@ int c2w_conv_lnfwd_supported(const C2wConvArgs* args, int dtype);
 /* 1 when c2w_conv_forward can run args with the fused LayerNorm backward (bf16, Cout == ldy == 128, 3x3 stride-1 on an
  * image the halo-patch kernel tiles, no mul / act / y2), else 0.  Callers fall back to conv + c2w_ln_backward. */
 int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);
+/* 1 when c2w_conv_forward can run args with the fused training loss (loss_sum / loss_seed / loss_gscale / loss_C): 16-bit, 3x3
+ * stride-1 on the 16x16-tile kernel, at most 80 weight rows in rows of 128 channels (the network-output conv, model/nn.py:194),
+ * loss_C <= wrows, Wout % 16 == 0, no res / mul / act / y2 / LayerNorm fusion.  Otherwise callers run the conv and
+ * c2w_mse_loss_grad_noise. */
+int c2w_conv_loss_supported(const C2wConvArgs* args, int dtype);
 
 /* Which kernel family c2w_conv_forward (naive == 0) / c2w_conv_wgrad run these arguments on -- a pure function of the geometry,
  * the dtype and the fusion fields; the parity tests assert with it that a case reaches the kernel it is meant to cover.

@@ -67,6 +67,10 @@ def conv_lnfwd_supported(g, dtype):
     return g["mode"] in (CONV_S1, CONV_UP) and g["Cout"] == g["ldy"]
 
 
+def conv_loss_supported(g, dtype):
+    return False  # the emulation has no Philox stream: trainers on the CPU inject eps and run the separate loss tail
+
+
 def conv_pool2_supported(g, dtype):
     return conv_patch_supported(g, dtype) and g["mode"] == CONV_S1 and g["Win"] != 8
 
@@ -94,7 +98,8 @@ def pack_conv_weights_batched(src, dst, desc, n, dtype):
 
 
 def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False, kvalid=0,
-         wpacked=False):
+         wpacked=False, loss=None):
+    assert loss is None, "conv_loss_supported() is False here: nobody may ask the emulation for the fused loss"
     if wpacked:
         assert conv_wpacked_supported(g, dtype)
         return conv(x, -w.reshape(-1)[: g["wrows"] * 9 * g["Cin"]], bias, y, g, dtype, act, res, mul, mulmode, naive, y2, ln, lnf, pool2, kvalid)

@@ -399,6 +399,65 @@ def test_two_stream_backward_reproduces_every_conv_weight_gradient_bit_for_bit()
         assert not changed, f"round {r}: {len(changed)} conv weight gradients changed between identical steps, first {changed[0]}"
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("C,scaled", [(65, False), (52, True), (80, False)])
+def test_loss_tail_fused_into_the_output_convolution(dt, packed, C, scaled):
+    """Round 6: c2w_conv_forward with C2wConvArgs.loss_* (src/thor/pipelines.py:35, training_loop.py:376-377): the network-output conv
+    (model/nn.py:194; narrow form of the 16x16-tile kernel, >= 1024 workgroups) turns its tile into dY = (prediction - eps) * gscale and
+    adds sum (prediction - eps)^2 to loss_sum, eps regenerated from the step's Philox stream.  Against the unfused pair of launches it
+    replaces -- the same conv followed by c2w_mse_loss_grad_noise: dY bit for bit (same arithmetic on the same rounded prediction), the
+    loss to fp32 summation order -- and against the PyTorch restatement over the materialised stream (c2w_philox_normal)."""
+    B, H = 16, 128
+    g = geom(B, H, H, 128, H, H, 128, 128, C, S1)
+    assert ops.conv_loss_supported(g, dt) and ops.conv_dispatch(g, dt) == T3
+    npix = B * H * H
+    x = rnd((npix, 128), dt, 1)
+    w = rnd((C, 9, 128), dt, 2, scale=1.0 / math.sqrt(9 * 128))
+    bias = rnd((C,), F32, 3)
+    wop = w
+    if packed:
+        wop = torch.empty(ops.packed_conv_weights_numel(C, 128), dtype=TD[dt], device=dev())
+        ops.pack_conv_weights_batched(w, wop, torch.tensor([[0, 0, C, 128]], dtype=torch.int64, device=dev()), 1, dt)
+    seed, gs = 0x1234567890ABCDEF & ((1 << 62) - 1), 2.0 / (B * C * H * H)
+    scaler = torch.tensor([512.0, 0.0, 0.0, 0.0], device=dev()) if scaled else None
+    # unfused: conv, then the loss tail
+    y = torch.empty((npix, 128), dtype=TD[dt], device=dev())
+    ops.conv(x, wop, bias, y, g, dt, wpacked=packed)
+    dy_ref, ls_ref = torch.full_like(y, 9.0), torch.zeros(1, device=dev())
+    assert ops.mse_loss_grad_noise(y, seed, dy_ref, ls_ref, B, C, H * H, 128, gs, dt, scaler=scaler)
+    # fused
+    dy, ls = torch.full_like(y, 7.0), torch.zeros(1, device=dev())
+    ops.conv(x, wop, bias, dy, g, dt, wpacked=packed, loss=dict(sum=ls, seed=seed, gscale=gs, C=C, scaler=scaler))
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy_ref)
+    assert dy[:, :C].float().abs().sum().item() > 0 and dy[:, C:].float().abs().max().item() == 0.0  # padding channels: zero gradient
+    assert ls.item() == pytest.approx(ls_ref.item(), rel=2e-6)
+    # restatement: materialised stream, PyTorch arithmetic on the same stored prediction
+    eps = torch.empty((B, C, H, H), dtype=torch.float32, device=dev())
+    ops.philox_normal(eps, eps.numel(), seed)
+    d = y[:, :C].float() - eps.permute(0, 2, 3, 1).reshape(npix, C)
+    assert ls.item() == pytest.approx((d.double() ** 2).sum().item(), rel=2e-5)
+    close(dy[:, :C], (d * gs * (512.0 if scaled else 1.0)).to(TD[dt]), 1e-6, "fused loss gradient")
+    # a second launch ACCUMULATES into loss_sum (the trainer zeroes it per round)
+    ops.conv(x, wop, bias, dy, g, dt, wpacked=packed, loss=dict(sum=ls, seed=seed, gscale=gs, C=C, scaler=scaler))
+    assert ls.item() == pytest.approx(2 * ls_ref.item(), rel=4e-6)
+
+
+def test_loss_fusion_is_refused_where_the_kernel_does_not_exist():
+    """No silent unfused result: geometries outside c2w_conv_loss_supported fail loudly when handed loss arguments."""
+    g_small = geom(2, 128, 128, 128, 128, 128, 128, 128, 65, S1)  # 128 workgroups: the 8x16-tile kernel
+    g_wide = geom(16, 128, 128, 128, 128, 128, 128, 128, 128, S1)  # a full-width conv
+    for g in (g_small, g_wide):
+        assert not ops.conv_loss_supported(g, BF16)
+        npix = g["B"] * 128 * 128
+        x, w = rnd((npix, 128), BF16, 1), rnd((g["wrows"], 9, 128), BF16, 2, scale=0.03)
+        y, ls = torch.empty((npix, 128), dtype=torch.bfloat16, device=dev()), torch.zeros(1, device=dev())
+        with pytest.raises(_lib.C2wError):
+            ops.conv(x, w, None, y, g, BF16, loss=dict(sum=ls, seed=1, gscale=1.0, C=min(65, g["wrows"])))
+    assert not ops.conv_loss_supported(geom(16, 128, 128, 128, 128, 128, 128, 128, 65, S1), F32)
+
+
 PACKED_CASES = [  # (name, B, H, Cin, Cout, wrows, epilogue)
     ("128->128 @128^2 bias+SiLU pair", 16, 128, 128, 128, 128, "pair"),
     ("128->128 @128^2 residual + LayerNorm emission", 16, 128, 128, 128, 128, "res+lnf"),

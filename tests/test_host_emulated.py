@@ -261,7 +261,9 @@ def test_bucket_collectives_never_make_the_compute_stream_wait(emu, golden_dir, 
         tr.chase_optimizer = chase
         monkeypatch.setattr(tmod, "_current_stream", lambda dev: stack[-1])
         monkeypatch.setattr(tmod, "_stream_ctx", Ctx)
-        monkeypatch.setattr(Trainer, "_comm_stream", lambda self: comm)
+        want_comm = bool(wire) or chase  # plain fp32 wire: asynchronous collectives from the compute stream, waited for at the end only
+        monkeypatch.setattr(Trainer, "_comm_stream", lambda self: comm if self._wants_comm_stream() else None)  # the product's decision, a stand-in stream
+        assert (tr.wire is not None) == bool(wire)
         monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
         updates = []
         orig_update = Trainer._update_range
@@ -271,18 +273,21 @@ def test_bucket_collectives_never_make_the_compute_stream_wait(emu, golden_dir, 
         dist.destroy_process_group()
     nb = len(tr.buckets)
     ars = [i for i, ev in enumerate(log) if ev[0] == "all_reduce"]
-    assert len(ars) == nb and all(log[i][1] == "comm" for i in ars)
+    waits = [i for i, ev in enumerate(log) if ev[0] == "work.wait"]
+    assert len(ars) == nb and len(waits) == nb
     assert {log[i][2] for i in ars} == {"torch.bfloat16" if wire else "torch.float32"}
-    waits = [ev for ev in log if ev[0] == "work.wait"]
-    assert len(waits) == nb and all(w[1] == "comm" for w in waits)  # never the compute stream
-    joins = [i for i, ev in enumerate(log) if ev == ("wait_stream", "compute", "comm")]
-    assert len(joins) == 1 and joins[0] > ars[-1]  # the one join sits behind the last bucket's collective
-    orders = [i for i, ev in enumerate(log) if ev == ("wait_stream", "comm", "compute")]
-    assert len(orders) > 4 and orders[0] < ars[0]  # buckets were handed over during the backward, each behind an event of the compute stream
-    for a in ars:  # every collective is preceded by a hand-over newer than the previous progress call's
-        assert any(o < a for o in orders)
-    if wire or chase:  # the waits are issued next to their collectives (inside the backward), not collected at the end
-        assert [i for i, ev in enumerate(log) if ev[0] == "work.wait"][0] < ars[-1]
+    if want_comm:
+        assert all(log[i][1] == "comm" for i in ars) and all(log[i][1] == "comm" for i in waits)  # never the compute stream
+        joins = [i for i, ev in enumerate(log) if ev == ("wait_stream", "compute", "comm")]
+        assert len(joins) == 1 and joins[0] > ars[-1]  # the one join sits behind the last bucket's collective
+        orders = [i for i, ev in enumerate(log) if ev == ("wait_stream", "comm", "compute")]
+        assert len(orders) > 4 and orders[0] < ars[0]  # buckets were handed over during the backward, each behind an event of the compute stream
+        for a in ars:  # every collective is preceded by a hand-over
+            assert any(o < a for o in orders)
+        assert waits[0] < ars[-1]  # the waits sit next to their collectives (inside the backward) -- on the communication stream
+    else:  # asynchronous collectives from the compute stream: no wait of any kind before the last bucket's collective is out
+        assert all(log[i][1] == "compute" for i in ars) and waits[0] > ars[-1]
+        assert not [ev for ev in log if ev[0] == "wait_stream"]
     assert (len(updates) == nb and set(updates) == {"comm"}) if chase else updates == ["compute"]
     if wire is None:
         assert torch.equal(tr.eng.flat, ref.eng.flat) and torch.equal(tr.ema_flats[0], ref.ema_flats[0])
