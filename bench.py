@@ -309,6 +309,8 @@ def compact_line(full: dict, extras_file=None) -> str:
     # the reference's own arithmetic (fp16, train.py:98) and its own recipe (4 variables -> 52 channels, run_training.sh:39-45), same step
     for key, path in (("trainer_fp16_windows_per_s", ("module_api", "trainer_fp16", "windows_per_s")),
                       ("trainer_bf16_c52_windows_per_s", ("module_api", "trainer_bf16_c52", "windows_per_s")),
+                      ("trainer_bf16_b64_windows_per_s", ("module_api", "trainer_bf16_b64", "windows_per_s")),
+                      ("trainer_bf16_b64_mfma_frac_whole_step", ("module_api", "trainer_bf16_b64", "mfma_frac_whole_step")),
                       ("module_api_bf16_autocast_windows_per_s", ("module_api", "bf16_autocast", "windows_per_s")),
                       ("module_api_fp16_gradscaler_windows_per_s", ("module_api", "fp16_autocast_gradscaler", "windows_per_s")),
                       ("serialised_step_ms", ("by_kernel", "serialised_step_ms")),

@@ -168,7 +168,7 @@ def _step_stats(ms):
 
 
 
-def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16", "trainer_bf16_c52"), item=True, lazy=False,
+def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autocast_gradscaler", "trainer_fp16", "trainer_bf16", "trainer_bf16_c52", "trainer_bf16_b64"), item=True, lazy=False,
                wrap=None):
     """What a maintainer gets who changes ONLY the five class_name / func_name strings of train.py:164-193 and
     leaves training_loop.py alone: the loop of training_loop.py:369-391, statement for statement -- optimizer.zero_grad(); data =
@@ -191,7 +191,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
                     "C = %d, %dx%d; loss.item() every step as the reference does; vs_trainer = windows/s over the headline Trainer's" % (B, C, a.size, a.size),
                trainer_windows_per_s=trainer_windows_per_s)
 
-    def timed(step):
+    def timed(step, windows=B):
         for _ in range(warm):
             step()
         torch.cuda.synchronize()
@@ -203,7 +203,7 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
             marks[i + 1].record()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        return dict(windows_per_s=round(B / dt, 1), ms_per_step=round(1e3 * dt, 3), vs_trainer=round(B / dt / trainer_windows_per_s, 4),
+        return dict(windows_per_s=round(windows / dt, 1), ms_per_step=round(1e3 * dt, 3), vs_trainer=round(windows / dt / trainer_windows_per_s, 4),
                     step_ms=_step_stats([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]))
 
     for name, ac, use_scaler in (("bf16_autocast", torch.bfloat16, False), ("fp16_autocast_gradscaler", torch.float16, True)):
@@ -246,24 +246,29 @@ def module_api(dev, a, trainer_windows_per_s, legs=("bf16_autocast", "fp16_autoc
         del net, mod, optimizer, ema, feed, ds, pipeline, step  # the allocator keeps its blocks: the next leg has the same working set
     # the fused Trainer in the reference's arithmetic type (loss scale, inf check and skipped steps on the device)
     # ... and in bf16 on the reference's own recipe: 4 variables x window 13 = 52 channels (run_training.sh:39-45)
-    for leg, prec, nvars in (("trainer_fp16", "fp16", a.vars), ("trainer_bf16", "bf16", a.vars), ("trainer_bf16_c52", "bf16", 4)):
+    # ... and at 64 windows per GPU: the reference's global batch of 512 (run_training.sh:43-45) strong-scaled over the 8 GPUs of a node
+    for leg, prec, nvars, Bl in (("trainer_fp16", "fp16", a.vars, B), ("trainer_bf16", "bf16", a.vars, B), ("trainer_bf16_c52", "bf16", 4, B),
+                                 ("trainer_bf16_b64", "bf16", a.vars, 64)):
         if leg not in legs:
             continue
         torch.manual_seed(0)
         net = ScoreUNet(channels=nvars * w, spatial=2, activation=torch.nn.SiLU, **DEFAULT_CFG).to(dev)
         tr = Trainer(net, SDAPipeline(), lr_fn=lambda n: linear_learning_rate_schedule(n, total_ndata, 1e-4), weight_decay=1e-3, ema_rates=[0.9999],
-                     precision=prec, batch_size=B, seed=1000)
+                     precision=prec, batch_size=Bl, seed=1000)
         ds = SyntheticWindowDataset(n_frames=1024 + w - 1, n_vars=nvars, height=a.size, width=a.size, window=w, seed=0)
         feed = DeviceWindowFeed(ds, dev, seed=0)
-        r = timed(lambda: tr.step(feed.next_batch(B, lazy=True)))
-        r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale(), channels=nvars * w)
+        r = timed(lambda: tr.step(feed.next_batch(Bl, lazy=True)), windows=Bl)
+        r.update(optimizer_steps_taken=tr.optimizer_steps_taken(), loss_scale=tr.loss_scale(), channels=nvars * w, windows_per_step=Bl)
+        if Bl != B and a.size == 128:  # whole-step matrix-core fraction at this batch (fwd + dgrad + wgrad minus the input conv's dgrad)
+            gf = GFLOP_FWD.get(nvars * w, 116.0)
+            r["mfma_frac_whole_step"] = round(r["windows_per_s"] * (3 * gf - 1.96) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         res[leg] = r
         del tr, net, feed, ds
     # the like-for-like ratio: every leg over the fused bf16 Trainer timed in THIS process, minutes after the headline and on the
     # same allocator state (vs_trainer compares with the headline line, taken in another process at another moment)
     if "trainer_bf16" in res:
         for k, v in res.items():
-            if isinstance(v, dict) and "windows_per_s" in v:
+            if isinstance(v, dict) and "windows_per_s" in v and v.get("windows_per_step", B) == B:
                 v["vs_trainer_same_process"] = round(v["windows_per_s"] / res["trainer_bf16"]["windows_per_s"], 4)
     return res
 

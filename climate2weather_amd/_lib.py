@@ -15,7 +15,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
-CONV_POOL2, CONV_WPACKED = 1, 2  # ConvArgs.flags (bit set)
+CONV_POOL2, CONV_WPACKED, CONV_NO_Y = 1, 2, 4  # ConvArgs.flags (bit set)
 KERNEL_GATHER, KERNEL_PATCH_8X16, KERNEL_PATCH_16X16, KERNEL_PATCH_PAIR, KERNEL_PATCH_TS2 = 0, 1, 2, 3, 4  # c2w_conv_dispatch
 
 
@@ -32,7 +32,9 @@ class ConvArgs(Structure):
         ("ln_x", c_void_p), ("ln_m", c_void_p), ("ln_dm", c_void_p), ("ln_ldm", c_int32), ("ln_unbiased", c_int32),
         ("ln_eps", c_float), ("flags", c_int32), ("lnf_y", c_void_p), ("lnf_m", c_void_p), ("kvalid", c_int32),
         ("lnf_rstd", c_void_p), ("ln_rstd", c_void_p),
-        ("loss_sum", c_void_p), ("loss_scaler", c_void_p), ("loss_seed", c_ulonglong), ("loss_gscale", c_float), ("loss_C", c_int32),
+        ("lnf_mean", c_void_p), ("res_rstd", c_void_p), ("res_mean", c_void_p), ("res_m", c_void_p),
+        ("loss_sum", c_void_p), ("loss_scaler", c_void_p), ("loss_eps", c_void_p), ("loss_gscale", c_float), ("loss_C", c_int32),
+        ("loss_lde", c_int32),
     ]
 
 
@@ -46,6 +48,7 @@ _PROTOS = {
     "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_loss_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_lnfwd_chain_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_pool2_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_dispatch": [POINTER(ConvArgs), c_int],
@@ -68,6 +71,7 @@ _PROTOS = {
     "c2w_mse_loss_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "c2w_mse_loss_grad_scaled": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p],
     "c2w_philox_normal": [c_void_p, c_longlong, c_ulonglong, c_void_p],
+    "c2w_nchw_to_nhwc_noise_rows": [c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_nchw_to_nhwc_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_windows_to_nhwc_noise": [c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "c2w_mse_loss_grad_noise": [c_void_p, c_ulonglong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p],

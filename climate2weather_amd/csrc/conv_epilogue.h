@@ -338,10 +338,17 @@ struct EpiStore {
 
     // ---- fused LayerNorm FORWARD of the consumer (bf16 tile with whole 128-channel rows of one image `img`):
     //   y = O (+ res), stored; lnf_y = LN_C(y_as_stored + lnf_m[img])  -- the arithmetic of ln_fwd_kernel (two-pass variance)
+    // Round 6 (C2wConvArgs.res_rstd / res_mean / res_m, C2W_CONV_NO_Y, lnf_mean):
+    //   RESN: `res` holds the NORMALISED rows h = LN(x + res_m) an earlier launch emitted, with that LayerNorm's per-pixel statistics:
+    //         the residual is rebuilt as x = h / rstd + mean - res_m[img] (the block input itself was never written);
+    //   C2W_CONV_NO_Y: y is not stored (its only readers are this LayerNorm and the next block's residual, which rebuilds it the same
+    //         way from lnf_y, lnf_rstd and lnf_mean); the LayerNorm then sees the fp32 sum instead of its 16-bit rounding.
+    template <bool RESN = false>
     __device__ __forceinline__ void finish_lnf(const C2wConvArgs& p, const char* O, int OS, int tid, int img) {
         static_assert(EARLY && SEGS == 16 && PER16 == 8, "fused LN forward: 16-bit tiles only");
         typedef __attribute__((ext_vector_type(2))) float f2;
         const int cs = tid & (SEGS - 1);
+        const bool store_y = (p.flags & C2W_CONV_NO_Y) == 0;  // kernel argument: uniform
         f2 m2[4];
         if (p.lnf_m != nullptr) {
             const float* mr = p.lnf_m + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + cs * PER16;
@@ -350,6 +357,25 @@ struct EpiStore {
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) m2[k] = (f2){0.f, 0.f};
+        }
+        f2 rm2[4];
+        float rsig[RESN ? NIT : 1], rmean[RESN ? NIT : 1];
+        if constexpr (RESN) {
+            if (p.res_m != nullptr) {
+                const float* mr = p.res_m + (size_t)(p.ln_ldm ? img : 0) * p.ln_ldm + cs * PER16;
+                const f32x4_t ma = *(const f32x4_t*)mr, mb = *(const f32x4_t*)(mr + 4);
+                rm2[0] = (f2){ma[0], ma[1]}; rm2[1] = (f2){ma[2], ma[3]}; rm2[2] = (f2){mb[0], mb[1]}; rm2[3] = (f2){mb[2], mb[3]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rm2[k] = (f2){0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {  // 16 lanes share a pixel row (256 B): one address each
+                rsig[i] = p.res_rstd[ok(i) ? off[i] >> 8 : 0];
+                rmean[i] = p.res_mean[ok(i) ? off[i] >> 8 : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) rsig[i] = __builtin_amdgcn_rcpf(rsig[i]);  // sigma
         }
         const float inv_den = 1.0f / (float)(128 - (p.ln_unbiased ? 1 : 0));
         auto unpack2 = [](const u32x4_t& v, f2* f) {
@@ -364,18 +390,25 @@ struct EpiStore {
         for (int i = 0; i < NIT; ++i) {
             u32x4_t out = *(const u32x4_t*)lds_seg(O, OS, tid, i);
             f2 u[4];
-            if (p.res != nullptr) {
+            unpack2(out, u);
+            if (RESN || p.res != nullptr) {
                 f2 r[4];
-                unpack2(out, u);
                 unpack2(rr[i], r);
+                if constexpr (RESN) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    u[k] += r[k];
-                    out[k] = pack2<T>(u[k][0], u[k][1]);
+                    for (int k = 0; k < 4; ++k) r[k] = r[k] * rsig[i] + (rmean[i] - rm2[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[k] += r[k];
+                if (store_y) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) out[k] = pack2<T>(u[k][0], u[k][1]);
                 }
             }
-            if (ok(i)) epi_st((char*)p.y + off[i], out);
-            unpack2(out, u);  // the values as stored (bf16), like the separate LN pass would read them
+            if (store_y) {
+                if (ok(i)) epi_st((char*)p.y + off[i], out);
+                unpack2(out, u);  // the values as stored (bf16), like the separate LN pass would read them
+            }
             f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -394,8 +427,12 @@ struct EpiStore {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ln[k] = pack2<T>(u[k][0] * rs, u[k][1] * rs);
             if (ok(i)) epi_st((char*)p.lnf_y + off[i], ln);
-            // the row's 1/sigma for the backward (ln_rstd): one lane per pixel row (rows are 256 B: pixel = byte offset >> 8)
-            if (p.lnf_rstd != nullptr && cs == 0 && ok(i)) p.lnf_rstd[off[i] >> 8] = rs;
+            // the row's 1/sigma (and mean) for the backward / the next block's residual: one lane per pixel row (rows are 256 B:
+            // pixel = byte offset >> 8)
+            if (cs == 0 && ok(i)) {
+                if (p.lnf_rstd != nullptr) p.lnf_rstd[off[i] >> 8] = rs;
+                if (p.lnf_mean != nullptr) p.lnf_mean[off[i] >> 8] = mean;
+            }
         }
     }
 

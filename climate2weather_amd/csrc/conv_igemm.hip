@@ -367,6 +367,7 @@ C2wKnobs read_knobs() {
     k.lnf = getenv("C2W_NO_LNF") == nullptr;
     k.wgrad_atomics = getenv("C2W_WGRAD_ATOMICS") != nullptr;
     k.loss_fusion = getenv("C2W_NO_LOSS_FUSION") == nullptr;
+    k.ln_chain = getenv("C2W_NO_LN_CHAIN") == nullptr;
     k.conv_t3_min_wgs = getenv("C2W_CONV_T3_MIN_WGS") && atoi(getenv("C2W_CONV_T3_MIN_WGS")) > 0 ? atoi(getenv("C2W_CONV_T3_MIN_WGS")) : 1024;
     k.attn_valu = getenv("C2W_ATTN_VALU") != nullptr;
     return k;
@@ -401,12 +402,19 @@ extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     return c2w_conv_patch_eligible(*a) && !c2w_knobs().force_gather && c2w_knobs().ln_fusion ? 1 : 0;
 }
 
+extern "C" int c2w_conv_lnfwd_chain_supported(const C2wConvArgs* a, int dtype) {
+    if (!c2w_conv_lnfwd_supported(a, dtype)) return 0;
+    return c2w_knobs().ln_chain && a->mode == C2W_CONV_S1 && c2w_conv_patch3_wanted(*a, dtype) ? 1 : 0;
+}
+
 extern "C" int c2w_conv_loss_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->mode != C2W_CONV_S1 || a->wrows > 80 || a->Cout > 128 || a->ldy != 128 || a->res != nullptr || a->mul != nullptr || a->y2 != nullptr ||
         a->act != C2W_ACT_NONE || a->ln_x != nullptr || a->lnf_y != nullptr || (a->flags & C2W_CONV_POOL2) != 0)
         return 0;
-    if (a->loss_sum != nullptr && (a->loss_C <= 0 || a->loss_C > a->wrows)) return 0;
+    if (a->loss_sum != nullptr && (a->loss_eps == nullptr || a->loss_C <= 0 || a->loss_C > a->wrows || (a->loss_lde & 7) != 0 || a->loss_lde < a->loss_C ||
+                                   a->loss_lde > 128))
+        return 0;
     const C2wKnobs& k = c2w_knobs();
     return !k.force_gather && k.loss_fusion && k.wgrad_narrow && c2w_conv_patch_eligible(*a) && c2w_conv_patch3_wanted(*a, dtype) ? 1 : 0;
 }
@@ -439,6 +447,12 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (a->ln_x != nullptr && (naive != 0 || !c2w_conv_lnbwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if (a->lnf_y != nullptr && (naive != 0 || !c2w_conv_lnfwd_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if ((a->ln_rstd != nullptr && a->ln_x == nullptr) || (a->lnf_rstd != nullptr && a->lnf_y == nullptr)) return C2W_ERR_BAD_ARG;  // statistics of a LayerNorm that is not fused
+    if (a->lnf_mean != nullptr || a->res_rstd != nullptr || a->res_mean != nullptr || a->res_m != nullptr || (a->flags & C2W_CONV_NO_Y) != 0) {
+        if (a->lnf_y == nullptr || (a->res_rstd == nullptr) != (a->res_mean == nullptr) || (a->res_m != nullptr && a->res_rstd == nullptr) ||
+            (a->res_rstd != nullptr && a->res == nullptr))
+            return C2W_ERR_BAD_ARG;
+        if (naive != 0 || !c2w_conv_lnfwd_chain_supported(a, dtype)) return C2W_ERR_BAD_SHAPE;
+    }
     if ((a->flags & C2W_CONV_POOL2) != 0 && (naive != 0 || !c2w_conv_pool2_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if (a->loss_sum != nullptr && (naive != 0 || !c2w_conv_loss_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
     if ((a->flags & C2W_CONV_WPACKED) != 0 && (naive != 0 || !c2w_conv_wpacked_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no other kernel reads that layout

@@ -31,7 +31,6 @@
 
 #include "conv_epilogue.h"
 #include "knobs.h"
-#include "philox.h"
 
 namespace {
 
@@ -104,8 +103,10 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     // 16-channel block; the weight pieces of channels 80-127 (waves 5-7) are not fetched: 20 instead of 32 MFMAs per SIMD and stage,
     // 5 of 8 KiB of weights per stage.
     // EPI = 7 (round 6): EPI 5 with the training loss fused -- the tile a = conv + bias (rounded to the storage type, in LDS) becomes
-    // dY = (a - eps) * gscale in place, eps regenerated from the step's Philox stream, sum (a - eps)^2 added to loss_sum
-    // (C2wConvArgs.loss_*): the prediction is never written and c2w_mse_loss_grad_noise's pass over it (0.36 ms per step) is gone.
+    // dY = (a - eps) * gscale in place, eps read from the half-precision noise rows the input conversion kept, sum (a - eps)^2 added to
+    // loss_sum (C2wConvArgs.loss_*): the prediction is never written and the loss tail's own pass (0.36 ms per step) is gone.  (A first
+    // version regenerated eps from the Philox stream here: 1.06 ms for the launch against 0.42 + 0.36 unfused -- ten dependent
+    // multiply rounds on four waves per SIMD are latency-bound; profiles/r06_experiments.md.)
     constexpr bool NARROW = EPI == 5 || EPI == 7;
     const int wm = NARROW ? wid >> 2 : wid & 1, wn = NARROW ? wid & 3 : wid >> 1;
     const bool light = NARROW && wid >= 4;
@@ -330,34 +331,28 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
     for (int j = 0; j < NB; ++j)
         epi_acc_to_lds<T>(O, T3_OS, acc[j], bv, p.act, wm * 64, (wn * NB + j) * 64, li_e, lg_e);
     if constexpr (EPI == 7) {
-        // items = (channel c < loss_C) x (64 quads of four consecutive pixels of a tile row): one Philox counter each (the stream's
-        // element index is the NCHW linear index, four consecutive pixels of a channel plane = one block).  Lanes take consecutive
-        // channels of one quad: 2-byte LDS accesses of neighbouring lanes share a dword (2-way conflicts at most).
+        // items = (tile row R of 256) x (16-byte segment of the noise row: loss_lde / 8 of them): y and eps are both NHWC rows, so a thread
+        // turns 8 channels of one pixel into their gradient in place; channels loss_C .. loss_lde-1 are zero on both sides
         __syncthreads();  // the whole 256-row tile is in LDS
         float gs = p.loss_gscale;
         if (p.loss_scaler != nullptr) gs *= p.loss_scaler[0];
-        const uint32_t k0 = (uint32_t)p.loss_seed, k1 = (uint32_t)(p.loss_seed >> 32);
-        const int LC = p.loss_C, nitem = 64 * LC;
-        const unsigned long long HWl = (unsigned long long)H * W;
+        const int lde = p.loss_lde, nseg = lde >> 3, nitem = 256 * nseg;
+        const char* const erow0 = (const char*)p.loss_eps + (((long long)b * H + oh0) * W + ow0) * (long long)lde * 2;
         float local = 0.f;
         for (int it = tid_e; it < nitem; it += T3_NTHR) {
-            const int quad = it / LC, c = it - quad * LC;
-            const int r = quad >> 2, q4 = quad & 3;
-            const unsigned long long e = ((unsigned long long)b * LC + c) * HWl + (unsigned long long)(oh0 + r) * W + ow0 + 4 * q4;
-            const f32x4_t ep = philox_normal4(k0, k1, e >> 2);
-            // eps as VALUES before the subtraction (pointwise.hip, sq_err_tiled_kernel): hipcc would contract the Box-Muller product
-            // with the difference -- one rounding less than the unfused kernel, which reads a materialised eps tile
-            float e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
-            asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
-            const float ev[4] = {e0, e1, e2, e3};
-            char* const q = O + (quad * 4) * T3_OS + c * 2;
+            const int R = it / nseg, cs = it - R * nseg;
+            const u32x4_t ev = *(const u32x4_t*)(erow0 + ((long long)(R >> 4) * W + (R & 15)) * lde * 2 + cs * 16);
+            char* const cell = O + R * T3_OS + cs * 16;
+            float yf[8], ef[8];
+            unpack16<T>(*(const u32x4_t*)cell, yf);
+            unpack16<f16_t>(ev, ef);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                T* const cell = (T*)(q + j * T3_OS);
-                const float d = Elem<T>::ld(cell) - ev[j];
+            for (int e = 0; e < 8; ++e) {
+                const float d = yf[e] - ef[e];
                 local += d * d;
-                Elem<T>::st(cell, d * gs);
+                yf[e] = d * gs;
             }
+            *(u32x4_t*)cell = pack16<T>(yf);
         }
         local = wave_sum(local);
         if (lane_e == 0) atomicAdd(p.loss_sum, local);
@@ -376,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         for (int h = 0; h < 2; ++h) {
             auto& est = h == 0 ? est0 : est1;
             const char* const Oh = O + h * 128 * T3_OS;
-            if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+            if constexpr (EPI == 2 || EPI == 8) est.template finish_lnf<EPI == 8>(p, Oh, T3_OS, tid_e, b);
             else if constexpr (EPI == 3) est.template finish_ln_rows<false>(p, Oh, T3_OS, tid_e, b, dmsum);
             else if constexpr (EPI == 6) est.template finish_ln_rows<true>(p, Oh, T3_OS, tid_e, b, dmsum);
             else est.finish(p, Oh, T3_OS, tid_e);
@@ -392,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         __syncthreads();
         const char* const Oh = O + h * 128 * T3_OS;
         // EPI 2 / 3 / 4: instantiations that carry one epilogue only (picked by the launcher)
-        if constexpr (EPI == 2) est.finish_lnf(p, Oh, T3_OS, tid_e, b);
+        if constexpr (EPI == 2 || EPI == 8) est.template finish_lnf<EPI == 8>(p, Oh, T3_OS, tid_e, b);
         else if constexpr (EPI == 3 || EPI == 6) est.finish_ln(p, Oh, T3_OS, tid_e, b, red);
         else if constexpr (EPI == 4) est.finish(p, Oh, T3_OS, tid_e);
         else if (pool2) est.finish_pool2(p, Oh, T3_OS, tid_e, co0, ((long long)b * (H >> 1) + ((oh0 + 8 * h) >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
@@ -425,7 +420,7 @@ int t3_launch_as(const C2wConvArgs& a, hipStream_t st) {
 template <int TR, typename T, int NW>
 int t3_launch(const C2wConvArgs& a, hipStream_t st) {
     if (TR == 16 && (a.flags & C2W_CONV_POOL2) == 0) {
-        if (a.lnf_y != nullptr) return t3_launch_as<16, T, NW, 2>(a, st);
+        if (a.lnf_y != nullptr) return a.res_rstd != nullptr ? t3_launch_as<16, T, NW, 8>(a, st) : t3_launch_as<16, T, NW, 2>(a, st);  // 8: the residual rebuilt from normalised rows
         if (a.ln_x != nullptr) return a.ln_rstd != nullptr ? t3_launch_as<16, T, NW, 6>(a, st) : t3_launch_as<16, T, NW, 3>(a, st);
         if (a.loss_sum != nullptr) return t3_launch_as<16, T, NW, 7>(a, st);  // (c2w_conv_loss_supported: the narrow form's conditions)
         if (a.wrows <= 80 && a.Cout <= 128 && c2w_knobs().wgrad_narrow) return t3_launch_as<16, T, NW, 5>(a, st);  // the output conv: 65 weight rows

@@ -18,6 +18,7 @@ struct C2wKnobs {
     bool wgrad_narrow;    // C2W_NO_NARROW=1      edge convs (<= 80 output channels) NOT on the narrow forms of the halo-patch kernels
     bool wpacked;         // C2W_NO_WPACKED=1     c2w_conv_wpacked_supported answers 0 (callers hand over the plain [rows][9][Cin] weights)
     bool loss_fusion;     // C2W_NO_LOSS_FUSION=1 c2w_conv_loss_supported answers 0 (callers run the output conv and c2w_mse_loss_grad_noise)
+    bool ln_chain;        // C2W_NO_LN_CHAIN=1    c2w_conv_lnfwd_chain_supported answers 0 (every residual block writes its output)
     int conv_t3_min_wgs;  // C2W_CONV_T3_MIN_WGS=N  workgroups from which the 16x16-tile conv kernel replaces the 8x16 one (default 1024)
     int wgrad_wgs;        // C2W_WGRAD_WGS=N      workgroups a halo-patch weight-gradient launch splits its K range into (default 256: one per CU)
 };

@@ -471,6 +471,69 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __
     }
 }
 
+// nchw_to_nhwc_tiled_kernel<T, true> that KEEPS the noise (round 6): eps is rounded to half precision, mixed into x_t in that rounded
+// form and written as NHWC rows erows [B*HW][lde] -- the loss tail reads it back (conv_patch_t3_kernel EPI 7) instead of running the
+// generator a second time.  Second LDS tile [lde][LT_LD] for the noise.  HW % 4 == 0; 16-bit outputs.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_eps_kernel(const float* __restrict__ x, const float* __restrict__ musig, T* __restrict__ y,
+                                                               f16_t* __restrict__ erows, int B, int C, int HW, int ldc, int lde,
+                                                               long long img_stride, uint32_t k0, uint32_t k1,
+                                                               const long long* __restrict__ img_off) {
+    constexpr int P = Elem<T>::PER16;
+    static_assert(P == 8, "16-bit storage");
+    extern __shared__ float lt_tile[];
+    float* const et = lt_tile + (size_t)ldc * LT_LD;
+    const int ntile = (HW + LT_PT - 1) / LT_PT, nvec = ldc / P, nve = lde / 8;
+    const float* const x_all = x;
+    const int q = threadIdx.x & (LT_PT / 4 - 1), cb = threadIdx.x / (LT_PT / 4);
+    const int cmax = ldc > lde ? ldc : lde;
+    for (int blk = blockIdx.x; blk < B * ntile; blk += gridDim.x) {
+        const int b = blk / ntile, p0 = (blk - b * ntile) * LT_PT;
+        if (img_off != nullptr) x = x_all + (img_off[b] - (long long)b * img_stride);
+        const float mu = musig[2 * b], sg = musig[2 * b + 1];
+        const bool in = p0 + 4 * q < HW;
+#pragma unroll 2
+        for (int c = cb; c < cmax; c += 256 / (LT_PT / 4)) {
+            f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f}, e = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (c < C && in) {
+                const size_t o = (size_t)b * img_stride + (size_t)c * HW + p0 + 4 * q;
+                const f32x4_t xv = *(const f32x4_t*)(x + o);
+                const f32x4_t en = philox_normal4(k0, k1, (unsigned long long)o >> 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e[k] = (float)(f16_t)en[k];  // the step's noise: the stream rounded to half precision (RNE), here and in the loss
+                    v[k] = __fmaf_rn(sg, e[k], __fmul_rn(mu, xv[k]));
+                }
+            }
+            if (c < ldc) {
+                float* d = lt_tile + c * LT_LD + 4 * q;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+            if (c < lde) {
+                float* d = et + c * LT_LD + 4 * q;
+                d[0] = e[0]; d[1] = e[1]; d[2] = e[2]; d[3] = e[3];
+            }
+        }
+        __syncthreads();
+        const int npx = min(LT_PT, HW - p0);
+        for (int i = threadIdx.x; i < npx * nvec; i += 256) {
+            const int px = i / nvec, v = i - px * nvec;
+            float f[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) f[k] = lt_tile[(v * P + k) * LT_LD + px];
+            *(u32x4_t*)(y + ((size_t)b * HW + p0) * ldc + (size_t)i * P) = pack16<T>(f);
+        }
+        for (int i = threadIdx.x; i < npx * nve; i += 256) {
+            const int px = i / nve, v = i - px * nve;
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = et[(v * 8 + k) * LT_LD + px];
+            *(u32x4_t*)(erows + ((size_t)b * HW + p0) * lde + (size_t)i * 8) = pack16<f16_t>(f);
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, bool PHILOX = false>
 __global__ __launch_bounds__(256) void mse_loss_grad_tiled_kernel(const T* __restrict__ y, const float* __restrict__ eps, T* __restrict__ dy,
                                                                   float* __restrict__ loss_sum, int B, int C, int HW, int ldc, float gscale,
@@ -942,6 +1005,21 @@ extern "C" int c2w_nchw_to_nhwc_noise(const float* x, unsigned long long seed, c
     const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
     DISPATCH_T(dtype, (nchw_to_nhwc_tiled_kernel<T, true><<<nblk, 256, lds, (hipStream_t)stream>>>(
                           x, nullptr, musig, (T*)y, B, C, HW, ldc, (long long)C * HW, (uint32_t)seed, (uint32_t)(seed >> 32))));
+    return (int)hipGetLastError();
+}
+
+extern "C" int c2w_nchw_to_nhwc_noise_rows(const float* x, const long long* img_off, unsigned long long seed, const float* musig, void* y, void* erows,
+                                           int B, int C, int HW, int ldc, int lde, int dtype, void* stream) {
+    if (!x || !y || !erows || !musig || dtype == C2W_DTYPE_F32 || !vec_ok(dtype, ldc) || ldc < C || lde < C || (lde & 7) != 0) return C2W_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)(ldc + lde) * LT_LD * sizeof(float);
+    if (lds > 64 * 1024 || (HW & 3) != 0) return C2W_ERR_UNSUPPORTED;  // callers fall back to the regenerating pair
+    const int nblk = (int)std::min<long long>((long long)B * ((HW + LT_PT - 1) / LT_PT), 65536);
+    if (dtype == C2W_DTYPE_BF16)
+        nchw_to_nhwc_eps_kernel<bf16_t><<<nblk, 256, lds, (hipStream_t)stream>>>(x, musig, (bf16_t*)y, (f16_t*)erows, B, C, HW, ldc, lde, (long long)C * HW,
+                                                                               (uint32_t)seed, (uint32_t)(seed >> 32), img_off);
+    else
+        nchw_to_nhwc_eps_kernel<f16_t><<<nblk, 256, lds, (hipStream_t)stream>>>(x, musig, (f16_t*)y, (f16_t*)erows, B, C, HW, ldc, lde, (long long)C * HW,
+                                                                              (uint32_t)seed, (uint32_t)(seed >> 32), img_off);
     return (int)hipGetLastError();
 }
 

@@ -754,9 +754,10 @@ class Engine:
         None is returned; otherwise the NHWC output rows are returned and the caller scatters them.
         noise = (eps, musig): fuse the forward noise process x_t = mu x + sigma eps into the input conversion; eps may be an int
         seed instead of a tensor: the kernel regenerates the Philox stream of that seed (ops.philox_normal) and eps never exists.
-        ``loss`` (training, with ``nhwc_out``): dict(sum, seed, gscale[, scaler]) -- fuse the loss tail of src/thor/pipelines.py:35 into
-        the output convolution where the kernel exists (ops.conv_loss_supported): the returned rows are then dY = (prediction - eps) *
-        gscale, ``sum`` has received sum (prediction - eps)^2 and ``tape.meta["loss_fused"]`` is True; otherwise nothing changes.
+        ``loss`` (training, with ``nhwc_out`` and a noise SEED): dict(sum, gscale[, scaler]) -- fuse the loss tail of src/thor/pipelines.py:35
+        into the output convolution where the kernel exists (ops.conv_loss_supported): the input conversion keeps the noise it mixes in
+        (half-precision rows), the returned rows are dY = (prediction - eps) * gscale, ``sum`` has received sum (prediction - eps)^2 and
+        ``tape.meta["loss_fused"]`` is True; otherwise nothing changes.
         With ``tape`` every op records its backward closure (training / exact guidance)."""
         lay = self.layout
         self.refresh_version()
@@ -819,13 +820,30 @@ class Engine:
             dm_all = None
 
         # ---- network input -> NHWC
+        loss_rows = None  # (noise rows, channel stride) the input conversion kept for the fused loss tail
         if x_nhwc is not None:
             x0 = x_nhwc
         else:
             x0 = torch.empty((B * H * W, lay.cin_pad), dtype=T, device=dev)
             regen = noise is not None and isinstance(noise[0], int)  # regenerated noise: (seed, musig)
             done = False
-            if lazy:  # windows still inside the dataset array: convert them in place where the fused kernel takes the shape
+            # Fused loss tail (round 6): where the output conv takes it (ops.conv_loss_supported), the input conversion KEEPS the noise it
+            # mixes in -- rounded to half precision, as NHWC rows -- and the output conv's epilogue reads it back: the generator runs
+            # once per step instead of twice and the prediction is never written.  The step's noise is then the rounded stream.
+            if loss is not None and train and nhwc_out and regen and self.fuse_loss and dt != DTYPE_F32 and lay.out_channels == C and (H * W) % 4 == 0:
+                rec_o = lay.convs["unet." + lay.levels[0].tail_key]
+                g_o = self._geom(B, H, W, rec_o.kstride, H, W, lay.cout_pad, lay.cout_pad, rec_o.rows, CONV_S1)
+                if ops.conv_loss_supported(g_o, dt):
+                    lde = _round_up(C, 8)
+                    erows = torch.empty((B * H * W, lde), dtype=torch.float16, device=dev)
+                    src, offs = (x.data, x.offsets()) if lazy else (x, None)
+                    if (not lazy or (x.data.is_contiguous() and x.data.dtype == torch.float32)) and \
+                            ops.nchw_to_nhwc_noise_rows(src, offs, noise[0], noise[1], x0, erows, B, C, H * W, lay.cin_pad, lde, dt):
+                        done = True
+                        loss_rows = (erows, lde)
+            if done:
+                pass
+            elif lazy:  # windows still inside the dataset array: convert them in place where the fused kernel takes the shape
                 done = regen and x.data.is_contiguous() and x.data.dtype == torch.float32 and \
                     ops.windows_to_nhwc_noise(x.data, x.offsets(), noise[0], noise[1], x0, B, C, H * W, lay.cin_pad, dt)
                 if not done:
@@ -840,28 +858,35 @@ class Engine:
             else:
                 ops.nchw_to_nhwc(x, noise[0] if noise else None, noise[1] if noise else None, x0, B, C, H * W, lay.cin_pad, dt)
 
-        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None, want_ln=None, loss=None):
+        def conv3(name, xin, Hi, Wi, Ho, Wo, mode, act=ACT_NONE, res=None, ldy=None, cout=None, y2=None, want_ln=None, loss=None,
+                  resn=None, no_y=False):
             """want_ln: None, or the consumer's LayerNorm to emit from this conv's epilogue: ("mod", modulation rows) for a
-            residual block, ("plain", None) for an up-block.  Returns (y, geometry, record[, LN output or None])."""
+            residual block, ("plain", None) for an up-block.  Returns (y, geometry, record[, LN output or None]).
+            The chain form (res_block): ``resn`` = dict(rstd, mean, m) -- ``res`` holds normalised rows and the residual is rebuilt from
+            them; ``no_y`` -- the result is not written (y is returned as None), the emitted LayerNorm keeps its mean next to its 1/sigma."""
             rec = lay.convs[name]
             ldy_ = ldy or rec.rows
-            y = torch.empty((B * Ho * Wo, ldy_), dtype=T, device=dev)
+            y = torch.empty((B * Ho * Wo, ldy_), dtype=T, device=dev) if not no_y else None
             g = self._geom(B, Hi, Wi, rec.kstride, Ho, Wo, cout or rec.rows, ldy_, rec.rows, mode)
             hn = None
             lnf = None
             if want_ln is not None and act == ACT_NONE and y2 is None and ops.conv_lnfwd_supported(g, dt):
-                hn = torch.empty_like(y)
+                hn = torch.empty((B * Ho * Wo, ldy_), dtype=T, device=dev)
                 lnf = dict(y=hn, m=want_ln[1], ldm=ldm if want_ln[1] is not None else 0, eps=LN_EPS, unbiased=self.ln_unbiased)
                 if train and self.keep_ln_stats and want_ln[0] == "mod":
                     # training: the epilogue also leaves every pixel row's 1/sigma; the block's backward then takes its LayerNorm
                     # statistics from here and the normalised rows (kept anyway: conv1's input) instead of recomputing both (res_block)
                     lnf["rstd"] = hn._c2w_rstd = torch.empty((B * Ho * Wo,), dtype=torch.float32, device=dev)
+                if no_y:
+                    lnf["mean"] = hn._c2w_mean = torch.empty((B * Ho * Wo,), dtype=torch.float32, device=dev)
+            if no_y or resn is not None:  # (the rebuilt residual lives in the LayerNorm-emitting epilogue; an output that is not written needs its statistics kept)
+                assert lnf is not None and (not no_y or "rstd" in lnf), "chain form without a fused LayerNorm (run_blocks decides both from the same answers)"
             # padded operand (network input at C = 65: rows of 128 channels): channels >= rec.cin are zero in x and in w -- a promise the
             # 16x16-tile kernel turns into fewer K steps
             wop, wpk = self._conv_weights("f", rec, dt, g)
-            ops.conv(xin, wop, self._b(rec), y, g, dt, act=act, res=res, y2=y2, lnf=lnf,
-                     kvalid=rec.cin if rec.kstride != rec.cin else 0, wpacked=wpk, loss=loss)
-            if self.debug_trace is not None:
+            ops.conv(xin, wop, self._b(rec), y if y is not None else hn, g, dt, act=act, res=res, y2=y2, lnf=lnf,
+                     kvalid=rec.cin if rec.kstride != rec.cin else 0, wpacked=wpk, loss=loss, resn=resn, no_y=no_y)
+            if self.debug_trace is not None and y is not None:
                 self.debug_trace.append((name, y, dict(x=xin, w=self._w(rec, dt), g=g, act=act, res=res)))
                 if hn is not None:
                     self.debug_trace.append((name + " [LayerNorm emitted]", hn))
@@ -883,14 +908,20 @@ class Engine:
                      kvalid=rec.rows if rec.dg_ld != rec.rows else 0, wpacked=wpk)
             return dx
 
-        def res_block(b: BlockSpec, xin, Hc, Wc, h0=None, want_ln=None):
+        def res_block(b: BlockSpec, xin, Hc, Wc, h0=None, want_ln=None, elide=False):
             """h0: LN(xin + m) if the producer of xin already emitted it; want_ln: the consumer's LayerNorm to emit from
-            conv2's epilogue (see conv3).  Returns (block output, consumer's LN input or None)."""
+            conv2's epilogue (see conv3).  Returns (block output, consumer's LN input or None).
+            The chain form (round 6; training, 16-bit, 128-channel levels on the 16x16-tile kernel): ``xin`` None -- the previous block did
+            not write its output; this block's residual is rebuilt inside conv2's epilogue from h0 and the statistics that came with it
+            (x = h0 / rstd + mean - m); ``elide`` -- this block does not write ITS output either (returned as None): the next block of the
+            side is its only reader besides the LayerNorm emitted here."""
             p = "unet." + b.key
             Cc = b.channels
             npix = B * Hc * Wc
             m = m_all.view(-1)[b.mod_offset:]
             rstd0 = getattr(h0, "_c2w_rstd", None) if h0 is not None else None
+            if xin is None:
+                assert rstd0 is not None and getattr(h0, "_c2w_mean", None) is not None
             if h0 is None:
                 h0 = torch.empty((npix, Cc), dtype=T, device=dev)
                 ops.ln_forward(xin, m, h0, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
@@ -901,7 +932,9 @@ class Engine:
             act_inf, act_train = (ACT_RELU, ACT_RELU_PAIR) if lay.activation == "relu" else (ACT_SILU, ACT_SILU_PAIR)
             h1, g1, r1 = conv3(p + ".residue.1", h0, Hc, Wc, Hc, Wc, CONV_S1, act=act_train if train else act_inf, y2=d1)
             if want_ln is not None:
-                out, g2, r2, hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin, want_ln=want_ln)
+                resn = dict(rstd=rstd0, mean=h0._c2w_mean, m=m) if xin is None else None
+                out, g2, r2, hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin if xin is not None else h0, want_ln=want_ln,
+                                        resn=resn, no_y=elide)
             else:
                 (out, g2, r2), hn = conv3(p + ".residue.3", h1, Hc, Wc, Hc, Wc, CONV_S1, res=xin), None
             if train:
@@ -918,6 +951,7 @@ class Engine:
                         lnb = dict(x=xin, m=m, dm=dm, ldm=ldm, eps=LN_EPS, unbiased=self.ln_unbiased)
                     dx = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc, res=gy, ln=lnb)
                     if dx is None:
+                        assert xin is not None, "chain form: the fused LayerNorm backward this block was built on is gone (knobs changed between forward and backward?)"
                         dh0 = dgrad(r1, da1, Hc, Wc, Hc, Wc, CONV_S1, Cc)
                         dx = torch.empty_like(dh0)
                         ops.ln_backward(dh0, xin, m, gy, dx, dm, npix, Hc * Wc, Cc, ldm, LN_EPS, self.ln_unbiased, dt)
@@ -983,16 +1017,32 @@ class Engine:
                 tape.done(rec.w_off)
                 return dx0
             tape.steps.append(bw_head0)
+        def chain_ok(Cc, Hc, Wc):
+            """Do conv2 (LayerNorm emission with lnf_mean / rebuilt residual / no output) and the next block's fused LayerNorm backward
+            exist for a residual block of this level?  One answer per level geometry."""
+            g = self._geom(B, Hc, Wc, Cc, Hc, Wc, Cc, Cc, Cc, CONV_S1)
+            return dt != DTYPE_F32 and ops.conv_lnfwd_chain_supported(g, dt) and ops.conv_lnbwd_supported(g, dt)
+
         def run_blocks(blocks, cur, Hc, Wc, h0, tail_ln):
             """The blocks of one level side in order.  Each residual block asks its producer -- the previous block's second
             conv -- for its LayerNorm input; ``tail_ln`` is what the consumer after the last block wants.  Returns the
             output and that consumer's LN input (None if it was not fused)."""
             hn = h0
+
+            def want_of(j):  # the LayerNorm block j's second conv emits for its consumer
+                nb = blocks[j + 1] if j + 1 < len(blocks) else None
+                return (mod_of(nb) if nb.kind == "res" else None) if nb is not None else tail_ln
             for j, b in enumerate(blocks):
                 if b.kind == "res":
                     nb = blocks[j + 1] if j + 1 < len(blocks) else None
-                    want = (mod_of(nb) if nb.kind == "res" else None) if nb is not None else tail_ln
-                    cur, hn = res_block(b, cur, Hc, Wc, h0=hn, want_ln=want)
+                    want = want_of(j)
+                    # chain form: this block's output has no reader but the next block of the side (its LayerNorm comes out of this
+                    # block's conv2, its residual add can rebuild the sum) -- where the kernels exist, it is not written.  The rebuilding
+                    # lives in the LayerNorm-emitting epilogue, so the NEXT block's conv2 must emit one too (a side's last block does
+                    # only in front of an up-block)
+                    elide = train and self.chain_blocks and self.keep_ln_stats and nb is not None and nb.kind == "res" and \
+                        want_of(j + 1) is not None and chain_ok(b.channels, Hc, Wc)
+                    cur, hn = res_block(b, cur, Hc, Wc, h0=hn, want_ln=want, elide=elide)
                 else:
                     cur, hn = attn_block(b, cur, Hc, Wc), None
             return cur, hn
@@ -1068,11 +1118,8 @@ class Engine:
                 if fold is not None and not train and nhwc_out and self._fold_output(fold, "unet." + lv.tail_key, xin, B, Hc, Wc, dt):
                     return None
                 lfuse = None
-                if loss is not None and train and nhwc_out and self.fuse_loss:
-                    rec_o = lay.convs["unet." + lv.tail_key]
-                    g_o = self._geom(B, Hc, Wc, rec_o.kstride, Hc, Wc, lay.cout_pad, lay.cout_pad, rec_o.rows, CONV_S1)
-                    if ops.conv_loss_supported(g_o, dt):
-                        lfuse = dict(loss, C=lay.out_channels)
+                if loss_rows is not None:
+                    lfuse = dict(sum=loss["sum"], gscale=loss["gscale"], scaler=loss.get("scaler"), eps=loss_rows[0], lde=loss_rows[1], C=lay.out_channels)
                 cur, g_t, r_t = conv3("unet." + lv.tail_key, xin, Hc, Wc, Hc, Wc, CONV_S1, ldy=lay.cout_pad, cout=lay.cout_pad, loss=lfuse)
                 if train:
                     tape.meta["loss_fused"] = lfuse is not None
@@ -1094,6 +1141,7 @@ class Engine:
         return y
 
     use_center_conv = os.environ.get("C2W_NO_CENTER_CONV") != "1"  # A/B knob
+    chain_blocks = os.environ.get("C2W_NO_LN_CHAIN") is None  # A/B knob: every residual block writes its output (rounds 1-5); the library reads the same variable
     fuse_loss = os.environ.get("C2W_NO_LOSS_FUSION") is None  # A/B knob: the loss tail as its own pass (rounds 1-5); the library reads the same variable
     use_gemv = os.environ.get("C2W_NO_GEMV") != "1"  # A/B knob: one-row Linear layers as matrix-vector products
 

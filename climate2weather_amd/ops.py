@@ -35,7 +35,7 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
-def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=None) -> ConvArgs:
+def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=None, resn=None) -> ConvArgs:
     a = ConvArgs(_p(x), _p(w), _p(bias), _p(res), _p(mul), _p(y), _p(y2), g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"],
                  g["Cout"], g["ldy"], g["wrows"], g["mode"], act, mulmode)
     if ln is not None:
@@ -45,27 +45,33 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
     if lnf is not None:
         a.lnf_y, a.lnf_m = _p(lnf["y"]), _p(lnf.get("m"))
         a.lnf_rstd = _p(lnf.get("rstd"))
+        a.lnf_mean = _p(lnf.get("mean"))
         a.ln_ldm, a.ln_unbiased, a.ln_eps = int(lnf.get("ldm", 0)), int(lnf["unbiased"]), float(lnf["eps"])
+    if resn is not None:  # `res` holds normalised rows: the residual is rebuilt as res / rstd + mean - m (c2w_hip.h, round 6)
+        a.res_rstd, a.res_mean, a.res_m = _p(resn["rstd"]), _p(resn["mean"]), _p(resn.get("m"))
     return a
 
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
-         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False, loss: Optional[dict] = None):
+         ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False, loss: Optional[dict] = None,
+         resn: Optional[dict] = None, no_y: bool = False):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased[, rstd]): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
     dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.  With ``rstd`` (what the forward's lnf kept), ``x`` holds the
     NORMALISED rows and ``m`` is not read.
     lnf = dict(y, m, ldm, eps, unbiased[, rstd]): also write y = LN(result + m), the consumer block's normalised input (and, with
     ``rstd``, every pixel row's 1/sigma) -- only where conv_lnfwd_supported(g, dtype) says so."""
-    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf)
+    a = _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2, ln, lnf, resn)
+    if no_y:  # with lnf: the result itself is not written (``y``: any valid pointer) -- only where conv_lnfwd_chain_supported says so; so are
+        a.flags |= _lib.CONV_NO_Y  # lnf["mean"] and ``resn`` = dict(rstd, mean[, m]): ``res`` holds normalised rows, the residual is rebuilt
     if pool2:  # y: [B][Hout/2][Wout/2][ldy] <- 2x2 sums of the result (only where conv_pool2_supported says so)
         a.flags |= _lib.CONV_POOL2
     if wpacked:  # w: the stage-major copy made by pack_conv_weights_batched (only where conv_wpacked_supported says so)
         a.flags |= _lib.CONV_WPACKED
     a.kvalid = int(kvalid)  # promise: input channels >= kvalid are all zero in x or in w (0: no promise)
-    if loss is not None:  # dict(sum, seed, gscale, C[, scaler]): y receives (result - eps(seed)) * gscale, sum += sum of squares -- only
+    if loss is not None:  # dict(sum, eps, lde, gscale, C[, scaler]): y receives (result - eps rows) * gscale, sum += sum of squares -- only
         a.loss_sum, a.loss_scaler = _p(loss["sum"]), _p(loss.get("scaler"))  # where conv_loss_supported(g, dtype) says so
-        a.loss_seed, a.loss_gscale, a.loss_C = int(loss["seed"]), float(loss["gscale"]), int(loss["C"])
+        a.loss_eps, a.loss_lde, a.loss_gscale, a.loss_C = _p(loss["eps"]), int(loss["lde"]), float(loss["gscale"]), int(loss["C"])
     check(_lib.load().c2w_conv_forward(ctypes.byref(a), dtype, int(naive), _stream()), "c2w_conv_forward")  # naive: 0 product, 1 direct, 2 gather
 
 
@@ -113,6 +119,11 @@ def conv_lnfwd_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
     return bool(_lib.load().c2w_conv_lnfwd_supported(ctypes.byref(a), dtype))
+
+
+def conv_lnfwd_chain_supported(g: dict, dtype: int) -> bool:
+    """True when c2w_conv_forward takes lnf["mean"] / resn / no_y for this geometry (include/c2w_hip.h)."""
+    return bool(_lib.load().c2w_conv_lnfwd_chain_supported(ctypes.byref(_geom_args(g)), dtype))
 
 
 def conv_loss_supported(g: dict, dtype: int) -> bool:
@@ -257,6 +268,16 @@ def nchw_to_nhwc_noise(x, seed, musig, y, B, C, HW, ldc, dtype) -> bool:
     if rc == -3:
         return False
     check(rc, "c2w_nchw_to_nhwc_noise")
+    return True
+
+
+def nchw_to_nhwc_noise_rows(x, img_off, seed, musig, y, erows, B, C, HW, ldc, lde, dtype) -> bool:
+    """nchw_to_nhwc_noise (``img_off`` None) / windows_to_nhwc_noise that also writes the noise it mixed in, rounded to half precision,
+    as NHWC rows ``erows`` [B*HW][lde] float16 -- and mixes THAT rounded noise (include/c2w_hip.h).  False: shape not supported."""
+    rc = _lib.load().c2w_nchw_to_nhwc_noise_rows(_p(x), _p(img_off), int(seed), _p(musig), _p(y), _p(erows), B, C, HW, ldc, lde, dtype, _stream())
+    if rc == -3:
+        return False
+    check(rc, "c2w_nchw_to_nhwc_noise_rows")
     return True
 
 

@@ -295,9 +295,10 @@ class Trainer:
         self.loss_sum.zero_()
         n = B * C * H * W
         gs = 2.0 * self.loss_scaling / n
-        # regenerated noise: the loss tail rides the output convolution's epilogue where that kernel exists (the prediction is then never
-        # written; round 6) -- eng.forward returns dY and says so in tape.meta
-        lf = dict(sum=self.loss_sum, seed=seed, gscale=gs, scaler=self.scaler) if (seed is not None and H * W % 4 == 0) else None
+        # regenerated noise: the loss tail rides the output convolution's epilogue where that kernel exists (round 6: the prediction is
+        # never written, the noise is generated once -- the input conversion keeps it as half-precision rows, and the step's noise IS
+        # that rounded stream) -- eng.forward returns dY and says so in tape.meta
+        lf = dict(sum=self.loss_sum, gscale=gs, scaler=self.scaler) if seed is not None else None
         y = eng.forward(x, t, self.dt, tape=tape, noise=(seed if seed is not None else eps, musig), nhwc_out=True, loss=lf)
         if tape.meta.get("loss_fused"):
             eng.backward(tape, y)

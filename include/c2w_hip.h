@@ -42,7 +42,7 @@ enum {
  * y = max(a, 0), y2 = (a > 0) -- the backward pass multiplies by y2 with C2W_MUL_PLAIN. */
 enum { C2W_ACT_NONE = 0, C2W_ACT_SILU = 1, C2W_ACT_SILU_PAIR = 2, C2W_ACT_RELU = 3, C2W_ACT_RELU_PAIR = 4 };
 enum { C2W_MUL_PLAIN = 0, C2W_MUL_DSILU = 1 };
-enum { C2W_CONV_POOL2 = 1, C2W_CONV_WPACKED = 2 }; /* C2wConvArgs.flags (bit set) */
+enum { C2W_CONV_POOL2 = 1, C2W_CONV_WPACKED = 2, C2W_CONV_NO_Y = 4 }; /* C2wConvArgs.flags (bit set) */
 
 /* y[q][co] = act( sum_{tap,ci} w[co][tap][ci] * x[src(q,tap)][ci] + bias[co] ) (* mul' ) (+ res)
  * q runs over the B*Hout*Wout output pixels in NHWC raster order. */
@@ -94,17 +94,33 @@ typedef struct C2wConvArgs {
      *   four 16-lane reductions per pixel row and the modulation add leave the epilogue (model/nn.py:28,154 backward). */
     float* lnf_rstd;
     const float* ln_rstd;
+    /* Optional, with lnf_y (round 6; see c2w_conv_lnfwd_chain_supported) -- a chain of residual blocks (model/nn.py:27-28,146-159) whose
+     * intermediate outputs are never written: block k's second conv reads its residual x_k, adds its result, and emits the next
+     * block's normalised input h_{k+1} = LN(x_{k+1} + m_{k+1}) together with that LayerNorm's per-pixel mean and 1/sigma; x_{k+1} itself
+     * is read by nothing but block k+1's residual add, which can rebuild it from what was emitted:  x = h / rstd + mean - m.
+     *   lnf_mean:  [B*Hout*Wout] fp32, the mean of every pixel row this launch normalises (next to lnf_rstd), or NULL;
+     *   res_rstd, res_mean, res_m (all or none): `res` holds NORMALISED rows h = LN(x + res_m[b]) (an earlier launch's lnf_y) and these
+     *     are that LayerNorm's lnf_rstd / lnf_mean and its modulation rows (stride ln_ldm, NULL = none): the residual added is
+     *     h / res_rstd + res_mean - res_m[b];
+     *   flags & C2W_CONV_NO_Y: y is not written (pass any valid pointer); lnf_y then normalises the fp32 sum instead of its 16-bit
+     *     rounding.  537 MB less per launch at 128 channels x 128^2 x 128 windows. */
+    float* lnf_mean;
+    const float* res_rstd;
+    const float* res_mean;
+    const float* res_m;
     /* Optional fused training loss (round 6; see c2w_conv_loss_supported): with loss_sum != NULL the conv result itself is not
-     * stored.  Instead, with eps = the Philox stream of loss_seed (c2w_philox_normal; element index = NCHW linear index over
-     * [B][loss_C][Hout][Wout]) and a = the result rounded to the storage type, loss_sum += sum (a - eps)^2 over the loss_C real
-     * channels and y = (a - eps) * loss_gscale [* loss_scaler[0]] (channels >= loss_C: zero) -- c2w_mse_loss_grad_noise applied to
-     * the network-output conv's tile while it is still on chip (src/thor/pipelines.py:35, training_loop.py:376-377: the loss and
-     * the gradient the backward pass starts from; the prediction is used by nothing else in a training step). */
+     * stored.  Instead, with eps = the noise rows loss_eps ([B*Hout*Wout][loss_lde] IEEE half, NHWC like y; written by
+     * c2w_nchw_to_nhwc_noise_rows next to the noised input they were mixed into) and a = the result rounded to the storage type,
+     * loss_sum += sum (a - eps)^2 over the loss_C real channels and y = (a - eps) * loss_gscale [* loss_scaler[0]] (channels >=
+     * loss_C: zero) -- c2w_mse_loss_grad applied to the network-output conv's tile while it is still on chip
+     * (src/thor/pipelines.py:35, training_loop.py:376-377: the loss and the gradient the backward pass starts from; the prediction
+     * is used by nothing else in a training step). */
     float* loss_sum;          /* one fp32, accumulated (atomics), or NULL = no fusion */
     const float* loss_scaler; /* device-resident loss scale (fp16 training, c2w_grad_scaler_*) or NULL */
-    unsigned long long loss_seed;
+    const void* loss_eps;     /* half rows, channels loss_C .. loss_lde-1 zero */
     float loss_gscale;
     int32_t loss_C;
+    int32_t loss_lde;         /* channel stride of loss_eps: a multiple of 8, loss_C <= loss_lde <= 128 */
 } C2wConvArgs;
 
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
@@ -119,10 +135,12 @@ int c2w_conv_lnfwd_supported(const C2wConvArgs* args, int dtype);
 /* 1 when c2w_conv_forward can run args with the fused LayerNorm backward (bf16, Cout == ldy == 128, 3x3 stride-1 on an
  * image the halo-patch kernel tiles, no mul / act / y2), else 0.  Callers fall back to conv + c2w_ln_backward. */
 int c2w_conv_lnbwd_supported(const C2wConvArgs* args, int dtype);
+/* 1 when c2w_conv_forward takes lnf_mean / res_rstd + res_mean + res_m / C2W_CONV_NO_Y for this geometry (c2w_conv_lnfwd_supported's
+ * conditions on the 16x16-tile kernel).  Elsewhere those fields make the call fail with C2W_ERR_BAD_SHAPE. */
+int c2w_conv_lnfwd_chain_supported(const C2wConvArgs* args, int dtype);
 /* 1 when c2w_conv_forward can run args with the fused training loss (loss_sum / loss_seed / loss_gscale / loss_C): 16-bit, 3x3
  * stride-1 on the 16x16-tile kernel, at most 80 weight rows in rows of 128 channels (the network-output conv, model/nn.py:194),
- * loss_C <= wrows, Wout % 16 == 0, no res / mul / act / y2 / LayerNorm fusion.  Otherwise callers run the conv and
- * c2w_mse_loss_grad_noise. */
+ * loss_C <= wrows, no res / mul / act / y2 / LayerNorm fusion.  Otherwise callers run the conv and c2w_mse_loss_grad[_noise]. */
 int c2w_conv_loss_supported(const C2wConvArgs* args, int dtype);
 
 /* Which kernel family c2w_conv_forward (naive == 0) / c2w_conv_wgrad run these arguments on -- a pure function of the geometry,
@@ -201,6 +219,13 @@ int c2w_upsample2(const void* x, void* y, int B, int H, int W, int C, int dtype,
 int c2w_nchw_to_nhwc(const float* x, const float* eps, const float* musig, void* y, int B, int C, int HW, int ldc,
                      int dtype, void* stream);
 int c2w_nhwc_to_nchw(const void* y, float* out, int B, int C, int HW, int ldc, int dtype, void* stream);
+/* c2w_nchw_to_nhwc_noise (below) that also KEEPS the noise it mixed in: erows [B*HW][lde] IEEE half (lde = a multiple of 8 >= C,
+ * channels C .. lde-1 zero) receives eps rounded to half precision, and y = mu x + sigma * (that rounded value) -- the step's noise IS
+ * the rounded stream, so the loss tail (C2wConvArgs.loss_eps) reads back exactly what the input was noised with instead of running
+ * Philox + Box-Muller a second time (0.2 ms of VALU work per 128 windows).  img_off (may be NULL): as in c2w_windows_to_nhwc_noise.
+ * HW % 4 == 0.  C2W_ERR_UNSUPPORTED: shape outside the kernel (callers fall back to the *_noise pair). */
+int c2w_nchw_to_nhwc_noise_rows(const float* x, const long long* img_off, unsigned long long seed, const float* musig, void* y, void* erows,
+                                int B, int C, int HW, int ldc, int lde, int dtype, void* stream);
 /* loss tail (src/thor/pipelines.py:35, training_loop.py:377): loss_sum += sum (y-eps)^2 ; dy = (y-eps) * gscale */
 int c2w_mse_loss_grad(const void* y, const float* eps, void* dy, float* loss_sum, int B, int C, int HW, int ldc,
                       float gscale, int dtype, void* stream);

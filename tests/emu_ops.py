@@ -67,6 +67,13 @@ def conv_lnfwd_supported(g, dtype):
     return g["mode"] in (CONV_S1, CONV_UP) and g["Cout"] == g["ldy"]
 
 
+CHAIN = True  # tests flip it: does the emulation offer the chain form (residual blocks whose intermediate outputs are never written)?
+
+
+def conv_lnfwd_chain_supported(g, dtype):
+    return CHAIN and conv_lnfwd_supported(g, dtype) and g["mode"] == CONV_S1 and dtype != DTYPE_F32
+
+
 def conv_loss_supported(g, dtype):
     return False  # the emulation has no Philox stream: trainers on the CPU inject eps and run the separate loss tail
 
@@ -98,12 +105,38 @@ def pack_conv_weights_batched(src, dst, desc, n, dtype):
 
 
 def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False, kvalid=0,
-         wpacked=False, loss=None):
+         wpacked=False, loss=None, resn=None, no_y=False):
     assert loss is None, "conv_loss_supported() is False here: nobody may ask the emulation for the fused loss"
     if wpacked:
         assert conv_wpacked_supported(g, dtype)
-        return conv(x, -w.reshape(-1)[: g["wrows"] * 9 * g["Cin"]], bias, y, g, dtype, act, res, mul, mulmode, naive, y2, ln, lnf, pool2, kvalid)
+        return conv(x, -w.reshape(-1)[: g["wrows"] * 9 * g["Cin"]], bias, y, g, dtype, act, res, mul, mulmode, naive, y2, ln, lnf, pool2, kvalid,
+                    resn=resn, no_y=no_y)
     # kvalid: a promise that input channels >= kvalid are zero (the HIP kernels may skip them); the restatement multiplies everything
+    if resn is not None or no_y or (lnf is not None and lnf.get("mean") is not None):
+        # the chain form (c2w_hip.h, round 6): residual rebuilt from normalised rows, the sum not written, the LayerNorm's mean kept
+        assert lnf is not None and ln is None and mul is None and y2 is None and act == ACT_NONE and conv_lnfwd_chain_supported(g, dtype)
+        npix, HW, C, T = g["B"] * g["Hout"] * g["Wout"], g["Hout"] * g["Wout"], g["Cout"], TD[dtype]
+        tmp = torch.zeros((npix, g["ldy"]), dtype=T, device=x.device)
+        conv(x, w, bias, tmp, g, dtype)
+        u = tmp[:, :C].float()  # the conv result rounded to the storage type (the tile in LDS)
+        if resn is not None:
+            hrows = _rows(res, npix, g["ldy"])[:, :C].float()
+            sig = 1.0 / resn["rstd"].reshape(-1)[:npix].float().unsqueeze(1)
+            u = u + (hrows * sig + (resn["mean"].reshape(-1)[:npix].float().unsqueeze(1) - _mrows(resn.get("m"), npix, HW, C, lnf.get("ldm", 0))))
+        elif res is not None:
+            u = u + _rows(res, npix, g["ldy"])[:, :C].float()
+        if not no_y:
+            _rows(y, npix, g["ldy"])[:, :C] = u.to(T)
+            u = u.to(T).float()
+        xm = u + _mrows(lnf.get("m"), npix, HW, C, lnf.get("ldm", 0))
+        var, mean = torch.var_mean(xm, dim=1, unbiased=bool(lnf["unbiased"]), keepdim=True)
+        rs = (var + lnf["eps"]).rsqrt()
+        _rows(lnf["y"], npix, g["ldy"])[:, :C] = ((xm - mean) * rs).to(T)
+        if lnf.get("rstd") is not None:
+            lnf["rstd"].reshape(-1)[:npix] = rs.view(-1)
+        if lnf.get("mean") is not None:
+            lnf["mean"].reshape(-1)[:npix] = mean.view(-1)
+        return
     if lnf is not None:  # second output: LN of the stored result (+ the consumer's modulation)
         assert ln is None and mul is None and y2 is None and act == ACT_NONE
         conv(x, w, bias, y, g, dtype, res=res)

@@ -373,3 +373,54 @@ def test_weight_gradients_of_a_level_go_out_together_and_done_waits_for_them(emu
         for off, suffix in seen:
             assert torch.equal(suffix, final[off:]), f"gradients at or above offset {off} were still being written when it was reported done"
     assert len(seen1) < len(seen0)  # grouped: fewer, larger notifications
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_residual_blocks_whose_intermediate_outputs_are_never_written(emu, monkeypatch, precision):
+    """Round 6, the chain form of a level side (model/nn.py:27-28,146-159; engine.res_block): block k's second conv emits the next block's
+    normalised input with its mean and 1/sigma and does NOT write the block output; block k + 1 rebuilds its residual from them.  Against
+    the written form (emu_ops.CHAIN off) on a three-block level: same loss and gradients up to the 16-bit rounding the written form
+    applies to the intermediate outputs, and against the fp32 oracle inside the mode's usual tolerance; the launches are counted."""
+    from climate2weather_amd.training import Trainer
+    cfg = dict(embedding_dim=64, hidden_channels=[64, 64], hidden_blocks=[3, 2], attention_levels=[], kernel_size=3, padding_mode="zeros")
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 6, 16, 16, generator=gen) * 0.5 + 0.5
+    t, eps = torch.rand(2, generator=gen), torch.randn(2, 6, 16, 16, generator=gen)
+    calls = []
+    real_conv = c2w_ops.conv
+
+    def counting(*a, **k):
+        calls.append((bool(k.get("no_y")), k.get("resn") is not None, k.get("lnf") is not None and k["lnf"].get("mean") is not None))
+        return real_conv(*a, **k)
+    monkeypatch.setattr(c2w_ops, "conv", counting)
+    res = {}
+    for chain in (True, False):
+        monkeypatch.setattr(emu_ops, "CHAIN", chain)
+        calls.clear()
+        torch.manual_seed(5)
+        net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg)
+        tr = Trainer(net, precision=precision, ema_rates=())
+        tr.eng.flat_grad.zero_()
+        loss = tr._forward_backward(x, t, eps, sync=False)
+        S = tr.loss_scale()
+        res[chain] = (float(loss), tr.eng.flat_grad.clone() / S, list(calls))
+    no_y = [c for c in res[True][2] if c[0]]
+    # an output is not written when the NEXT block of the side emits a LayerNorm too (a side's last block does so only in front of an
+    # up-block: the ascent side of level 1): descent 0: 1 of 3, descent 1: 0 of 2, ascent 1: 1 of 2, ascent 0: 1 of 3 -- each with its
+    # mean kept, each followed by a block that rebuilds its residual
+    assert len(no_y) == 3 and all(c[2] for c in no_y) and sum(1 for c in res[True][2] if c[1]) == 3
+    assert not any(c[0] or c[1] or c[2] for c in res[False][2])
+    tol = 3e-2 if precision == "bf16" else 1e-2  # two 16-bit runs that round at different places (observed 6.3e-3 on a modulation projection in fp16)
+    assert abs(res[True][0] - res[False][0]) <= tol * abs(res[False][0])
+    ga, gb = res[True][1], res[False][1]
+    assert not torch.equal(ga, gb)
+    views = tr.eng.layout.views
+    for name, (off, shape, strides) in views.items():
+        n = int(np.prod(shape))
+        a, b_ = ga[off:off + n], gb[off:off + n]
+        assert (a - b_).abs().max().item() <= tol * max(b_.abs().max().item(), 1e-12), name
+    # and against the fp32 oracle
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    yo = ou.score_unet_forward(sd, od.perturb(x, t.view(-1, 1, 1, 1), eps), t, cfg["hidden_blocks"], cfg["attention_levels"])
+    lo = ((yo - eps) ** 2).mean()
+    assert abs(res[True][0] - lo.item()) <= tol * lo.item()

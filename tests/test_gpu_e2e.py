@@ -197,7 +197,8 @@ def _rl2_cos(a, b):
 # (relative L2 <=, cosine >=) per gradient tensor the fixtures hold (strided slices of 44 weight gradients incl. every modulation
 # projection, all 114 bias gradients in full).  Round 6; bounds = about twice the worst case observed on MI355X
 # (profiles/r06_full_grad_parity.txt)
-FULL_GRAD_L2COS = {"fp32": (1e-4, 1.0 - 1e-8), "bf16": (2e-2, 0.9995), "fp16": (3e-3, 0.99999)}
+# observed (4 identical runs, profiles/r06_full_grad_parity.txt): fp32 1.5e-6 / 1 - 1.1e-12; bf16 1.27e-2 / 1 - 7.3e-5; fp16 1.57e-3 / 1 - 1.1e-6
+FULL_GRAD_L2COS = {"fp32": (1e-5, 1.0 - 1e-10), "bf16": (2e-2, 1.0 - 1.5e-4), "fp16": (3e-3, 1.0 - 2.2e-6)}
 
 # (loss rel, output slice, per-tensor |g|_2 and sum|g| rel, gradient slices) -- all "of the scale": max|a - b| / max|b| for tensors
 # Observed on MI355X (profiles/r02_full_grad_parity.txt): fp32 2e-7 / 2e-6 / 6e-7 / 2e-6; bf16 4e-5 / 1e-2 / 3e-3 / 1.2e-2; fp16 3e-6 / 1.4e-3 / 4e-4 / 2e-3
@@ -256,6 +257,10 @@ def test_full_size_backward_vs_reference_gradients(golden_dir, C):
         report.append(f"C={C} {mode}: loss {e_loss:.2e}  y {e_y:.2e}  |g|_2 {e_norm[0]:.2e} ({e_norm[1]})  sum|g| {e_abs[0]:.2e} ({e_abs[1]})  "
                       f"slices {e_slice[0]:.2e} ({e_slice[1]})  | over {n_cmp} tensors: rel-L2 {e_l2[0]:.2e} ({e_l2[1]})  "
                       f"1-cos {1.0 - e_cos[0]:.2e} ({e_cos[1]})  | y rel-L2 {y_l2:.2e} 1-cos {1.0 - y_cos:.2e}")
+        if not (e_norm[0] <= tn and e_abs[0] <= tn and e_slice[0] <= ts and e_l2[0] <= FULL_GRAD_L2COS[mode][0]):
+            # keep the evidence of a mismatch (one run in six of round 6's first GPU call failed here in fp16 and never again): the worst tensors
+            os.makedirs("gpurun_out", exist_ok=True)
+            torch.save({n: grads[n] for n in {e_norm[1], e_abs[1], e_slice[1], e_l2[1]} if n}, os.path.join("gpurun_out", f"parity_fail_c{C}_{mode}.pt"))
         assert e_loss <= tl and e_y <= ty, report[-1]
         assert e_norm[0] <= tn and e_abs[0] <= tn, report[-1]
         assert e_slice[0] <= ts, report[-1]
