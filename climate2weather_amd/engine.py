@@ -254,7 +254,7 @@ class Engine:
         self.group_wgrads_top = max(1, int(os.environ.get("C2W_WGRAD_GROUP_TOP", "1")))
         self._wg_groups: Dict[tuple, list] = {}  # (geometry, dtype) -> [(x, dY, record, geometry)] not launched yet
         self._wg_group_ok: Dict[tuple, bool] = {}
-        self._done_release = None  # set by backward_steps: hands on the "done" offsets held back while a group was pending
+        self._done_releases: list = []  # one callback per live backward_steps generator: hands on the "done" offsets it held back while a group was pending
         self._pub = None  # ops.HostRing of published scalars (publish / published)
         self._skip_dw = False  # inside backward(want_dw=False): weight-gradient launches are skipped
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
@@ -646,8 +646,8 @@ class Engine:
                 lst.append((x, gy, rec, g))
                 if len(lst) >= cap:
                     self._flush_group(key)
-                    if not self._wg_groups and self._done_release is not None:
-                        self._done_release()
+                    if not self._wg_groups:
+                        self._release_done()
                 return
         self._on_grad_stream(lambda: ops.conv_wgrad(x, gy, self._gw(rec), g, dt, dbias=self._gb(rec), workspace=self.workspace()), x, gy)
 
@@ -671,8 +671,11 @@ class Engine:
         """Launch every queued weight gradient (one launch per geometry) and hand on the "done" offsets that were held back for them."""
         for key in list(self._wg_groups):
             self._flush_group(key)
-        if self._done_release is not None:
-            self._done_release()
+        self._release_done()
+
+    def _release_done(self) -> None:
+        for rel in list(self._done_releases):
+            rel()
 
     def _wgrad(self, rec: ConvRec, x: torch.Tensor, gy: torch.Tensor, g: dict, dt: int) -> None:
         """dW (+ dbias) of ``rec`` into the flat gradient buffer; a padded-operand layer goes through a padded scratch."""
@@ -1255,9 +1258,31 @@ class Engine:
             if held[0] is not None and not self._wg_groups:
                 off, held[0] = held[0], None
                 emit(off)
+        # Grouped weight gradients queued by ANOTHER backward that is still being consumed on this engine (two recorded forwards whose
+        # backward generators interleave: score.py::_GradSegment chains driven by autograd) are legitimate pending work: launch them and
+        # let that backward hand on the offsets it held, instead of dropping them silently (round-5 advisor finding).  What a backward
+        # that RAISED left behind is dropped by its own generator (the finally clause below), never seen here.
+        if self._wg_groups:
+            self.flush_wgrad_groups()
         tape.progress = progress
-        self._done_release = release
-        self._wg_groups.clear()  # (a backward that raised half-way may have left some behind)
+        self._done_releases.append(release)
+        completed = False
+        try:
+            dx0, m = yield from self._backward_body(tape, gy_nhwc, want_dx, want_dw, low, outer)
+            completed = True
+        finally:
+            if release in self._done_releases:
+                self._done_releases.remove(release)
+            if not completed:  # raised or closed half-way: queued launches hold tensors of a pass that will never finish
+                self._wg_groups.clear()
+                tape.progress = outer
+        if not want_dx or dx0 is None:
+            return None
+        dx = torch.empty((m["B"], m["C"], m["H"], m["W"]), dtype=torch.float32, device=dx0.device)
+        ops.nhwc_to_nchw(dx0, dx, m["B"], m["C"], m["H"] * m["W"], self.layout.cin_pad, m["dt"])
+        return dx
+
+    def _backward_body(self, tape: Tape, gy_nhwc: torch.Tensor, want_dx: bool, want_dw: bool, low, outer):
         if self._dg_ready is not None:  # operands prefetched on the gradient stream: this stream reads them from here on
             torch.cuda.current_stream().wait_event(self._dg_ready)
             self._dg_ready = None
@@ -1283,16 +1308,10 @@ class Engine:
                 gm = bw(gm)
                 yield low[0]
         self.join_grad_stream()  # every gradient is in flat_grad for whoever runs next on this stream (optimizer, autograd)
-        self._done_release = None
         tape.steps = []
         tape.gskip.clear()
         tape.progress = outer
-        if not want_dx or dx0 is None:
-            return None
-        m = tape.meta
-        dx = torch.empty((m["B"], m["C"], m["H"], m["W"]), dtype=torch.float32, device=dx0.device)
-        ops.nhwc_to_nchw(dx0, dx, m["B"], m["C"], m["H"] * m["W"], self.layout.cin_pad, m["dt"])
-        return dx
+        return dx0, tape.meta
 
 
 def _module_links(net, names):

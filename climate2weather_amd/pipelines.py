@@ -152,8 +152,14 @@ class SDAPipeline:
                             sumsq.zero_()
                             ops.sumsq(eps, sumsq, n)
                             ops.sampler_correct(x, eps, z, sumsq, nan_flag, n, tau, sg_n)
-                    if pending is not None and ring.read_bits(*pending):  # the flag as it stood behind the PREVIOUS step
-                        raise ValueError("NaN detected in sample")
+                    if pending is not None:  # the flag as it stood behind the PREVIOUS step
+                        bits = ring.read_bits(*pending)
+                        if bits is None:  # nothing arrived in time (or the slot was reused): say so instead of reading it as "no NaN"
+                            import warnings
+                            warnings.warn("SDAPipeline.sample: the NaN flag of the previous step did not arrive in pinned memory in time; "
+                                          "that step's check is skipped (the final check behind the loop still runs)", RuntimeWarning, stacklevel=2)
+                        elif bits:
+                            raise ValueError("NaN detected in sample")
                     pending = ring.publish(nan_flag)
                 else:
                     x = self._sample_step(score_fn, x, t, dt, proc_x0=proc_x0)

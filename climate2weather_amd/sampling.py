@@ -60,10 +60,15 @@ def run_ensemble(net, pipeline: Optional[SDAPipeline] = None, *, length: int, n_
         score_fn.condition_on(A=A, y=y, std=std, gamma=gamma, exact_grad=exact_grad)
     out = []
     if members_per_batch is None:
-        # Default: without a corrector (every shipped configuration, exp/configs/**) co-sampled members ARE the one-by-one members, so as
+        # Default: without a corrector (every shipped configuration, exp/configs/**) co-sampled members are the one-by-one members -- the
+        # same noise, the same arithmetic per window; in fp32 equal to 1e-4 (tested), in the 16-bit modes equal to ROUNDING only, because
+        # the kernel a layer runs on depends on the number of windows in the batch (tests/test_gpu_host.py: bf16 tolerance test) -- so as
         # many of this rank's members share the network batches as it takes to reach the score function's window floor (L = 49: 37
         # windows per member, 7 members; 6.4 k -> 9.2 k window-forwards/s).  With a corrector the normals would be drawn in another
         # order than the reference's loop draws them: one member at a time unless the caller asks.
+        # Observable differences from the reference's loop (exp/downscaling.py:248-265): on_sample fires for a group's members when the
+        # whole group has finished, and a NaN in ONE member (raised one step late, pipelines.HostRing) discards the group it was
+        # sampled with; members_per_batch=1 restores the reference's behaviour exactly.
         nwin = max(1, length - 2 * markov_order)
         floor = score_fn._window_floor(height * width) if corrections == 0 else 1
         group = min(per_gpu, max(1, -(-floor // nwin)))

@@ -34,6 +34,11 @@ from .ops import DTYPE_BF16, DTYPE_F16, DTYPE_F32, TORCH_DTYPE
 from .pipelines import SDAPipeline
 
 
+# C2W_EMULATE_COLLECTIVE_US=n (A/B runs with ONE rank, profiles/r06_experiments.md): n microseconds of spinning on the stream that waits for
+# each bucket's collective (torch.cuda._sleep counts ~2.35 GHz cycles on MI355X, climate2weather_amd/streams.py)
+_EMULATED_COLLECTIVE_CYCLES = int(float(os.environ.get("C2W_EMULATE_COLLECTIVE_US", "0") or 0) * 2350)
+
+
 def _current_stream(device):
     """(indirection: the emulated stream test swaps the two stream accessors)"""
     return torch.cuda.current_stream(device)
@@ -178,6 +183,11 @@ class Trainer:
                     wb.copy_(self.eng.flat_grad[s:e])
                     work = dist.all_reduce(wb, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                     work.wait()  # the COMMUNICATION stream waits for RCCL's (a stream-side wait; gloo: the host); the copy back must see the sum
+                    if _EMULATED_COLLECTIVE_CYCLES and wb.is_cuda:
+                        # measurement knob (one-rank runs: RCCL's all-reduce over a single rank launches no kernel at all): the stream that
+                        # waits for the collective is held for the time a 25-MB bucket takes over xGMI -- on the communication stream
+                        # that time must not show in the step, on the compute stream (C2W_COMM_ON_COMPUTE=1) all of it does
+                        torch.cuda._sleep(_EMULATED_COLLECTIVE_CYCLES)
                     self.eng.flat_grad[s:e].copy_(wb)
                     work = None
                 if self._chase is not None:

@@ -164,7 +164,7 @@ int c2w_conv_forward(const C2wConvArgs* args, int dtype, int naive, void* stream
  * workspace / workspace_bytes: caller-owned device scratch (16-byte aligned) for the split's partial sums, handed over PER CALL --
  * the library keeps no pointer, so the entry point is re-entrant: with it the workgroups store their partial tiles and a second
  * launch on the same stream reduces them in a fixed order (75 MB of coalesced stores + reads per launch instead of 75 MB of fp32
- * atomics; results are deterministic); NULL, or fewer bytes than c2w_conv_wgrad_workspace_bytes() asks for: fp32 atomics.
+ * atomics; dw is then bit-reproducible run to run -- dbias is NOT: every split workgroup adds its column sums with fp32 atomics); NULL, or fewer bytes than c2w_conv_wgrad_workspace_bytes() asks for: fp32 atomics.
  * Contents are undefined before and after the call.  One buffer must not be handed to launches that may run concurrently
  * (different streams without an ordering between them): give each stream its own.
  * Replaces autograd's weight/bias backward of every Conv2d/Conv1d/Linear cited above. */
@@ -178,7 +178,7 @@ long long c2w_conv_wgrad_workspace_bytes(const C2wConvArgs* args, int dtype);
  * residual-block convs of a UNet level (model/nn.py:146-159: 6 or 12 layers of one shape) have their output gradients one after the
  * other during the backward pass and independent weight gradients; a launch per layer must split its pixel reduction over the whole
  * chip (at 8x8: 8 K tiles per workgroup, each followed by 295 KB of partial sums), together the layers fill it with a fraction of
- * the splits.  `items` is a HOST array, copied into the kernel arguments (nothing is kept).  Results are deterministic (a fixed
+ * the splits.  `items` is a HOST array, copied into the kernel arguments (nothing is kept).  The dw results are deterministic (dbias: fp32 atomics across the split workgroups, last-bit order noise) (a fixed
  * reduction order) but differ in rounding from n single calls (another split of the same sum).
  * c2w_conv_wgrad_grouped_supported: 1 when the n layers run as one launch (2 <= n <= 16; the halo-patch geometries on
  * wgrad_patch_group_kernel, 1x1 layers -- the attention level's qkv / proj_out, model/nn.py:45,47 -- on wgrad_group_kernel); otherwise

@@ -424,3 +424,60 @@ def test_residual_blocks_whose_intermediate_outputs_are_never_written(emu, monke
     yo = ou.score_unet_forward(sd, od.perturb(x, t.view(-1, 1, 1, 1), eps), t, cfg["hidden_blocks"], cfg["attention_levels"])
     lo = ((yo - eps) ** 2).mean()
     assert abs(res[True][0] - lo.item()) <= tol * lo.item()
+
+
+def test_two_backward_passes_on_one_engine_may_interleave_and_one_may_fail(emu):
+    """Grouped weight gradients are queued on the engine between level boundaries.  (a) A second backward generator that starts while
+    another is half-consumed (two recorded forwards, their autograd chains interleaved) must not drop what the first one queued: both
+    passes' gradients add up to the two passes run one after the other.  (b) A backward that raises half-way drops its own queue -- the
+    next pass does not launch weight gradients of the dead one.  (Round-5 advisor finding: the queue used to be cleared at the start of
+    every pass.)"""
+    from climate2weather_amd.engine import Tape
+    from climate2weather_amd.ops import DTYPE_F32
+    net = _tiny()
+    eng = net._get_engine()
+    eng.ensure_grad_buffer()
+    gen = torch.Generator().manual_seed(9)
+    xs = [torch.randn(2, 6, 32, 32, generator=gen) for _ in range(2)]
+    ts = [torch.rand(2, generator=gen) for _ in range(2)]
+
+    def record(i):
+        tape = Tape()
+        y = eng.forward(xs[i], ts[i], DTYPE_F32, tape=tape, nhwc_out=True)
+        return tape, torch.ones_like(y) / y.numel()
+    # reference: one after the other
+    eng.flat_grad.zero_()
+    for i in range(2):
+        tape, gy = record(i)
+        eng.backward(tape, gy)
+    ref = eng.flat_grad.clone()
+    # (a) interleaved: A runs two closures (weight gradients queued, nothing launched), B runs to the end, A resumes
+    eng.flat_grad.zero_()
+    (ta, ga), (tb, gb) = record(0), record(1)
+    ita = eng.backward_steps(ta, ga)
+    for _ in range(2):  # the output conv, then a residual block: its two weight gradients are queued until the level boundary
+        next(ita)
+    assert eng._wg_groups  # something of pass A is queued
+    for _ in eng.backward_steps(tb, gb):
+        pass
+    for _ in ita:
+        pass
+    assert not eng._wg_groups and not eng._done_releases
+    assert torch.allclose(eng.flat_grad, ref, rtol=1e-5, atol=1e-7) and (eng.flat_grad - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    # (b) a pass that dies half-way leaves nothing behind
+    eng.flat_grad.zero_()
+    ta, ga = record(0)
+    ita = eng.backward_steps(ta, ga)
+    for _ in range(2):  # the output conv, then a residual block: its two weight gradients are queued until the level boundary
+        next(ita)
+    assert eng._wg_groups
+    ita.close()  # what an exception inside the consumer does to the generator
+    assert not eng._wg_groups and not eng._done_releases
+    eng.flat_grad.zero_()
+    tb, gb = record(1)
+    eng.backward(tb, gb)
+    only_b = eng.flat_grad.clone()
+    eng.flat_grad.zero_()
+    tb, gb = record(1)
+    eng.backward(tb, gb)
+    assert torch.equal(only_b, eng.flat_grad)
