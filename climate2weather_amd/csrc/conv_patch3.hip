@@ -354,8 +354,10 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
             }
             *(u32x4_t*)cell = pack16<T>(yf);
         }
+        // one atomic per WORKGROUP: with one per wave (65 k atomics on a single address per launch at B = 128) the launch took 0.90 ms
+        // instead of 0.42 -- the L2 serialises them; the waves' sums meet in LDS behind the tile, thread 0 adds them after the barrier below
         local = wave_sum(local);
-        if (lane_e == 0) atomicAdd(p.loss_sum, local);
+        if (lane_e == 0) red[tid_e >> 6] = local;
     }
     // both 8-row blocks' residual / multiplier rows are requested before the first block is finished: the second block's HBM latency
     // runs behind the first block's arithmetic and stores (the accumulators have left the registers, so both sets fit)
@@ -365,6 +367,14 @@ __global__ __launch_bounds__(64 * NW, (T3Cfg<TR, NW>::WAVES_PER_SIMD)) void conv
         est0.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0) * W + ow0, W);
         est1.prefetch_tile16(p, tid_e, co0, ((long long)b * H + oh0 + 8) * W + ow0, W);
         __syncthreads();
+        if constexpr (EPI == 7) {
+            if (tid_e == 0) {
+                float tot = 0.f;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) tot += red[i];
+                atomicAdd(p.loss_sum, tot);
+            }
+        }
         typename EpiStore<T, 128, T3_NTHR>::LnColSums dmsum;  // LayerNorm backward: modulation-gradient column sums, carried over both blocks
         if constexpr (EPI == 3 || EPI == 6) dmsum.clear();
 #pragma unroll

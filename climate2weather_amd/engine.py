@@ -1144,7 +1144,13 @@ class Engine:
         return y
 
     use_center_conv = os.environ.get("C2W_NO_CENTER_CONV") != "1"  # A/B knob
-    chain_blocks = os.environ.get("C2W_NO_LN_CHAIN") is None  # A/B knob: every residual block writes its output (rounds 1-5); the library reads the same variable
+    # Opt-in (C2W_LN_CHAIN=1 or the attribute): the chain form of a level side -- residual-block outputs that only the next block reads are
+    # not written, the next block rebuilds its residual from the LayerNorm rows this one emitted (res_block).  Measured at B = 128, bf16
+    # (profiles/r06_experiments.md): -0.23 ms per step (five 128-channel launches lose their 537 / 134 MB store), but the rebuilt
+    # residual carries the rounding of h = LN(x + m) scaled by sigma -- 2^-9 |x + m - mean| instead of 2^-9 |x| -- and where the modulation
+    # dominates the block input that is MORE than rounding x itself: against the CPU oracle the worst gradient tensor moves from
+    # 8.7e-3 to 1.7e-2 relative L2 (bf16; fp16 5e-3 -> 8.5e-3 of the output scale).  Parity before 0.5 %: off.
+    chain_blocks = os.environ.get("C2W_LN_CHAIN") == "1"
     fuse_loss = os.environ.get("C2W_NO_LOSS_FUSION") is None  # A/B knob: the loss tail as its own pass (rounds 1-5); the library reads the same variable
     use_gemv = os.environ.get("C2W_NO_GEMV") != "1"  # A/B knob: one-row Linear layers as matrix-vector products
 

@@ -400,6 +400,7 @@ def test_residual_blocks_whose_intermediate_outputs_are_never_written(emu, monke
         torch.manual_seed(5)
         net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, **cfg)
         tr = Trainer(net, precision=precision, ema_rates=())
+        tr.eng.chain_blocks = True  # opt-in (engine.Engine.chain_blocks); the emulation's CHAIN switch stands for the kernels' existence
         tr.eng.flat_grad.zero_()
         loss = tr._forward_backward(x, t, eps, sync=False)
         S = tr.loss_scale()

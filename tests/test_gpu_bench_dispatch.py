@@ -383,6 +383,7 @@ def test_step_with_the_fused_loss_tail_equals_the_step_on_the_materialised_noise
     x = (torch.randn(B, C, H, H, generator=gen) * 0.5 + 0.5).cuda()
     t = torch.rand(B, generator=gen).cuda()
     tr = Trainer(net, precision=mode, ema_rates=(), seed=3)
+    tr.eng.chain_blocks = True  # opt-in: the first two runs use the chain form, the third the written form
     launches = []
     real = ops.conv
 
@@ -418,7 +419,7 @@ def test_step_with_the_fused_loss_tail_equals_the_step_on_the_materialised_noise
     # outputs not written at B = 16: the 128^2 level only (1024 workgroups: the 16x16-tile kernel), descent 1 + ascent 1 (engine.run_blocks;
     # at the bench's B = 128 the 64^2 level adds descent 1 + ascent 2); each followed by a rebuilt residual
     assert sum(1 for f in n_plain if f[1]) == 2 and sum(1 for f in n_plain if f[2]) == 2 and not any(f[1] or f[2] for f in n_written)
-    assert l_fused == pytest.approx(l_plain, rel=2e-6)
+    assert l_fused == pytest.approx(l_plain, rel=2e-5)
     S = tr.loss_scale()
     for n_, p in net.named_parameters():
         if p.dim() != 4:
@@ -547,13 +548,13 @@ def test_loss_tail_fused_into_the_output_convolution(dt, packed, C, scaled):
     torch.cuda.synchronize()
     assert torch.equal(dy, dy_ref)
     assert dy[:, :C].float().abs().sum().item() > 0 and dy[:, C:].float().abs().max().item() == 0.0  # padding channels: zero gradient
-    assert ls.item() == pytest.approx(ls_ref.item(), rel=2e-6)
+    assert ls.item() == pytest.approx(ls_ref.item(), rel=2e-5)  # 17 M squares summed in another order (fp32)
     d = y[:, :C].float() - er[:, :C].float()
     assert ls.item() == pytest.approx((d.double() ** 2).sum().item(), rel=2e-5)
     assert torch.equal(dy[:, :C], (d * (gs * (512.0 if scaled else 1.0))).to(TD[dt]))
     # a second launch ACCUMULATES into loss_sum (the trainer zeroes it per round)
     ops.conv(x, wop, bias, dy, g, dt, wpacked=packed, loss=lf)
-    assert ls.item() == pytest.approx(2 * ls_ref.item(), rel=4e-6)
+    assert ls.item() == pytest.approx(2 * ls_ref.item(), rel=2e-5)
 
 
 def test_loss_fusion_is_refused_where_the_kernel_does_not_exist():
