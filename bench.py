@@ -431,10 +431,11 @@ def run_rank(a):
     out = None
     if rank == 0:
         # Dominant kernel: the 3x3 residual-block conv at full resolution (128 -> 128 @128x128: 24 of the 70 convs of a forward and the
-        # same again as input gradients).  Its forward launches have the chip to themselves; its input-gradient launches share it with
-        # the weight-gradient stream (engine.grad_stream), so their durations include that interference.  The roofline is priced on the
-        # launches that run alone (the kernel's own rate); the average over every launch is reported beside it (it is what
-        # `rocprofv3 --stats` averages; tools/rocprof_db_stats.py splits a trace the same way).
+        # same again as input gradients).  Since round 5 the whole step runs on ONE stream: every launch has the chip to itself, forward
+        # and input-gradient alike (with C2W_WGRAD_STREAM=1 the input-gradient launches share it with the weight-gradient stream).  The
+        # roofline is priced on the FORWARD launches (bias / SiLU pair / residual / LayerNorm-emission epilogues); the average over every
+        # launch of the same layers, input gradients included (LayerNorm-backward epilogues), is reported beside it -- it is what
+        # `rocprofv3 --stats` averages.
         dom_f = timer.summarise(lambda rec, kind: kind == "fwd", steps=a.steps)
         dom_a = timer.summarise(steps=a.steps)
         gf_fwd = GFLOP_FWD.get(C, 116.0) if a.size == 128 else None
@@ -448,11 +449,12 @@ def run_rank(a):
             roof = dict(bound="mfma",
                         kernel=f"conv_patch_t3_kernel<16> ({a.precision}): {kname}, residual-block conv forward launches (bias / SiLU / residual / LayerNorm "
                                "epilogues included; they run alone on the chip); network-input / output convs are NOT in this set",
+                        kernel_short=f"conv_patch_t3_kernel<16,{a.precision}> {kname}: forward launches, fused epilogues included"[:150],
                         achieved=kf["tflops"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=kf["frac"],
                         launches_timed=int(round(kf["launches_per_step"] * a.steps)), avg_launch_ms=kf["avg_ms"],
                         flops_per_launch=kf["gflop_per_launch"] * 1e9,
                         **pmc_traffic(a),
-                        all_launches=dict(note="forward + input-gradient launches of the same layers; the latter overlap the weight-gradient stream",
+                        all_launches=dict(note="forward + input-gradient launches of the same layers (one stream: each runs alone; the latter carry the LayerNorm-backward epilogues)",
                                           launches_timed=int(round(all_n * a.steps)), avg_launch_ms=round(all_ms / all_n, 4) if all_n else None,
                                           achieved=round(all_tf, 1), frac=round(all_tf / MFMA_PEAK_TFLOPS, 4)))
         out = dict(metric="UNet denoise steps/sec (train fwd+bwd+allreduce+AdamW+EMA windows/s)", value=round(value, 2), unit="windows/s",

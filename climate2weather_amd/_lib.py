@@ -34,7 +34,7 @@ class ConvArgs(Structure):
         ("lnf_rstd", c_void_p), ("ln_rstd", c_void_p),
         ("lnf_mean", c_void_p), ("res_rstd", c_void_p), ("res_mean", c_void_p), ("res_m", c_void_p),
         ("loss_sum", c_void_p), ("loss_scaler", c_void_p), ("loss_eps", c_void_p), ("loss_gscale", c_float), ("loss_C", c_int32),
-        ("loss_lde", c_int32),
+        ("loss_lde", c_int32), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_ulonglong), ("splitk", c_int32),
     ]
 
 
@@ -48,6 +48,7 @@ _PROTOS = {
     "c2w_conv_lnbwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_lnfwd_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_loss_supported": [POINTER(ConvArgs), c_int],
+    "c2w_conv_splitk_plan": [POINTER(ConvArgs), c_int, POINTER(c_ulonglong)],
     "c2w_conv_lnfwd_chain_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_patch_supported": [POINTER(ConvArgs), c_int],
     "c2w_conv_pool2_supported": [POINTER(ConvArgs), c_int],

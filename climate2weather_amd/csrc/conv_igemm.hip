@@ -368,7 +368,8 @@ C2wKnobs read_knobs() {
     k.wgrad_atomics = getenv("C2W_WGRAD_ATOMICS") != nullptr;
     k.loss_fusion = getenv("C2W_NO_LOSS_FUSION") == nullptr;
     k.ln_chain = getenv("C2W_NO_LN_CHAIN") == nullptr;
-    k.conv_t3_min_wgs = getenv("C2W_CONV_T3_MIN_WGS") && atoi(getenv("C2W_CONV_T3_MIN_WGS")) > 0 ? atoi(getenv("C2W_CONV_T3_MIN_WGS")) : 1024;
+    k.splitk = getenv("C2W_NO_SPLITK") == nullptr;
+    k.conv_t3_min_wgs = getenv("C2W_CONV_T3_MIN_WGS") && atoi(getenv("C2W_CONV_T3_MIN_WGS")) > 0 ? atoi(getenv("C2W_CONV_T3_MIN_WGS")) : 512;
     k.attn_valu = getenv("C2W_ATTN_VALU") != nullptr;
     return k;
 }
@@ -400,6 +401,12 @@ extern "C" int c2w_conv_lnbwd_supported(const C2wConvArgs* a, int dtype) {
     if (a == nullptr || (dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16)) return 0;
     if (a->Cout != 128 || a->ldy != 128 || a->mul != nullptr || a->y2 != nullptr || a->act != C2W_ACT_NONE) return 0;
     return c2w_conv_patch_eligible(*a) && !c2w_knobs().force_gather && c2w_knobs().ln_fusion ? 1 : 0;
+}
+
+int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long long* ws_bytes);  // conv_patch.hip
+extern "C" int c2w_conv_splitk_plan(const C2wConvArgs* a, int dtype, unsigned long long* ws_bytes) {
+    if (a == nullptr) return C2W_ERR_BAD_ARG;
+    return c2w_conv_splitk_plan_impl(*a, dtype, ws_bytes);
 }
 
 extern "C" int c2w_conv_lnfwd_chain_supported(const C2wConvArgs* a, int dtype) {
@@ -455,6 +462,10 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     }
     if ((a->flags & C2W_CONV_POOL2) != 0 && (naive != 0 || !c2w_conv_pool2_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;
     if (a->loss_sum != nullptr && (naive != 0 || !c2w_conv_loss_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no silent unfused result
+    if (a->splitk > 1) {  // exactly the plan's answer, with its scratch, or nothing
+        unsigned long long need = 0;
+        if (naive != 0 || a->splitk_ws == nullptr || c2w_conv_splitk_plan_impl(*a, dtype, &need) != a->splitk || a->splitk_ws_bytes < need) return C2W_ERR_BAD_SHAPE;
+    }
     if ((a->flags & C2W_CONV_WPACKED) != 0 && (naive != 0 || !c2w_conv_wpacked_supported(a, dtype))) return C2W_ERR_BAD_SHAPE;  // no other kernel reads that layout
     const bool patch = naive == 0 && !c2w_knobs().force_gather;
     if (patch && c2w_conv_patch_eligible(*a)) return c2w_conv_patch_s1(*a, dtype, st);

@@ -67,7 +67,12 @@ __device__ __forceinline__ void wait_vm4(int n) {  // wave-uniform n in {0, 4}
 // zero halo -- patch columns 0..9 belong to image b, 10..19 to image b + 1; tile column c >= 8 reads patch column c + 2 + kw.
 // Replaces the per-tap gather kernel at that level (585 -> ~1000 TFLOP/s class); the fused LayerNorm epilogues (one image per
 // tile) are not available in this mode.
-template <typename T, bool PAIR = false>
+// SPLITK (round 6; C2wConvArgs.splitk / splitk_ws): launches that leave most of the chip idle -- the deep levels of a sampler step on a
+// short trajectory: 512 -> 512 @8x8 at 37 windows is 76 workgroups walking 72 stages each -- split the K chunks over `splitk`
+// workgroups per tile; each stores its fp32 accumulators as a partial tile, conv_splitk_epilogue_kernel adds them in a fixed order
+// and applies bias / activation / multiplier / residual (the chain a launch costs is its stage count whatever it carries:
+// profiles/r04_experiments.md section 15).  A second launch, not an in-kernel fix-up: results stay bit-reproducible.
+template <typename T, bool PAIR = false, bool SPLITK = false>
 __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wConvArgs p) {
     constexpr int ESZ = sizeof(T);
     constexpr int CK = 128 / ESZ;
@@ -85,7 +90,10 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tn = L % nN, tm = L / nN;
+    const int nsplit = SPLITK ? p.splitk : 1;
+    const int sp = SPLITK ? L % nsplit : 0;  // the splits of a tile are neighbours in the launch order
+    const int Lt = SPLITK ? L / nsplit : L;
+    const int tn = Lt % nN, tm = Lt / nN;
     const int co0 = tn * 128;
     // H x W = the grid the tiles and the taps live on (= the output); with C2W_CONV_UP it is the nearest-neighbour x2 upsampling of the
     // Hs x Ws source map, which is never materialised: patch pixel (ih, iw) is fetched from source pixel (ih >> 1, iw >> 1)
@@ -157,24 +165,26 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int nchunk = p.Cin / CK;
+    const int nchunk_all = p.Cin / CK;
+    const int nchunk = SPLITK ? nchunk_all / nsplit : nchunk_all;  // (the plan picks a divisor)
+    const int c_lo = SPLITK ? sp * nchunk : 0;
     const int NS = nchunk * 9;
 
-    issue_patch(0);
-    issue_w(0, 0, 0);
-    issue_w(0, 1, 1);
+    issue_patch(c_lo);
+    issue_w(c_lo, 0, 0);
+    issue_w(c_lo, 1, 1);
     float bv[4][4];
-    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    if constexpr (!SPLITK) epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
     int np = 4;  // LDS-DMA pieces of the previous stage that may still be in flight
     u32x4_t da[4] = {}, db[4] = {};
 
     auto stage = [&](auto TAPc, int c) {
         constexpr int TAP = decltype(TAPc)::value;
         constexpr int KH = TAP / 3, KW = TAP % 3, WS = TAP % 3, T2 = (TAP + 2) % 9;
-        const int s = c * 9 + TAP;
+        const int s = (c - c_lo) * 9 + TAP;
         wait_vm4(np);
         __builtin_amdgcn_s_barrier();
-        if (TAP == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+        if (TAP == 0 && c > c_lo) {  // single patch buffer: every wave is past the previous chunk only now
             issue_patch(c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
     };
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c_lo; c < c_lo + nchunk; ++c) {
         stage(IC<0>{}, c); stage(IC<1>{}, c); stage(IC<2>{}, c); stage(IC<3>{}, c); stage(IC<4>{}, c);
         stage(IC<5>{}, c); stage(IC<6>{}, c); stage(IC<7>{}, c); stage(IC<8>{}, c);
     }
@@ -218,6 +228,16 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+
+    if constexpr (SPLITK) {  // partial tile [tile row R = 16 * row + column][128 co] fp32, straight from the accumulators (64 KB per workgroup)
+        float* const dst = p.splitk_ws + ((size_t)sp * (gridDim.x / nsplit) + Lt) * (128 * 128);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                *(f32x4_t*)(dst + (wn * 64 + n * 16 + li) * 128 + wm * 64 + m * 16 + lg * 4) = acc[m][n];
+        return;
+    }
 
     constexpr int OS = 128 * ESZ + 16;
     EpiStore<T, 128, H_NTHR> est;
@@ -490,6 +510,89 @@ int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
     return rc;
 }
 
+// Second launch of a split-K convolution: one workgroup per output tile adds the `splitk` partial tiles in a fixed order and applies the
+// epilogue of EpiStore::finish -- bias, activation (none / SiLU / ReLU), multiplier (plain or silu'), residual -- to 16-byte NHWC stores.
+template <typename T, bool PAIR>
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const C2wConvArgs p, int ntiles) {
+    constexpr int ESZ = sizeof(T), PER16 = 16 / ESZ, SEGS = 128 / PER16;
+    const int Lt = blockIdx.x;
+    const int nN = (p.Cout + 127) / 128;
+    const int tn = Lt % nN, tm = Lt / nN, co0 = tn * 128;
+    const int H = p.Hout, W = p.Wout;
+    const int tw = PAIR ? 1 : W >> 4, tpi = (H >> 3) * tw;
+    const int b = PAIR ? 2 * (tm / tpi) : tm / tpi, tt = tm - (tm / tpi) * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 3, ow0 = tx << 4;
+    const int nimg = PAIR ? (b + 1 < p.B ? 2 : 1) : 1;
+    const float* const part = p.splitk_ws + (size_t)Lt * (128 * 128);
+    const size_t sstride = (size_t)ntiles * (128 * 128);
+    for (int it = threadIdx.x; it < 128 * SEGS; it += 256) {
+        const int R = it / SEGS, cs = it - R * SEGS;
+        const int c = co0 + cs * PER16;
+        const int trow = R >> 4, col = R & 15;
+        long long pix;
+        bool ok = c < p.Cout;
+        if constexpr (PAIR) {
+            const int img = col >> 3;
+            pix = ((long long)(b + img) * H + oh0 + trow) * W + (col & 7);
+            ok = ok && img < nimg;
+        } else {
+            pix = ((long long)b * H + oh0 + trow) * W + ow0 + col;
+        }
+        if (!ok) continue;
+        float f[PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) f[e] = 0.f;
+        for (int s_ = 0; s_ < p.splitk; ++s_) {
+            const float* src = part + s_ * sstride + R * 128 + cs * PER16;
+#pragma unroll
+            for (int e = 0; e < PER16; e += 4) {
+                const f32x4_t v = *(const f32x4_t*)(src + e);
+                f[e] += v[0]; f[e + 1] += v[1]; f[e + 2] += v[2]; f[e + 3] += v[3];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) {
+            float v = f[e] + ((p.bias != nullptr && c + e < p.wrows) ? p.bias[c + e] : 0.f);
+            if (p.act == C2W_ACT_SILU) v = silu_f(v);
+            if (p.act == C2W_ACT_RELU) v = fmaxf(v, 0.f);
+            f[e] = v;
+        }
+        const size_t off = ((size_t)pix * p.ldy + c) * ESZ;
+        if (p.mul != nullptr || p.res != nullptr) {  // on the value as the unsplit kernel would have staged it: rounded to the storage type first
+            u32x4_t st = pack16<T>(f);
+            unpack16<T>(st, f);
+            if (p.mul != nullptr) {
+                float gm[PER16];
+                unpack16<T>(*(const u32x4_t*)((const char*)p.mul + off), gm);
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) f[e] *= p.mulmode == C2W_MUL_DSILU ? dsilu_f(gm[e]) : gm[e];
+            }
+            if (p.res != nullptr) {
+                float gr[PER16];
+                unpack16<T>(*(const u32x4_t*)((const char*)p.res + off), gr);
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) f[e] += gr[e];
+            }
+        }
+        *(u32x4_t*)((char*)p.y + off) = pack16<T>(f);
+    }
+}
+
+template <typename T, bool PAIR>
+int launch_splitk(const C2wConvArgs& a, int ntiles, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    conv_patch_half_kernel<T, PAIR, true><<<ntiles * a.splitk, H_NTHR, H_LDS, st>>>(a);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    conv_splitk_epilogue_kernel<T, PAIR><<<ntiles, 256, 0, st>>>(a, ntiles);
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 int launch(const C2wConvArgs& a, hipStream_t st) {  // two 8x16-tile workgroups per CU
     constexpr int ESZ = sizeof(T);
@@ -501,6 +604,7 @@ int launch(const C2wConvArgs& a, hipStream_t st) {  // two 8x16-tile workgroups 
     }
     const int nN = (a.Cout + 127) / 128;
     const int nMh = a.B * (a.Hout >> 3) * (a.Wout >> 4);
+    if (a.splitk > 1) return launch_splitk<T, false>(a, nMh * nN, st);
     conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, H_LDS, st>>>(a);
     return (int)hipGetLastError();
 }
@@ -517,10 +621,34 @@ int launch_pair(const C2wConvArgs& a, hipStream_t st) {
     }
     const int nN = (a.Cout + 127) / 128;
     const int nM = ((a.B + 1) >> 1) * (a.Hin >> 3);
+    if (a.splitk > 1) return launch_splitk<T, true>(a, nM * nN, st);
     conv_patch_half_kernel<T, true><<<nM * nN, H_NTHR, H_LDS, st>>>(a);
     return (int)hipGetLastError();
 }
 }  // namespace
+
+// Split-K plan of a convolution on the 8x16-tile kernels (see conv_patch_half_kernel<T, PAIR, SPLITK>): the number of workgroups each
+// output tile's K chunks are dealt to (1: no split) and the scratch the partial tiles need.
+int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long long* ws_bytes) {
+    if (ws_bytes != nullptr) *ws_bytes = 0;
+    if (!c2w_knobs().splitk || c2w_knobs().force_gather) return 1;
+    if (a.y2 != nullptr || a.ln_x != nullptr || a.lnf_y != nullptr || a.loss_sum != nullptr || (a.flags & (C2W_CONV_POOL2 | C2W_CONV_NO_Y | C2W_CONV_WPACKED)) != 0) return 1;
+    if (a.act != C2W_ACT_NONE && a.act != C2W_ACT_SILU && a.act != C2W_ACT_RELU) return 1;
+    const bool pair = c2w_conv_pair_eligible(a);
+    if (!pair && !(c2w_conv_patch_eligible(a) && !c2w_conv_patch3_wanted(a, dtype))) return 1;
+    const int nN = (a.Cout + 127) / 128;
+    const long long tiles = (pair ? (long long)((a.B + 1) >> 1) * (a.Hin >> 3) : (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4)) * nN;
+    const int nchunk = a.Cin / (dtype == C2W_DTYPE_F32 ? 32 : 64);
+    if (tiles >= 256 || nchunk < 2) return 1;  // a workgroup per CU already: the launch is not a bare chain
+    int best = 1;
+    for (int d = 2; d <= nchunk; ++d) {  // the smallest divisor of the chunk count that reaches one workgroup per CU (else the largest)
+        if (nchunk % d != 0) continue;
+        best = d;
+        if (tiles * d >= 256) break;
+    }
+    if (ws_bytes != nullptr) *ws_bytes = (unsigned long long)best * tiles * 128 * 128 * sizeof(float);
+    return best;
+}
 
 // input gradient of the stride-2 convs per output-parity class on the halo patch (conv_patch_ts2_kernel)
 bool c2w_conv_ts2_patch_eligible(const C2wConvArgs& a) {

@@ -444,6 +444,9 @@ int t3_launch(const C2wConvArgs& a, hipStream_t st) {
 // The 16x16-tile variant pays off where the launch still fills the chip several times over (measured on MI355X, B = 128:
 // 128->128 @128^2 0.596 vs 0.621 ms, @64^2 0.156 vs 0.166 ms; 384->384 @16^2 with 384 workgroups 0.093 vs 0.079 ms).
 // Knob C2W_CONV_T3 = 0 disables it, = 16 forces it wherever the image is tiled by 16x16 (knobs.h).
+// Round 6: from 512 workgroups (one full round of two per CU) instead of 1024 -- what the 32^2 level has at the 8-GPU strong-scaling
+// batch of 64 windows per GPU (step 26.16 -> 26.00 ms) and the 64^2 level of a one-member sampler step at L = 49 (37 windows: 6.36 k ->
+// 6.64 k window-forwards/s); 256 is behind again (26.97 against 26.90 ms at B = 64).  C2W_CONV_T3_MIN_WGS overrides.
 bool c2w_conv_patch3_wanted(const C2wConvArgs& a, int dtype) {
     const int mode = c2w_knobs().conv_t3;
     if ((dtype != C2W_DTYPE_BF16 && dtype != C2W_DTYPE_F16) || mode == 0 || (a.Hout & 15) != 0 || (a.Wout & 15) != 0) return false;

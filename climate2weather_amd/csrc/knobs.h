@@ -5,7 +5,7 @@
 
 struct C2wKnobs {
     bool force_gather;    // C2W_FORCE_GATHER=1   every conv / weight gradient on the general gather kernels (no halo-patch kernels)
-    int conv_t3;          // C2W_CONV_T3          -1 (default): 16x16-tile conv kernel from 1024 workgroups; 0: never; 16: wherever the image is tiled
+    int conv_t3;          // C2W_CONV_T3          -1 (default): 16x16-tile conv kernel from conv_t3_min_wgs workgroups; 0: never; 16: wherever the image is tiled
     bool conv_pair;       // C2W_CONV_PAIR=0      8-pixel-wide images NOT paired on the halo-patch kernels (gather kernels instead)
     bool conv_ts2_patch;  // C2W_CONV_TS2_PATCH=0 stride-2 input gradient NOT on the parity-class halo-patch kernel
     bool ts2_one_launch;  // C2W_TS2_FOUR_LAUNCHES=1 stride-2 input gradient as one launch per parity class instead of one launch for the four
@@ -19,7 +19,8 @@ struct C2wKnobs {
     bool wpacked;         // C2W_NO_WPACKED=1     c2w_conv_wpacked_supported answers 0 (callers hand over the plain [rows][9][Cin] weights)
     bool loss_fusion;     // C2W_NO_LOSS_FUSION=1 c2w_conv_loss_supported answers 0 (callers run the output conv and c2w_mse_loss_grad_noise)
     bool ln_chain;        // C2W_NO_LN_CHAIN=1    c2w_conv_lnfwd_chain_supported answers 0 (every residual block writes its output)
-    int conv_t3_min_wgs;  // C2W_CONV_T3_MIN_WGS=N  workgroups from which the 16x16-tile conv kernel replaces the 8x16 one (default 1024)
+    bool splitk;          // C2W_NO_SPLITK=1      c2w_conv_splitk_plan answers 1 (no convolution splits its K chunks over workgroups)
+    int conv_t3_min_wgs;  // C2W_CONV_T3_MIN_WGS=N  workgroups from which the 16x16-tile conv kernel replaces the 8x16 one (default 512 = one round of two workgroups per CU; 1024 in rounds 1-5)
     int wgrad_wgs;        // C2W_WGRAD_WGS=N      workgroups a halo-patch weight-gradient launch splits its K range into (default 256: one per CU)
 };
 

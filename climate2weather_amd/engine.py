@@ -258,6 +258,7 @@ class Engine:
         self._pub = None  # ops.HostRing of published scalars (publish / published)
         self._skip_dw = False  # inside backward(want_dw=False): weight-gradient launches are skipped
         self._ws: Dict[int, torch.Tensor] = {}  # stream handle -> split-K scratch of the weight-gradient launches on that stream
+        self._splitk_plans: Dict[tuple, tuple] = {}  # conv geometry -> (workgroups per tile, scratch bytes) (_splitk)
         self.debug_trace: Optional[list] = None  # diagnostics: a list collects (name, output tensor[, operands of a conv]) of every conv / attention launch of a forward
         self.attach(net)
 
@@ -626,6 +627,21 @@ class Engine:
             ws = self._ws[key] = ops.new_workspace(self.flat.device, max(ops.WORKSPACE_BYTES, (min_bytes + (1 << 20) - 1) >> 20 << 20))
         return ws
 
+    def _splitk(self, g: dict, dt: int, act: int):
+        """(scratch, workgroups per tile) if this inference launch should deal its K chunks to several workgroups (ops.conv_splitk_plan:
+        fewer output tiles than the chip has CUs -- the deep levels of a sampler step on a short trajectory), else None.  The plan is
+        a pure function of geometry and knobs: remembered per geometry."""
+        if not self.use_splitk or self.flat is None or not self.flat.is_cuda:
+            return None
+        key = (g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"], g["wrows"], g["mode"], dt, act, ops.KNOBS_GENERATION)
+        plan = self._splitk_plans.get(key)
+        if plan is None:
+            plan = self._splitk_plans[key] = ops.conv_splitk_plan(g, dt, act)
+        ns, nbytes = plan
+        if ns <= 1:
+            return None
+        return self.workspace(nbytes), ns
+
     def _wg(self, x: torch.Tensor, gy: torch.Tensor, rec: ConvRec, g: dict, dt: int, group: bool = False) -> None:
         """dW, dbias of ``rec`` (dense operand) into the flat gradient buffer, on the gradient stream.  ``group``: the layer is one of
         several with this geometry whose output gradients appear one after the other (the residual-block convs of a level side): it is
@@ -634,8 +650,13 @@ class Engine:
             return
         # "up to N x N grids" is meant at the reference's batch of 128 per GPU: what decides is the layer's K extent (B x H x W pixels;
         # the deep variant's 128x128 level at B = 32 is the default network's 64x64 level at B = 128)
-        small = g["B"] * g["Hout"] * g["Wout"] <= 128 * self.group_wgrads_max_side ** 2
+        npx = g["B"] * g["Hout"] * g["Wout"]
+        small = npx <= 128 * self.group_wgrads_max_side ** 2
         cap = 16 if small else self.group_wgrads_top
+        if not small and cap == 1 and npx <= 256 * self.group_wgrads_max_side ** 2:
+            # one size up -- the 128x128 level at 64 windows per GPU, the reference's global batch of 512 on 8 GPUs: groups of three
+            # (round 6, B = 64: 26.00 -> 25.84 ms per step; at B = 128 the same grouping costs 0.25 ms: profiles/r05_experiments.md)
+            cap = 3
         if group and self.group_wgrads and cap > 1:
             key = (g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"], g["mode"], dt, ops.KNOBS_GENERATION)
             ok = self._wg_group_ok.get(key)
@@ -888,7 +909,8 @@ class Engine:
             # 16x16-tile kernel turns into fewer K steps
             wop, wpk = self._conv_weights("f", rec, dt, g)
             ops.conv(xin, wop, self._b(rec), y if y is not None else hn, g, dt, act=act, res=res, y2=y2, lnf=lnf,
-                     kvalid=rec.cin if rec.kstride != rec.cin else 0, wpacked=wpk, loss=loss, resn=resn, no_y=no_y)
+                     kvalid=rec.cin if rec.kstride != rec.cin else 0, wpacked=wpk, loss=loss, resn=resn, no_y=no_y,
+                     splitk=self._splitk(g, dt, act) if (not train and lnf is None and y2 is None and loss is None and not wpk) else None)
             if self.debug_trace is not None and y is not None:
                 self.debug_trace.append((name, y, dict(x=xin, w=self._w(rec, dt), g=g, act=act, res=res)))
                 if hn is not None:
@@ -1151,6 +1173,7 @@ class Engine:
     # dominates the block input that is MORE than rounding x itself: against the CPU oracle the worst gradient tensor moves from
     # 8.7e-3 to 1.7e-2 relative L2 (bf16; fp16 5e-3 -> 8.5e-3 of the output scale).  Parity before 0.5 %: off.
     chain_blocks = os.environ.get("C2W_LN_CHAIN") == "1"
+    use_splitk = os.environ.get("C2W_NO_SPLITK") is None  # A/B knob: under-filled inference convs as one workgroup per tile (rounds 1-5)
     fuse_loss = os.environ.get("C2W_NO_LOSS_FUSION") is None  # A/B knob: the loss tail as its own pass (rounds 1-5); the library reads the same variable
     use_gemv = os.environ.get("C2W_NO_GEMV") != "1"  # A/B knob: one-row Linear layers as matrix-vector products
 

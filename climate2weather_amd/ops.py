@@ -54,7 +54,7 @@ def _conv_args(x, w, bias, res, mul, y, g, act, mulmode, y2=None, ln=None, lnf=N
 
 def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=None, mulmode: int = MUL_PLAIN, naive=False, y2=None,
          ln=None, lnf=None, pool2: bool = False, kvalid: int = 0, wpacked: bool = False, loss: Optional[dict] = None,
-         resn: Optional[dict] = None, no_y: bool = False):
+         resn: Optional[dict] = None, no_y: bool = False, splitk: Optional[tuple] = None):
     """c2w_conv_forward.  g: geometry dict(B,Hin,Win,Cin,Hout,Wout,Cout,ldy,wrows,mode).
     ln = dict(x, m, dm, ldm, eps, unbiased[, rstd]): fuse the LayerNorm backward into the epilogue (y = res + dLN(conv; x + m),
     dm accumulated) -- only where conv_lnbwd_supported(g, dtype) says so.  With ``rstd`` (what the forward's lnf kept), ``x`` holds the
@@ -69,6 +69,9 @@ def conv(x, w, bias, y, g: dict, dtype: int, act: int = ACT_NONE, res=None, mul=
     if wpacked:  # w: the stage-major copy made by pack_conv_weights_batched (only where conv_wpacked_supported says so)
         a.flags |= _lib.CONV_WPACKED
     a.kvalid = int(kvalid)  # promise: input channels >= kvalid are all zero in x or in w (0: no promise)
+    if splitk is not None:  # (scratch tensor, workgroups per tile): exactly conv_splitk_plan's answer for this launch
+        ws, ns = splitk
+        a.splitk_ws, a.splitk_ws_bytes, a.splitk = _p(ws), ws.numel() * ws.element_size(), int(ns)
     if loss is not None:  # dict(sum, eps, lde, gscale, C[, scaler]): y receives (result - eps rows) * gscale, sum += sum of squares -- only
         a.loss_sum, a.loss_scaler = _p(loss["sum"]), _p(loss.get("scaler"))  # where conv_loss_supported(g, dtype) says so
         a.loss_eps, a.loss_lde, a.loss_gscale, a.loss_C = _p(loss["eps"]), int(loss["lde"]), float(loss["gscale"]), int(loss["C"])
@@ -119,6 +122,18 @@ def conv_lnfwd_supported(g: dict, dtype: int) -> bool:
     a = ConvArgs(None, None, None, None, None, None, None, g["B"], g["Hin"], g["Win"], g["Cin"], g["Hout"], g["Wout"], g["Cout"], g["ldy"],
                  g["wrows"], g["mode"], ACT_NONE, MUL_PLAIN)
     return bool(_lib.load().c2w_conv_lnfwd_supported(ctypes.byref(a), dtype))
+
+
+def conv_splitk_plan(g: dict, dtype: int, act: int = ACT_NONE) -> tuple:
+    """(workgroups per output tile, scratch bytes) for a conv launch with bias / activation / mul / res epilogues only
+    (include/c2w_hip.h::c2w_conv_splitk_plan); (1, 0): the launch does not split."""
+    a = _geom_args(g)
+    a.act = act
+    nbytes = ctypes.c_ulonglong(0)
+    ns = int(_lib.load().c2w_conv_splitk_plan(ctypes.byref(a), dtype, ctypes.byref(nbytes)))
+    if ns < 0:
+        check(ns, "c2w_conv_splitk_plan")
+    return ns, int(nbytes.value)
 
 
 def conv_lnfwd_chain_supported(g: dict, dtype: int) -> bool:

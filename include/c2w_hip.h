@@ -121,6 +121,15 @@ typedef struct C2wConvArgs {
     float loss_gscale;
     int32_t loss_C;
     int32_t loss_lde;         /* channel stride of loss_eps: a multiple of 8, loss_C <= loss_lde <= 128 */
+    /* Optional split-K (round 6; c2w_conv_splitk_plan): splitk > 1 deals every output tile's K chunks to that many workgroups; their fp32
+     * partial tiles go through the caller's scratch splitk_ws (splitk_ws_bytes >= what the plan asked for; contents undefined before and
+     * after; one buffer per stream, like c2w_conv_wgrad's workspace) and a second launch on the same stream adds them in a fixed order
+     * and applies bias / activation / mul / res.  For launches of fewer workgroups than the chip has CUs (the deep levels of a
+     * sampler step on a short trajectory, exp/configs/000_on-model-eval/s16_t6.yml: 37 windows): such a launch costs its chain of K
+     * stages whatever it carries.  Results are bit-reproducible; they differ from the unsplit launch in summation order only. */
+    float* splitk_ws;
+    unsigned long long splitk_ws_bytes;
+    int32_t splitk;           /* 0 / 1: no split; else exactly c2w_conv_splitk_plan's answer for these arguments */
 } C2wConvArgs;
 
 /* 1 when c2w_conv_forward / c2w_conv_wgrad run this geometry on the halo-patch kernels (3x3 stride-1, image tiled exactly
@@ -142,6 +151,10 @@ int c2w_conv_lnfwd_chain_supported(const C2wConvArgs* args, int dtype);
  * stride-1 on the 16x16-tile kernel, at most 80 weight rows in rows of 128 channels (the network-output conv, model/nn.py:194),
  * loss_C <= wrows, no res / mul / act / y2 / LayerNorm fusion.  Otherwise callers run the conv and c2w_mse_loss_grad[_noise]. */
 int c2w_conv_loss_supported(const C2wConvArgs* args, int dtype);
+/* Workgroups per output tile c2w_conv_forward can deal the K chunks of these arguments to (1: no split -- geometry outside the 8x16-tile
+ * kernels, fused epilogues other than bias / activation / mul / res, or a launch that already has a workgroup per CU), and through
+ * *ws_bytes (may be NULL) the scratch it then needs.  A pure function of the arguments' geometry, epilogue fields and the dtype. */
+int c2w_conv_splitk_plan(const C2wConvArgs* args, int dtype, unsigned long long* ws_bytes);
 
 /* Which kernel family c2w_conv_forward (naive == 0) / c2w_conv_wgrad run these arguments on -- a pure function of the geometry,
  * the dtype and the fusion fields; the parity tests assert with it that a case reaches the kernel it is meant to cover.

@@ -74,6 +74,10 @@ def conv_lnfwd_chain_supported(g, dtype):
     return CHAIN and conv_lnfwd_supported(g, dtype) and g["mode"] == CONV_S1 and dtype != DTYPE_F32
 
 
+def conv_splitk_plan(g, dtype, act=ACT_NONE):
+    return 1, 0  # summation order is the kernels' business
+
+
 def conv_loss_supported(g, dtype):
     return False  # the emulation has no Philox stream: trainers on the CPU inject eps and run the separate loss tail
 
@@ -105,8 +109,9 @@ def pack_conv_weights_batched(src, dst, desc, n, dtype):
 
 
 def conv(x, w, bias, y, g, dtype, act=ACT_NONE, res=None, mul=None, mulmode=MUL_PLAIN, naive=False, y2=None, ln=None, lnf=None, pool2=False, kvalid=0,
-         wpacked=False, loss=None, resn=None, no_y=False):
+         wpacked=False, loss=None, resn=None, no_y=False, splitk=None):
     assert loss is None, "conv_loss_supported() is False here: nobody may ask the emulation for the fused loss"
+    assert splitk is None, "conv_splitk_plan() answers (1, 0) here"
     if wpacked:
         assert conv_wpacked_supported(g, dtype)
         return conv(x, -w.reshape(-1)[: g["wrows"] * 9 * g["Cin"]], bias, y, g, dtype, act, res, mul, mulmode, naive, y2, ln, lnf, pool2, kvalid,

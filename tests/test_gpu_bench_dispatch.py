@@ -1,7 +1,7 @@
 """Parity at the dispatch the bench times.
 
 bench.py runs the default network at B = 128, C = 65 in bf16; at that batch the dispatcher (c2w_conv_dispatch) sends the 128^2, 64^2
-and 32^2 levels, three of the four up-convs and the padded edge convs to conv_patch_t3_kernel<16> (>= 1024 workgroups), the weight
+and 32^2 levels, three of the four up-convs and the padded edge convs to conv_patch_t3_kernel<16> (>= 512 workgroups since round 6; 1024 before), the weight
 gradients to wgrad_patch_kernel with one-round split counts, the 8x8 level to the paired tiles.  The per-kernel tests of
 test_gpu_kernels.py stay small (seconds on any box) and therefore reach the 16x16-tile kernel at one shape only; this file covers
 
@@ -59,7 +59,7 @@ def out_hw(mode, H):
 # (name, kernel family, mode, B, Hin, Cin, Cout, wrows, cin_real, epilogues)
 # Epilogue names: bias, silu (inference), pair (training: silu + silu'), res, lnf (consumer's LayerNorm emitted; "mod" = with the
 # modulation rows), lnb (LayerNorm backward fused), mulp (x stored silu' -- conv2's input gradient), pool (2x2 sums: the up-conv's
-# input gradient).  B is the smallest batch at which the launch has the bench's kernel selection (>= 1024 workgroups for the 16x16
+# input gradient).  B is the smallest batch at which the launch has the bench's kernel selection (>= 512 workgroups, 1024 in rounds 1-5, for the 16x16
 # tiles; for the gather kernel the 256-pixel-tile form).
 FWD_CASES = [
     # residual blocks (model/nn.py:146-159): conv1 / conv2 / their input gradients
@@ -74,7 +74,8 @@ FWD_CASES = [
     # input gradients of the up-convs, leaving the kernel as 2x2 sums (adjoint of Upsample, model/nn.py:184)
     ("up-conv dgrad 256->384 @32^2 pooled (three co tiles)", T3, S1, 128, 32, 256, 384, 384, 256, ["pool"]),
     ("up-conv dgrad 128->256 @64^2 pooled", T3, S1, 32, 64, 128, 256, 256, 128, ["pool"]),
-    ("up-conv dgrad 384->512 @16^2 pooled", HALF, S1, 128, 16, 384, 512, 512, 384, ["pool"]),
+    ("up-conv dgrad 384->512 @16^2 pooled (512 workgroups: the 16x16-tile kernel since round 6)", T3, S1, 128, 16, 384, 512, 512, 384, ["pool"]),
+    ("up-conv dgrad 384->512 @16^2 pooled at half the batch (8x16 tiles)", HALF, S1, 64, 16, 384, 512, 512, 384, ["pool"]),
     # edge convs (model/nn.py:193-194) at C = 65: K padded 65 -> 128 with zero channels; 65 real output rows in a 128-wide buffer
     ("network input 65(128)->128 @128^2", T3, S1, 16, 128, 128, 128, 128, 65, ["bias+lnf", "bias"]),
     ("network output 128->65(128) @128^2", T3, S1, 16, 128, 128, 128, 65, 128, ["bias"]),
@@ -446,7 +447,7 @@ def test_two_stream_backward_reproduces_every_conv_weight_gradient_bit_for_bit()
     reductions on a second): the same batch, (t, eps) and weights twelve times at B = 128.  The 70 conv kernels' gradients -- split-K
     partial sums reduced in a fixed order from deterministic operands -- must be bit-identical every time; a race between workgroups
     shows up here as one that changes (round 3's weight-ring race did, in the forward).  Biases, LayerNorm-modulation sums and the
-    Linear weights fed by them use fp32 atomics and may differ in the last bits: not compared.  tools/hunt_flake_step.py is the long form."""
+    Linear weights fed by them use fp32 atomics and may differ in the last bits: not compared.  (The long-form hunts of round 3 are in the history: profiles/r03_experiments.md, "weight ring race".)"""
     from climate2weather_amd.score import ScoreUNet
     from climate2weather_amd.training import Trainer
     B, C, H = 128, 65, 128
@@ -724,3 +725,66 @@ def test_stage_major_packed_weights_give_the_same_bits(case, dt):
             torch.cuda.synchronize()
             got.append(y)
         assert torch.equal(got[0], got[1]), name + " (fused LayerNorm backward)"
+
+
+SPLITK_CASES = [  # (name, pair, B, H, Cin, Cout, expected workgroups per tile)
+    ("512->512 @8x8, 37 windows (L = 49): 76 tiles", True, 37, 8, 512, 512, 4),
+    ("384->384 @16x16, 37 windows: 222 tiles", False, 37, 16, 384, 384, 2),
+    ("512->512 @8x8, 5 windows: 12 tiles, every chunk its own workgroup", True, 5, 8, 512, 512, 8),
+    ("256->256 @32x32, 3 windows: 48 tiles", False, 3, 32, 256, 256, 4),
+]
+
+
+@pytest.mark.parametrize("dt", [BF16, F16, F32])
+@pytest.mark.parametrize("epi", ["bias+silu", "bias+res", "mul(dsilu)+res", "plain"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_split_k_convolution_for_underfilled_launches(case, epi, dt):
+    """Round 6 (C2wConvArgs.splitk; model/nn.py:146-159 at the deep levels of a sampler step on a short trajectory, exp/configs/000_on-model-eval/
+    s16_t6.yml): a conv launch with fewer output tiles than CUs deals its K chunks to c2w_conv_splitk_plan workgroups per tile and a second
+    launch adds the partial tiles in a fixed order.  Against the unsplit launch of the same arguments (summation order differs: the
+    storage type's rounding) and the PyTorch restatement; twice for bit-reproducibility; the plan's answers; refusal of a wrong plan."""
+    name, pair, B, H, Cin, Cout, want = case
+    if dt == F32:
+        Cin = Cin // 2  # (fp32 chunks are 32 channels: the same chunk counts)
+    g = geom(B, H, H, Cin, H, H, Cout, Cout, Cout, S1)
+    act = ops.ACT_SILU if "silu" in epi and "dsilu" not in epi else ops.ACT_NONE
+    ns, nbytes = ops.conv_splitk_plan(g, dt, act)
+    assert ns == want and nbytes == ns * ((B + 1) // 2 * (H // 8) if pair else B * (H // 8) * (H // 16)) * ((Cout + 127) // 128) * 65536, (ns, nbytes)
+    assert ops.conv_dispatch(g, dt) == (PAIR if pair else HALF)
+    npix = B * H * H
+    x = rnd((npix, Cin), dt, 1)
+    w = rnd((Cout, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd((Cout,), F32, 3) if "bias" in epi else None
+    kw = dict(act=act)
+    if "res" in epi:
+        kw["res"] = rnd((npix, Cout), dt, 4)
+    if "mul" in epi:
+        kw.update(mul=rnd((npix, Cout), dt, 5), mulmode=ops.MUL_DSILU)
+    ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=dev()).fill_(float("nan"))
+    y0 = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev())
+    ops.conv(x, w, bias, y0, g, dt, **kw)
+    outs = []
+    for _ in range(2):
+        y = torch.full((npix, Cout), 7.0, dtype=TD[dt], device=dev())
+        ws.fill_(float("nan"))
+        ops.conv(x, w, bias, y, g, dt, splitk=(ws, ns), **kw)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isnan(ws[nbytes // 4:]).all()  # nothing written past the plan's bytes
+    tol = 1e-5 if dt == F32 else TOL[dt] / 4
+    close(outs[0], y0, tol, name + " / " + epi + ": split vs unsplit")
+    y_ref = torch.empty_like(y0)
+    E.conv(x, w, bias, y_ref, g, dt, **kw)
+    close(outs[0], y_ref, 2e-5 if dt == F32 else TOL[dt], name + " / " + epi + ": split vs restatement")
+    with pytest.raises(_lib.C2wError):  # not the plan's answer
+        ops.conv(x, w, bias, y, g, dt, splitk=(ws, ns + 1 if ns < 8 else 2), **kw)
+    with pytest.raises(_lib.C2wError):  # scratch too small
+        ops.conv(x, w, bias, y, g, dt, splitk=(ws[: nbytes // 8], ns), **kw)
+
+
+def test_split_k_plan_leaves_filled_launches_alone():
+    for g, dt in ((geom(128, 8, 8, 512, 8, 8, 512, 512, 512, S1), BF16),      # 256 tiles: a workgroup per CU
+                  (geom(37, 64, 64, 128, 64, 64, 128, 128, 128, S1), BF16),   # 592 tiles on the 16x16-tile kernel
+                  (geom(4, 16, 16, 64, 16, 16, 128, 128, 128, S1), BF16)):    # one K chunk: nothing to split
+        assert ops.conv_splitk_plan(g, dt) == (1, 0)

@@ -275,8 +275,8 @@ def test_full_size_backward_vs_reference_gradients(golden_dir, C):
 def test_full_size_bf16_large_batch_matches_fp32_path():
     """B = 64 at C = 65 -- the bench's channel count -- as a SELF-comparison of the 16-bit modes with this repo's fp32 path (which is
     pinned to the reference by the fingerprint and gradient tests above).  At B = 64 the 128^2 and 64^2 levels and the 128-channel up-
-    convs dispatch to the 16x16-tile kernel with the fused LayerNorm epilogues (>= 1024 workgroups), the 32^2 level does NOT (8 x 64 = 512
-    workgroups: 8x16-tile kernel), 8x8 images are paired per tile.  The B = 128 dispatch of every level, against independent expected
+    convs dispatch to the 16x16-tile kernel with the fused LayerNorm epilogues, and since round 6 (threshold 512 workgroups) so does the 32^2 level (8 x 64 = 512
+    workgroups); the 16^2 level stays on the 8x16 tiles, 8x8 images are paired per tile.  The B = 128 dispatch of every level, against independent expected
     values (the PyTorch restatement per kernel, the CPU oracle for the whole step), is tests/test_gpu_bench_dispatch.py.
     Forward and parameter gradients of the modes on the same inputs: bf16 tolerance 3e-2 / 6e-2 of the scale, fp16 5e-3 / 1.5e-2."""
     B, C = 64, 65

@@ -937,7 +937,7 @@ def test_the_default_network_on_four_concurrent_streams_is_bit_identical_to_one_
                     outs.append(net(x, t))
             torch.cuda.synchronize()
             for si, y in enumerate(outs):
-                assert torch.equal(y, ref), f"round {rnd}, stream {si}: {int((y != ref).sum())} values differ (tools/hunt_flake_layers.py localises it)"
+                assert torch.equal(y, ref), f"round {rnd}, stream {si}: {int((y != ref).sum())} values differ (Engine.debug_trace localises the layer)"
 
 
 def test_conditioned_score_evaluation_at_the_shipped_full_length_folds_like_the_reference():
