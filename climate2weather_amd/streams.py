@@ -19,9 +19,9 @@ _PROBE_CYCLES = 8_000_000  # ~3.4 ms of torch.cuda._sleep on the stream that mus
 
 
 def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None, votes: int = 3) -> bool:
-    """True if a launch on ``side`` completes while a kernel enqueued earlier on ``main`` (default: the current stream) is still
-    running, i.e. the two streams are on different hardware queues.  One sample is one ~3.4-ms spin kernel on ``main``; a host hiccup
-    between the two queries of a sample flips it, so the verdict is the majority of up to ``votes`` samples (two agreeing end it)."""
+    """True if work handed from ``main`` (default: the current stream) to ``side`` through an event runs NEXT TO what ``main`` goes on
+    with (_overtakes_once).  One sample is three ~0.85-ms spin kernels; a host hiccup can flip one, so the verdict is the majority of up
+    to ``votes`` samples (two agreeing end it)."""
     yes = no = 0
     need = votes // 2 + 1
     while yes < need and no < need:
@@ -32,21 +32,46 @@ def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = N
     return yes >= need
 
 
+_SPIN_MS = [None]  # measured once: milliseconds one _PROBE_CYCLES / 4 spin kernel takes on this chip
+
+
 def _overtakes_once(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None) -> bool:
+    """The pattern the callers actually issue, timed:  main: spin T;  side waits for main's event, then spins T;  main: spin T again.
+    If main's second kernel runs NEXT TO side's, main is done after 2 T; if it is held behind it, after 3 T.
+
+    Round 6 (tools/probe_stream_overlap_*.py, profiles/r06_experiments.md): the earlier probes -- "a launch on side finishes while a
+    kernel on main is still running", also in both directions with two launches each -- pass on pairs of streams that nevertheless
+    SERIALISE under this pattern: once side has waited for an event of main, main's following kernel does not start before side's
+    has finished (12 x (500 us + 200 us) took 8.4 ms instead of 6.2).  Which streams of a process pair up like that depends on what
+    was created before them (a one-rank RCCL communicator's streams are enough to move it); nothing but timing the pattern tells."""
     main = main or torch.cuda.current_stream(side.device)
-    flag = torch.zeros(1, dtype=torch.int32, device=side.device)
-    main.synchronize()
+    cyc = _PROBE_CYCLES // 4
     with torch.cuda.stream(side):  # first use of a stream can take milliseconds (its hardware queue is created): not part of the verdict
-        flag.zero_()
+        torch.cuda._sleep(1000)
+    main.synchronize()
     side.synchronize()
+    if _SPIN_MS[0] is None:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(main):
+            torch.cuda._sleep(cyc)  # (the first spin kernel of a process also loads its code object)
+            c0.record(main)
+            torch.cuda._sleep(cyc)
+            c1.record(main)
+        main.synchronize()
+        _SPIN_MS[0] = c0.elapsed_time(c1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(main):
-        torch.cuda._sleep(_PROBE_CYCLES)
+        e0.record(main)
+        torch.cuda._sleep(cyc)
+    side.wait_stream(main)
     with torch.cuda.stream(side):
-        flag.fill_(1)
+        torch.cuda._sleep(cyc)
+    with torch.cuda.stream(main):
+        torch.cuda._sleep(cyc)
+        e1.record(main)
+    main.synchronize()
     side.synchronize()
-    ok = not main.query()
-    flag.record_stream(side)
-    return ok
+    return e0.elapsed_time(e1) < 2.5 * _SPIN_MS[0]
 
 
 def independent_stream(device, avoid=(), tries: int = 8, priority: int = 0) -> "torch.cuda.Stream":
