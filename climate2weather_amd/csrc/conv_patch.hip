@@ -166,8 +166,8 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int nchunk_all = p.Cin / CK;
-    const int nchunk = SPLITK ? nchunk_all / nsplit : nchunk_all;  // (the plan picks a divisor)
-    const int c_lo = SPLITK ? sp * nchunk : 0;
+    const int c_lo = SPLITK ? sp * nchunk_all / nsplit : 0;  // near-equal chunk ranges (8 chunks over 3 workgroups: 2, 3, 3)
+    const int nchunk = SPLITK ? (sp + 1) * nchunk_all / nsplit - c_lo : nchunk_all;
     const int NS = nchunk * 9;
 
     issue_patch(c_lo);
@@ -510,12 +510,15 @@ int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
     return rc;
 }
 
-// Second launch of a split-K convolution: one workgroup per output tile adds the `splitk` partial tiles in a fixed order and applies the
-// epilogue of EpiStore::finish -- bias, activation (none / SiLU / ReLU), multiplier (plain or silu'), residual -- to 16-byte NHWC stores.
+// Second launch of a split-K convolution: adds the `splitk` partial tiles in a fixed order and applies the epilogue of EpiStore::finish --
+// bias, activation (none / SiLU / ReLU), multiplier (plain or silu'), residual -- to 16-byte NHWC stores.  One workgroup per 16 tile rows,
+// one (row, 8-channel segment) per thread, every split's load in flight at once (a first version -- one workgroup per tile, eight rows
+// per thread, one split after the other -- took 18-21 us on 76-222 tiles: a chain of dependent loads on a quarter of the chip).
 template <typename T, bool PAIR>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const C2wConvArgs p, int ntiles) {
-    constexpr int ESZ = sizeof(T), PER16 = 16 / ESZ, SEGS = 128 / PER16;
-    const int Lt = blockIdx.x;
+    constexpr int ESZ = sizeof(T), PER16 = 16 / ESZ, SEGS = 128 / PER16, RPB = 256 / SEGS;  // rows per block: 16 (16-bit) / 8 (fp32)
+    constexpr int BPT = 128 / RPB;
+    const int Lt = blockIdx.x / BPT, rblk = blockIdx.x - Lt * BPT;
     const int nN = (p.Cout + 127) / 128;
     const int tn = Lt % nN, tm = Lt / nN, co0 = tn * 128;
     const int H = p.Hout, W = p.Wout;
@@ -524,59 +527,59 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const C2wConv
     const int ty = tt / tw, tx = tt - ty * tw;
     const int oh0 = ty << 3, ow0 = tx << 4;
     const int nimg = PAIR ? (b + 1 < p.B ? 2 : 1) : 1;
-    const float* const part = p.splitk_ws + (size_t)Lt * (128 * 128);
-    const size_t sstride = (size_t)ntiles * (128 * 128);
-    for (int it = threadIdx.x; it < 128 * SEGS; it += 256) {
-        const int R = it / SEGS, cs = it - R * SEGS;
-        const int c = co0 + cs * PER16;
-        const int trow = R >> 4, col = R & 15;
-        long long pix;
-        bool ok = c < p.Cout;
-        if constexpr (PAIR) {
-            const int img = col >> 3;
-            pix = ((long long)(b + img) * H + oh0 + trow) * W + (col & 7);
-            ok = ok && img < nimg;
-        } else {
-            pix = ((long long)b * H + oh0 + trow) * W + ow0 + col;
-        }
-        if (!ok) continue;
-        float f[PER16];
-#pragma unroll
-        for (int e = 0; e < PER16; ++e) f[e] = 0.f;
-        for (int s_ = 0; s_ < p.splitk; ++s_) {
-            const float* src = part + s_ * sstride + R * 128 + cs * PER16;
-#pragma unroll
-            for (int e = 0; e < PER16; e += 4) {
-                const f32x4_t v = *(const f32x4_t*)(src + e);
-                f[e] += v[0]; f[e + 1] += v[1]; f[e + 2] += v[2]; f[e + 3] += v[3];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < PER16; ++e) {
-            float v = f[e] + ((p.bias != nullptr && c + e < p.wrows) ? p.bias[c + e] : 0.f);
-            if (p.act == C2W_ACT_SILU) v = silu_f(v);
-            if (p.act == C2W_ACT_RELU) v = fmaxf(v, 0.f);
-            f[e] = v;
-        }
-        const size_t off = ((size_t)pix * p.ldy + c) * ESZ;
-        if (p.mul != nullptr || p.res != nullptr) {  // on the value as the unsplit kernel would have staged it: rounded to the storage type first
-            u32x4_t st = pack16<T>(f);
-            unpack16<T>(st, f);
-            if (p.mul != nullptr) {
-                float gm[PER16];
-                unpack16<T>(*(const u32x4_t*)((const char*)p.mul + off), gm);
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) f[e] *= p.mulmode == C2W_MUL_DSILU ? dsilu_f(gm[e]) : gm[e];
-            }
-            if (p.res != nullptr) {
-                float gr[PER16];
-                unpack16<T>(*(const u32x4_t*)((const char*)p.res + off), gr);
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) f[e] += gr[e];
-            }
-        }
-        *(u32x4_t*)((char*)p.y + off) = pack16<T>(f);
+    const int R = rblk * RPB + (int)threadIdx.x / SEGS, cs = (int)threadIdx.x % SEGS;
+    const int c = co0 + cs * PER16;
+    const int trow = R >> 4, col = R & 15;
+    long long pix;
+    bool ok = c < p.Cout;
+    if constexpr (PAIR) {
+        const int img = col >> 3;
+        pix = ((long long)(b + img) * H + oh0 + trow) * W + (col & 7);
+        ok = ok && img < nimg;
+    } else {
+        pix = ((long long)b * H + oh0 + trow) * W + ow0 + col;
     }
+    if (!ok) return;
+    const float* const src = p.splitk_ws + (size_t)Lt * (128 * 128) + R * 128 + cs * PER16;
+    const size_t sstride = (size_t)ntiles * (128 * 128);
+    f32x4_t part[8][PER16 / 4];
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+        for (int e = 0; e < PER16 / 4; ++e)
+            part[s_][e] = s_ < p.splitk ? *(const f32x4_t*)(src + s_ * sstride + 4 * e) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const size_t off = ((size_t)pix * p.ldy + c) * ESZ;
+    u32x4_t mv = {}, rv = {};
+    if (p.mul != nullptr) mv = *(const u32x4_t*)((const char*)p.mul + off);
+    if (p.res != nullptr) rv = *(const u32x4_t*)((const char*)p.res + off);
+    float f[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) v += part[s_][e >> 2][e & 3];  // split 0 first: a fixed order
+        v += (p.bias != nullptr && c + e < p.wrows) ? p.bias[c + e] : 0.f;
+        if (p.act == C2W_ACT_SILU) v = silu_f(v);
+        if (p.act == C2W_ACT_RELU) v = fmaxf(v, 0.f);
+        f[e] = v;
+    }
+    if (p.mul != nullptr || p.res != nullptr) {  // on the value as the unsplit kernel stages it: rounded to the storage type first
+        u32x4_t st = pack16<T>(f);
+        unpack16<T>(st, f);
+        if (p.mul != nullptr) {
+            float gm[PER16];
+            unpack16<T>(mv, gm);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) f[e] *= p.mulmode == C2W_MUL_DSILU ? dsilu_f(gm[e]) : gm[e];
+        }
+        if (p.res != nullptr) {
+            float gr[PER16];
+            unpack16<T>(rv, gr);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) f[e] += gr[e];
+        }
+    }
+    *(u32x4_t*)((char*)p.y + off) = pack16<T>(f);
 }
 
 template <typename T, bool PAIR>
@@ -589,7 +592,7 @@ int launch_splitk(const C2wConvArgs& a, int ntiles, hipStream_t st) {
     conv_patch_half_kernel<T, PAIR, true><<<ntiles * a.splitk, H_NTHR, H_LDS, st>>>(a);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
-    conv_splitk_epilogue_kernel<T, PAIR><<<ntiles, 256, 0, st>>>(a, ntiles);
+    conv_splitk_epilogue_kernel<T, PAIR><<<ntiles * (128 / (256 / (128 / (16 / (int)sizeof(T))))), 256, 0, st>>>(a, ntiles);
     return (int)hipGetLastError();
 }
 
@@ -639,13 +642,13 @@ int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long lon
     const int nN = (a.Cout + 127) / 128;
     const long long tiles = (pair ? (long long)((a.B + 1) >> 1) * (a.Hin >> 3) : (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4)) * nN;
     const int nchunk = a.Cin / (dtype == C2W_DTYPE_F32 ? 32 : 64);
-    if (tiles >= 256 || nchunk < 2) return 1;  // a workgroup per CU already: the launch is not a bare chain
-    int best = 1;
-    for (int d = 2; d <= nchunk; ++d) {  // the smallest divisor of the chunk count that reaches one workgroup per CU (else the largest)
-        if (nchunk % d != 0) continue;
-        best = d;
-        if (tiles * d >= 256) break;
-    }
+    // As many workgroups per tile as keep the launch at ONE workgroup per CU (two per CU share the matrix pipe: the chain gets
+    // shorter and each stage slower -- 444 workgroups of 27 stages took 31.6 us where 222 of 54 take 35.9, before the 18-us second
+    // launch), at most one per chunk and 8 (the reduction's unroll).  76 tiles x 8 chunks -> 3 workgroups of 2 / 3 / 3 chunks.
+    int best = (int)(256 / (tiles > 0 ? tiles : 1));
+    if (best > nchunk) best = nchunk;
+    if (best > 8) best = 8;
+    if (best < 2) return 1;
     if (ws_bytes != nullptr) *ws_bytes = (unsigned long long)best * tiles * 128 * 128 * sizeof(float);
     return best;
 }

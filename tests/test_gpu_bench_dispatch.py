@@ -728,8 +728,8 @@ def test_stage_major_packed_weights_give_the_same_bits(case, dt):
 
 
 SPLITK_CASES = [  # (name, pair, B, H, Cin, Cout, expected workgroups per tile)
-    ("512->512 @8x8, 37 windows (L = 49): 76 tiles", True, 37, 8, 512, 512, 4),
-    ("384->384 @16x16, 37 windows: 222 tiles", False, 37, 16, 384, 384, 2),
+    ("512->512 @8x8, 37 windows (L = 49): 76 tiles, chunks 2 / 3 / 3", True, 37, 8, 512, 512, 3),
+    ("384->384 @16x16, 18 windows: 108 tiles", False, 18, 16, 384, 384, 2),
     ("512->512 @8x8, 5 windows: 12 tiles, every chunk its own workgroup", True, 5, 8, 512, 512, 8),
     ("256->256 @32x32, 3 windows: 48 tiles", False, 3, 32, 256, 256, 4),
 ]
@@ -778,13 +778,14 @@ def test_split_k_convolution_for_underfilled_launches(case, epi, dt):
     E.conv(x, w, bias, y_ref, g, dt, **kw)
     close(outs[0], y_ref, 2e-5 if dt == F32 else TOL[dt], name + " / " + epi + ": split vs restatement")
     with pytest.raises(_lib.C2wError):  # not the plan's answer
-        ops.conv(x, w, bias, y, g, dt, splitk=(ws, ns + 1 if ns < 8 else 2), **kw)
+        ops.conv(x, w, bias, y, g, dt, splitk=(ws, ns + 1 if ns < 8 else 2), **kw)  # (scratch sized for the plan's answer; the count alone is refused)
     with pytest.raises(_lib.C2wError):  # scratch too small
         ops.conv(x, w, bias, y, g, dt, splitk=(ws[: nbytes // 8], ns), **kw)
 
 
 def test_split_k_plan_leaves_filled_launches_alone():
     for g, dt in ((geom(128, 8, 8, 512, 8, 8, 512, 512, 512, S1), BF16),      # 256 tiles: a workgroup per CU
+                  (geom(37, 16, 16, 384, 16, 16, 384, 384, 384, S1), BF16),   # 222 tiles: two per tile would be two workgroups on most CUs
                   (geom(37, 64, 64, 128, 64, 64, 128, 128, 128, S1), BF16),   # 592 tiles on the 16x16-tile kernel
                   (geom(4, 16, 16, 64, 16, 16, 128, 128, 128, S1), BF16)):    # one K chunk: nothing to split
         assert ops.conv_splitk_plan(g, dt) == (1, 0)
