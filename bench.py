@@ -408,6 +408,11 @@ def run_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     timer.mode = "dominant"
+    # the host enqueues ~330 launches per step one step ahead of the device; a generation-2 garbage collection in the middle of that (tens of
+    # thousands of live tensor / ctypes objects) shows as one 50-ms step in twenty: collect now, not inside the timed region
+    import gc
+    gc.collect()
+    gc.disable()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # step boundaries on the main stream (which joins the gradient stream inside every step)
     t0 = time.perf_counter()
     marks[0].record()
@@ -419,6 +424,7 @@ def run_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timer.mode = "off"
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)

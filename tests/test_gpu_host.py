@@ -612,7 +612,8 @@ def test_output_convolution_folds_inside_the_engine_on_the_gpu(prec, tol):
 def test_independent_stream_is_on_another_hardware_queue():
     """streams.py: HIP hands hardware queues to new streams in rotation and two streams on one queue run in order -- after a few
     streams exist, a freshly created one may sit on the caller's queue and the two-stream backward would silently serialise.
-    ``independent_stream`` returns one that overtakes a running kernel on the current stream, wherever the rotation stands."""
+    ``independent_stream`` returns one whose work, handed over through an event, runs next to what the current stream goes on with
+    (round 6: the probe times that pattern; the one-launch probe of rounds 4-5 passed on pairs that serialise), wherever the rotation stands."""
     from climate2weather_amd.streams import independent_stream, overtakes
     dev = torch.device("cuda", 0)
     plain = [torch.cuda.Stream(device=dev) for _ in range(12)]
@@ -632,7 +633,7 @@ def test_independent_stream_is_on_another_hardware_queue():
     net = ScoreUNet(channels=6, spatial=2, activation=torch.nn.SiLU, embedding_dim=64, hidden_channels=[64, 128], hidden_blocks=[1, 1],
                     attention_levels=[1], kernel_size=3, padding_mode="zeros").to(dev)
     eng = net._get_engine()
-    assert eng.grad_stream() is None  # one stream by default (round 5)
+    assert (eng.grad_stream() is None) == (os.environ.get("C2W_WGRAD_STREAM", "0") != "1")  # one stream by default (round 5)
     assert overtakes(eng.side_stream())
     torch.cuda.synchronize()
 
