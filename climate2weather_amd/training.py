@@ -5,8 +5,12 @@
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL on ROCm).  What differs from the reference below
 the API:
   * noise process, network forward, loss, and the whole backward are the engine's HIP sequences (no autograd graph); the noise
-    eps is a counter-based (Philox) stream that the input-conversion and the loss kernels each regenerate from a per-step seed,
-    so the (B, C, H, W) noise tensor is never written or read (``fused_noise=False`` or an injected ``eps`` restore the tensor);
+    eps is a counter-based (Philox) stream of a per-step seed and the (B, C, H, W) fp32 noise tensor is never written or read
+    (``fused_noise=False`` or an injected ``eps`` restore the tensor).  Where the output conv runs on the 16x16-tile kernel (round 6)
+    the stream is generated ONCE, by the input conversion, which keeps it as half-precision NHWC rows; the loss tail is the output
+    conv's epilogue and reads them back -- the step's noise is then the stream rounded to half precision, in x_t and in the loss
+    alike, and the network's prediction is never written.  Elsewhere the input conversion and the loss kernel each regenerate
+    the fp32 stream (rounds 1-5; ``C2W_NO_LOSS_FUSION=1`` everywhere);
   * gradients live in ONE flat fp32 buffer laid out in reverse finalisation order; while backward is still running,
     finished buckets of it are all-reduced over xGMI (replaces Lightning Fabric's DDP wrapper, training_loop.py:116,375-378)
     -- a sum; the 1/world_size mean is folded into the optimizer kernel.  Everything a bucket needs (the optional cast to the
