@@ -358,6 +358,7 @@ C2wKnobs read_knobs() {
     k.conv_pair = !off0("C2W_CONV_PAIR");
     k.conv_ts2_patch = !off0("C2W_CONV_TS2_PATCH");
     k.ts2_one_launch = getenv("C2W_TS2_FOUR_LAUNCHES") == nullptr;
+    k.ts2_pairs = !off0("C2W_TS2_PAIRS");
     k.up_patch = getenv("C2W_NO_UP_PATCH") == nullptr;
     k.wgrad_narrow = getenv("C2W_NO_NARROW") == nullptr;
     k.wpacked = getenv("C2W_NO_WPACKED") == nullptr;

@@ -16,6 +16,7 @@
 // (The 16x16-tile, one-workgroup-per-CU form of this kernel -- 156 KB of LDS -- measured 5 % behind two half-tile workgroups per CU
 // and was removed in round 3; the cycle-stamp / ablation builds live in lab/csrc/conv_patch_lab.hip.)
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_epilogue.h"
 #include "knobs.h"
@@ -440,6 +441,206 @@ __device__ __forceinline__ void conv_patch_ts2_class(const C2wConvArgs& p, char*
     est.finish(p, O, OS, tid);
 }
 
+// Round 6: TWO classes per workgroup.  A class's workgroup above is mostly overhead: 1-4 taps x Cout / 64 chunks = 2-8 MFMA stages between
+// a prologue (patch + two weight stages in flight), a patch reload per chunk and an epilogue with strided stores -- about 10 us per
+// workgroup of which 1-4 are matrix work (128 -> 128 from 64^2: 16,384 workgroups, 0.405 ms, 0.15 of peak).  Here a workgroup stages the
+// patch ONCE per chunk for two classes -- {3, 0}: 4 + 1 taps, {1, 2}: 2 + 2 taps -- keeps two accumulator sets (128 of the 256 registers a
+// wave has at two workgroups per CU) and runs two epilogues: half the workgroups, half the patch loads and prologues.
+struct Ts2PairTap { int t9, khp, kwp, set; };
+template <int SEL> struct Ts2Pair;
+template <> struct Ts2Pair<0> {  // classes 3 (set 0) and 0 (set 1)
+    static constexpr int NT = 5, CLS0 = 3, CLS1 = 0;
+    static constexpr Ts2PairTap taps[5] = {{0, 2, 2, 0}, {2, 2, 1, 0}, {6, 1, 2, 0}, {8, 1, 1, 0}, {4, 1, 1, 1}};
+};
+template <> struct Ts2Pair<1> {  // classes 1 (set 0) and 2 (set 1)
+    static constexpr int NT = 4, CLS0 = 1, CLS1 = 2;
+    static constexpr Ts2PairTap taps[4] = {{3, 1, 2, 0}, {5, 1, 1, 0}, {1, 2, 1, 1}, {7, 1, 1, 1}};
+};
+
+template <typename T, int SEL>
+__device__ __forceinline__ void conv_patch_ts2_pair(const C2wConvArgs& p, char* smem, int L) {
+    typedef Ts2Pair<SEL> TC;
+    constexpr int NT = TC::NT;
+    constexpr int ESZ = sizeof(T);
+    constexpr int CK = 128 / ESZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int nN = (p.Cout + 127) / 128;
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hin, W = p.Win;  // the dy grid; the output grid is 2H x 2W
+    const int tw = W >> 4, tpi = (H >> 3) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 3, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)H * W * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * NT;
+    // (source offsets are recomputed where they are used: two accumulator sets leave no registers to hold them across the loop)
+    auto issue_stage_w = [&](int st) {  // weights of global stage st = chunk * NT + idx into ring slot st % 3
+        const int c2 = st / NT, i2 = st - c2 * NT;
+        int t9 = TC::taps[0].t9;
+#pragma unroll
+        for (int k = 1; k < NT; ++k) t9 = i2 == k ? TC::taps[k].t9 : t9;
+        const uint32_t so = (uint32_t)(t9 * p.Cin + c2 * CK) * ESZ;
+        const int wslot = st % 3;
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (t_ >> 3) + 32 * i;
+            const uint32_t wvo = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((t_ & 7) ^ (row & 7)) << 4);
+            glds16(rw, smem + H_PBYTES + wslot * WBYTES + wid * 1024 + i * 4096, wvo, so);
+        }
+    };
+    auto issue_patch = [&](int chunk) {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int pc = r * 4 + wid;
+            pc = pc < H_NPIECE ? pc : H_NPIECE - 1;
+            const int pr = pc / 3, pg = pc - pr * 3;
+            const int px = pg * 8 + (l_ >> 3);
+            const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px;
+            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < 18;
+            const uint32_t lc = (uint32_t)((l_ & 7) ^ ((l_ >> 3) & 7));
+            const uint32_t pvo = ok ? (uint32_t)((ih * W + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+            glds16(rx, smem + pc * 1024, pvo, (uint32_t)chunk * 128u);
+        }
+    };
+
+    // Fragment addresses: FOUR registers instead of the 32 of conv_patch_half_kernel (two accumulator sets need the rest).  Row m of the
+    // A tile is 2048 bytes further (its swizzle depends on li only), pixel row n of the patch PW * 128 bytes further: immediates of the
+    // ds_read; the second K half flips chunk bit 2 of the swizzled 16-byte slot = bit 6 of the address (zero in everything else).
+    const uint32_t offA0 = (uint32_t)(H_PBYTES + (wm * 64 + li) * 128 + ((lg ^ (li & 7)) << 4));
+    uint32_t preB0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = li + kw;
+        preB0[kw] = (uint32_t)((wn * 4 * PW + px) * 128 + ((lg ^ (px & 7)) << 4));
+    }
+
+    f32x4_t acc[2][4][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[q][m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue_patch(0);
+    issue_stage_w(0);
+    issue_stage_w(1);
+    int np = 4;  // LDS-DMA pieces of the NEXT stage that may still be in flight when a stage starts
+    u32x4_t da[4] = {}, db[4] = {};
+
+    auto stage = [&](auto IDXc, int c) {
+        constexpr int IDX = decltype(IDXc)::value;
+        constexpr int KH = TC::taps[IDX].khp, KW = TC::taps[IDX].kwp, SET = TC::taps[IDX].set;
+        constexpr int PSET = TC::taps[(IDX + NT - 1) % NT].set;  // the set the deferred second half (da, db) of the PREVIOUS stage belongs to
+        const int s = c * NT + IDX;
+        const uint32_t wso = (uint32_t)(s % 3) * WBYTES;
+        wait_vm4(np);
+        __builtin_amdgcn_s_barrier();
+        if (IDX == 0 && c > 0) {  // single patch buffer: every wave is past the previous chunk only now
+            issue_patch(c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        np = 0;
+        if (s + 2 < NS) {
+            issue_stage_w(s + 2);
+            np = 4;
+        }
+        u32x4_t a0[4], b0[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA0 + wso + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b0[n] = *(const u32x4_t*)(smem + preB0[KW] + n * (PW * 128) + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[PSET][m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + wso + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) db[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[SET][m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        stage(IC<0>{}, c); stage(IC<1>{}, c); stage(IC<2>{}, c); stage(IC<3>{}, c);
+        if constexpr (NT > 4) stage(IC<4>{}, c);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[TC::taps[NT - 1].set][m][n]);
+
+    // the epilogues' lane coordinates are derived afresh (kept across the loop they cost registers the two accumulator sets do not leave)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, li_e = lane_e & 15, lg_e = lane_e >> 4;
+    float bv[4][4];
+    epi_load_bias(p, co0 + wm * 64 + lg_e * 4, bv);
+    constexpr int OS = 128 * ESZ + 16;
+    char* const O = smem;
+    // both accumulator sets leave the registers FIRST (two output tiles of 34,816 bytes fit the loop's LDS): with one set still live the
+    // epilogue's prefetch arrays do not fit next to it
+    static_assert(2 * 128 * OS <= H_LDS, "two output tiles");
+    __syncthreads();
+    epi_acc_to_lds<T>(O, OS, acc[0], bv, p.act, wm * 64, wn * 64, li_e, lg_e);
+    __builtin_amdgcn_sched_barrier(0);  // one set after the other (interleaved, the fp16 build's conversions need 9 registers more than there are)
+    epi_acc_to_lds<T>(O + 128 * OS, OS, acc[1], bv, p.act, wm * 64, wn * 64, li_e, lg_e);
+    __syncthreads();
+    {
+        constexpr int PY = TC::CLS0 >> 1, PX = TC::CLS0 & 1;
+        EpiStore<T, 128, H_NTHR> est;
+        est.prefetch_tile16_s2(p, tid_e, co0, ((long long)b * (2 * H) + 2 * oh0 + PY) * (2 * W) + 2 * ow0 + PX, 2 * W);
+        est.finish(p, O, OS, tid_e);
+    }
+    {
+        constexpr int PY = TC::CLS1 >> 1, PX = TC::CLS1 & 1;
+        EpiStore<T, 128, H_NTHR> est;
+        est.prefetch_tile16_s2(p, tid_e, co0, ((long long)b * (2 * H) + 2 * oh0 + PY) * (2 * W) + 2 * ow0 + PX, 2 * W);
+        est.finish(p, O + 128 * OS, OS, tid_e);
+    }
+}
+
+// blockIdx = 8 * (2 * tile-in-XCD + pair slot) + XCD: the two workgroups of a tile are neighbours on one XCD (their patch and residual
+// lines meet in its L2); slot 0 = classes {3, 0} (five taps), slot 1 = {1, 2} (four).
+template <typename T>
+__global__ __launch_bounds__(H_NTHR, 2) void conv_patch_ts2_pairs_kernel(const C2wConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x, xcd = bid & 7, rest = bid >> 3, slot = rest & 1, j = rest >> 1;
+    const int ntile = ((p.Cout + 127) / 128) * p.B * (p.Hin >> 3) * (p.Win >> 4);
+    const int q = ntile >> 3, r = ntile & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    if (j >= (xcd < r ? q + 1 : q)) return;  // (grid padded to a multiple of 8 tiles per slot)
+    if (slot == 0) conv_patch_ts2_pair<T, 0>(p, smem, L);
+    else conv_patch_ts2_pair<T, 1>(p, smem, L);
+}
+
 // One kernel per class (four launches): with the four bodies in one kernel the register allocation of the 4-tap class governs
 // all of them and the merged code spilled 144 VGPRs.
 template <typename T, int CLS>
@@ -501,7 +702,24 @@ int launch_ts2_class(const C2wConvArgs& a, hipStream_t st) {
 }
 
 template <typename T>
+int launch_ts2_pairs(const C2wConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_ts2_pairs_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    const int nN = (a.Cout + 127) / 128;
+    const int nM = a.B * (a.Hin >> 3) * (a.Win >> 4);
+    const int ntile = nM * nN, per_xcd = (ntile + 7) / 8;
+    conv_patch_ts2_pairs_kernel<T><<<8 * 2 * per_xcd, H_NTHR, H_LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
 int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
+    if constexpr (std::is_same<T, bf16_t>::value) {  // bf16 only: 249 registers; the fp16 build of the same body needs 9 more than a wave has
+        if (c2w_knobs().ts2_pairs && c2w_knobs().ts2_one_launch) return launch_ts2_pairs<T>(a, st);  // (and two fp32 accumulator sets are out of the question)
+    }
     if (c2w_knobs().ts2_one_launch) return launch_ts2_all<T>(a, st);
     int rc = launch_ts2_class<T, 3>(a, st);
     if (rc == 0) rc = launch_ts2_class<T, 1>(a, st);

@@ -9,6 +9,7 @@ struct C2wKnobs {
     bool conv_pair;       // C2W_CONV_PAIR=0      8-pixel-wide images NOT paired on the halo-patch kernels (gather kernels instead)
     bool conv_ts2_patch;  // C2W_CONV_TS2_PATCH=0 stride-2 input gradient NOT on the parity-class halo-patch kernel
     bool ts2_one_launch;  // C2W_TS2_FOUR_LAUNCHES=1 stride-2 input gradient as one launch per parity class instead of one launch for the four
+    bool ts2_pairs;       // C2W_TS2_PAIRS=0      stride-2 input gradient with one class per workgroup (round 4) instead of two (round 6; 16-bit)
     bool up_patch;        // C2W_NO_UP_PATCH=1    up-convs NOT on the halo-patch kernels (upsampling folded into the gather kernel instead)
     bool pool2;           // C2W_NO_POOL2=1       c2w_conv_pool2_supported answers 0 (callers run conv + c2w_sumpool2)
     bool ln_fusion;       // C2W_NO_LN_FUSION=1   no LayerNorm forward / backward in conv epilogues (callers run the separate passes)
