@@ -457,7 +457,9 @@ template <> struct Ts2Pair<1> {  // classes 1 (set 0) and 2 (set 1)
     static constexpr Ts2PairTap taps[4] = {{3, 1, 2, 0}, {5, 1, 1, 0}, {1, 2, 1, 1}, {7, 1, 1, 1}};
 };
 
-template <typename T, int SEL>
+// PIPE: the second K half of a stage is deferred across the next stage's barrier (conv_patch_half_kernel's schedule: 32 more registers).  The fp16
+// build does not fit with it (9 registers over; anything spilled breaks the counted vmcnt waits) and runs the two halves back to back.
+template <typename T, int SEL, bool PIPE>
 __device__ __forceinline__ void conv_patch_ts2_pair(const C2wConvArgs& p, char* smem, int L) {
     typedef Ts2Pair<SEL> TC;
     constexpr int NT = TC::NT;
@@ -568,34 +570,53 @@ __device__ __forceinline__ void conv_patch_ts2_pair(const C2wConvArgs& p, char* 
 #pragma unroll
         for (int n = 0; n < 4; ++n) b0[n] = *(const u32x4_t*)(smem + preB0[KW] + n * (PW * 128) + KH * PROW);
         __builtin_amdgcn_sched_barrier(0);
-        if (s > 0) {
+        if constexpr (PIPE) {
+            if (s > 0) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[PSET][m][n]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + wso + m * 2048);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) db[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[PSET][m][n]);
+                for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[SET][m][n]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[SET][m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + wso + m * 2048);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b0[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[SET][m][n]);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + wso + m * 2048);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) db[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) Mma<T>::run(a0[m], b0[n], acc[SET][m][n]);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment is in registers before its slot may be refilled
     };
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
         stage(IC<0>{}, c); stage(IC<1>{}, c); stage(IC<2>{}, c); stage(IC<3>{}, c);
         if constexpr (NT > 4) stage(IC<4>{}, c);
     }
+    if constexpr (PIPE) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[TC::taps[NT - 1].set][m][n]);
+            for (int n = 0; n < 4; ++n) Mma<T>::run(da[m], db[n], acc[TC::taps[NT - 1].set][m][n]);
+    }
 
     // the epilogues' lane coordinates are derived afresh (kept across the loop they cost registers the two accumulator sets do not leave)
     int tid_e = threadIdx.x;
@@ -637,8 +658,9 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_ts2_pairs_kernel(const C
     const int q = ntile >> 3, r = ntile & 7;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     if (j >= (xcd < r ? q + 1 : q)) return;  // (grid padded to a multiple of 8 tiles per slot)
-    if (slot == 0) conv_patch_ts2_pair<T, 0>(p, smem, L);
-    else conv_patch_ts2_pair<T, 1>(p, smem, L);
+    constexpr bool PIPE = std::is_same<T, bf16_t>::value;
+    if (slot == 0) conv_patch_ts2_pair<T, 0, PIPE>(p, smem, L);
+    else conv_patch_ts2_pair<T, 1, PIPE>(p, smem, L);
 }
 
 // One kernel per class (four launches): with the four bodies in one kernel the register allocation of the 4-tap class governs
@@ -717,8 +739,8 @@ int launch_ts2_pairs(const C2wConvArgs& a, hipStream_t st) {
 
 template <typename T>
 int launch_ts2(const C2wConvArgs& a, hipStream_t st) {  // largest class first
-    if constexpr (std::is_same<T, bf16_t>::value) {  // bf16 only: 249 registers; the fp16 build of the same body needs 9 more than a wave has
-        if (c2w_knobs().ts2_pairs && c2w_knobs().ts2_one_launch) return launch_ts2_pairs<T>(a, st);  // (and two fp32 accumulator sets are out of the question)
+    if constexpr (sizeof(T) == 2) {  // bf16: 249 registers with the deferred K half; fp16: without it (PIPE); two fp32 accumulator sets are out of the question
+        if (c2w_knobs().ts2_pairs && c2w_knobs().ts2_one_launch) return launch_ts2_pairs<T>(a, st);
     }
     if (c2w_knobs().ts2_one_launch) return launch_ts2_all<T>(a, st);
     int rc = launch_ts2_class<T, 3>(a, st);
