@@ -68,6 +68,32 @@ __device__ __forceinline__ void epi_acc_to_lds(char* O, int OS, const f32x4_t (&
     }
 }
 
+// The same for a wave tile of 64 (co) x 16 N (pixel) accumulators (conv_patch_half8_kernel: eight waves, two pixel rows each).
+template <typename T, int N>
+__device__ __forceinline__ void epi_acc_to_lds_n(char* O, int OS, const f32x4_t (&acc)[4][N], const float (&bv)[4][4], int act, int col0, int row0,
+                                                 int li, int lg) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int col = col0 + m * 16 + lg * 4;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const int row = row0 + n * 16 + li;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[m][n][r] + bv[m][r];
+                if (act == C2W_ACT_SILU) v[r] = silu_f(v[r]);  // (wave-uniform; 32 values per lane here, not 64: no separate instantiations)
+                if (act == C2W_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (sizeof(T) == 4) {
+                *(f32x4_t*)(O + row * OS + col * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+                *(u32x2_t*)(O + row * OS + col * 2) = (u32x2_t){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+            }
+        }
+    }
+}
+
 // LDS rows [NROWS][128 channels] -> global.  pix(row) maps a tile row to the NHWC pixel index, or -1 if the row is outside.
 // Split in two so that the residual / multiplier loads fly while the accumulators are staged through LDS:
 //   EpiStore st; st.prefetch(...);  __syncthreads(); epi_acc_to_lds(...); __syncthreads();  st.finish(...);

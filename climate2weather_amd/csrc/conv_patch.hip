@@ -265,6 +265,205 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// EIGHT waves on the same 8x16-pixel x 128-channel tile (round 6): for launches of at most one workgroup per CU.  There the 4-wave
+// kernel leaves ONE wave on every SIMD, and a lone wave issues its LDS-DMA, its fragment reads, its barrier waits and its 32 MFMAs per
+// stage one after the other: 0.55 us per stage where the matrix work is 0.25 (512 -> 512 @8x8 at B = 128: 256 workgroups, 0.31 of peak;
+// the deep levels of a sampler step on a short trajectory: 76-228).  Eight waves = 2 (channel halves) x 4 (pixel-row pairs), wave tile
+// 64 co x 32 px = 32 accumulator registers, two waves per SIMD: one's waits are the other's MFMAs.  Same LDS plan, same weight ring
+// (two 1-KiB pieces per wave and stage: counted vmcnt(2)), same patch, same epilogues (EpiStore<T, 128, 512>).
+constexpr int H8_NTHR = 512;
+// (A version with TWO patch buffers -- the next chunk's patch fetched during the current one -- and a five-slot weight ring filled four
+// stages ahead, 143 KB of LDS, was 6 us per launch SLOWER than this one at 512 -> 512 @8x8: 47.7 against 41.9 us, the 4-wave kernel 44.7;
+// whatever bounds these launches, it is not the distance of the prefetch.  profiles/r06_experiments.md section 11.)
+__device__ __forceinline__ void wait_vm2(int n) {  // wave-uniform n in {0, 2}
+    if (n == 2) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T, bool PAIR = false, bool SPLITK = false>
+__global__ __launch_bounds__(H8_NTHR, 2) void conv_patch_half8_kernel(const C2wConvArgs p) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int CK = 128 / ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [patch | W0 | W1 | W2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;  // wn: pixel rows 2 wn, 2 wn + 1 of the tile
+
+    const int nN = (p.Cout + 127) / 128;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int nsplit = SPLITK ? p.splitk : 1;
+    const int sp = SPLITK ? L % nsplit : 0;
+    const int Lt = SPLITK ? L / nsplit : L;
+    const int tn = Lt % nN, tm = Lt / nN;
+    const int co0 = tn * 128;
+    const bool up = !PAIR && p.mode == C2W_CONV_UP;
+    const int H = p.Hout, W = p.Wout, Ws = p.Win;
+    const int tw = PAIR ? 1 : W >> 4, tpi = (H >> 3) * tw;
+    const int b = PAIR ? 2 * (tm / tpi) : tm / tpi, tt = tm - (tm / tpi) * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 3, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESZ;
+    const int nimg = PAIR ? (b + 1 < p.B ? 2 : 1) : 1;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)(img_bytes * nimg));
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+
+    const int nchunk_all = p.Cin / CK;
+    const int c_lo = SPLITK ? sp * nchunk_all / nsplit : 0;
+    const int nchunk = SPLITK ? (sp + 1) * nchunk_all / nsplit - c_lo : nchunk_all;
+    const int NS = nchunk * 9;
+
+    // patch pieces: 30 pieces over 8 waves = 4 rounds (pieces past the end repeat the last one)
+    uint32_t pvo[4];
+    int pdst[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int pc = r * 8 + wid;
+        pc = pc < H_NPIECE ? pc : H_NPIECE - 1;
+        const int pr = pc / 3, pg = pc - pr * 3;
+        const int px = pg * 8 + (lane >> 3);
+        const int pimg = PAIR && px >= 10 ? 1 : 0;
+        const int ih = oh0 - 1 + pr, iw = ow0 - 1 + px - 10 * pimg;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && px < (PAIR ? 20 : 18);
+        const uint32_t lc = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+        const int spix = up ? (ih >> 1) * Ws + (iw >> 1) : ih * Ws + iw;
+        pvo[r] = ok ? (uint32_t)(spix * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)img_bytes + (lc << 4) : C2W_OOB;
+        pdst[r] = pc * 1024;
+    }
+    uint32_t wvo[2];  // weight tile: 128 rows x 8 chunks = 2 rounds of 512 threads
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+    auto issue_w = [&](int chunk, int tap, int wslot) {
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rw, smem + H_PBYTES + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
+    };
+    auto issue_patch = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) glds16(rx, smem + pdst[r], pvo[r], (uint32_t)chunk * 128u);
+    };
+
+    // fragment addresses as in conv_patch_ts2_pair: A row m = + m * 2048, patch row n = + n * PW * 128 (immediates), second K half = ^ 64
+    const uint32_t offA0 = (uint32_t)(H_PBYTES + (wm * 64 + li) * 128 + ((lg ^ (li & 7)) << 4));
+    uint32_t preB0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = li + kw + (PAIR && li >= 8 ? 2 : 0);
+        preB0[kw] = (uint32_t)((wn * 2 * PW + px) * 128 + ((lg ^ (px & 7)) << 4));
+    }
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    issue_patch(c_lo);
+    issue_w(c_lo, 0, 0);
+    issue_w(c_lo, 1, 1);
+    int np = 2;  // LDS-DMA pieces of the next stage that may still be in flight
+    u32x4_t da[4] = {}, db[2] = {};
+
+    auto stage = [&](auto TAPc, int c) {
+        constexpr int TAP = decltype(TAPc)::value;
+        constexpr int KH = TAP / 3, KW = TAP % 3, WS = TAP % 3, T2 = (TAP + 2) % 9;
+        const int s = (c - c_lo) * 9 + TAP;
+        wait_vm2(np);
+        __builtin_amdgcn_s_barrier();
+        if (TAP == 0 && c > c_lo) {  // single patch buffer: every wave is past the previous chunk only now
+            issue_patch(c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        np = 0;
+        if (s + 2 < NS) {
+            issue_w(TAP + 2 >= 9 ? c + 1 : c, T2, (TAP + 2) % 3);
+            np = 2;
+        }
+        u32x4_t a0[4], b0[2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA0 + WS * WBYTES + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b0[n] = *(const u32x4_t*)(smem + preB0[KW] + n * (PW * 128) + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + WS * WBYTES + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) db[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) Mma<T>::run(a0[m], b0[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
+    };
+#pragma unroll 1
+    for (int c = c_lo; c < c_lo + nchunk; ++c) {
+        stage(IC<0>{}, c); stage(IC<1>{}, c); stage(IC<2>{}, c); stage(IC<3>{}, c); stage(IC<4>{}, c);
+        stage(IC<5>{}, c); stage(IC<6>{}, c); stage(IC<7>{}, c); stage(IC<8>{}, c);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+
+    if constexpr (SPLITK) {
+        float* const dst = p.splitk_ws + ((size_t)sp * (gridDim.x / nsplit) + Lt) * (128 * 128);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                *(f32x4_t*)(dst + (wn * 32 + n * 16 + li) * 128 + wm * 64 + m * 16 + lg * 4) = acc[m][n];
+        return;
+    }
+
+    float bv[4][4];
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    constexpr int OS = 128 * ESZ + 16;
+    EpiStore<T, 128, H8_NTHR> est;
+    const bool pool2 = !PAIR && (p.flags & C2W_CONV_POOL2) != 0;
+    if constexpr (PAIR) est.prefetch_pair8(p, tid, co0, ((long long)b * H + oh0) * W, H * W, nimg);
+    else if (!pool2) est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    __syncthreads();
+    char* const O = smem;
+    float* const red = (float*)(smem + 128 * OS);
+    if constexpr (ESZ == 2) {
+        if (p.ln_x != nullptr && tid < 128) red[tid] = 0.f;
+    }
+    epi_acc_to_lds_n<T, 2>(O, OS, acc, bv, p.act, wm * 64, wn * 32, li, lg);
+    __syncthreads();
+    if (pool2) {
+        est.finish_pool2(p, O, OS, tid, co0, ((long long)b * (H >> 1) + (oh0 >> 1)) * (W >> 1) + (ow0 >> 1), W >> 1);
+    } else if constexpr (ESZ == 2 && !PAIR) {
+        if (p.ln_x != nullptr) est.finish_ln(p, O, OS, tid, b, red);
+        else if (p.lnf_y != nullptr) est.finish_lnf(p, O, OS, tid, b);
+        else est.finish(p, O, OS, tid);
+    } else {
+        est.finish(p, O, OS, tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Input gradient of the stride-2 convolutions (C2W_CONV_TS2) on the halo patch.  Output pixel (2i + py, 2j + px) of parity class
 // (py, px) receives   sum over kh in K(py), kw in K(px) of  w[.][kh*3 + kw][.] . dy[i + a(kh)][j + a(kw)],   K(0) = {1}, K(1) = {0, 2},
 // a(0) = 1, a(1) = a(2) = 0  (conv_geom.h::src_pixel, TS2) -- a stride-1 convolution over dy with 1 / 2 / 2 / 4 taps whose result
@@ -822,6 +1021,20 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const C2wConv
     *(u32x4_t*)((char*)p.y + off) = pack16<T>(f);
 }
 
+// at most one workgroup per CU: the eight-wave form (two waves per SIMD instead of one)
+static inline bool half8_wanted(long long wgs) { return c2w_knobs().half8 && wgs <= 256; }
+
+template <typename T, bool PAIR, bool SPLITK>
+int launch_half8(const C2wConvArgs& a, int nwg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half8_kernel<T, PAIR, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    conv_patch_half8_kernel<T, PAIR, SPLITK><<<nwg, H8_NTHR, H_LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+
 template <typename T, bool PAIR>
 int launch_splitk(const C2wConvArgs& a, int ntiles, hipStream_t st) {
     static bool attr = false;
@@ -829,8 +1042,13 @@ int launch_splitk(const C2wConvArgs& a, int ntiles, hipStream_t st) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half_kernel<T, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         attr = true;
     }
-    conv_patch_half_kernel<T, PAIR, true><<<ntiles * a.splitk, H_NTHR, H_LDS, st>>>(a);
-    int rc = (int)hipGetLastError();
+    int rc;
+    if (half8_wanted((long long)ntiles * a.splitk)) {
+        rc = launch_half8<T, PAIR, true>(a, ntiles * a.splitk, st);
+    } else {
+        conv_patch_half_kernel<T, PAIR, true><<<ntiles * a.splitk, H_NTHR, H_LDS, st>>>(a);
+        rc = (int)hipGetLastError();
+    }
     if (rc != 0) return rc;
     conv_splitk_epilogue_kernel<T, PAIR><<<ntiles * (128 / (256 / (128 / (16 / (int)sizeof(T))))), 256, 0, st>>>(a, ntiles);
     return (int)hipGetLastError();
@@ -848,6 +1066,7 @@ int launch(const C2wConvArgs& a, hipStream_t st) {  // two 8x16-tile workgroups 
     const int nN = (a.Cout + 127) / 128;
     const int nMh = a.B * (a.Hout >> 3) * (a.Wout >> 4);
     if (a.splitk > 1) return launch_splitk<T, false>(a, nMh * nN, st);
+    if (half8_wanted((long long)nMh * nN)) return launch_half8<T, false, false>(a, nMh * nN, st);
     conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, H_LDS, st>>>(a);
     return (int)hipGetLastError();
 }
@@ -865,6 +1084,7 @@ int launch_pair(const C2wConvArgs& a, hipStream_t st) {
     const int nN = (a.Cout + 127) / 128;
     const int nM = ((a.B + 1) >> 1) * (a.Hin >> 3);
     if (a.splitk > 1) return launch_splitk<T, true>(a, nM * nN, st);
+    if (half8_wanted((long long)nM * nN)) return launch_half8<T, true, false>(a, nM * nN, st);
     conv_patch_half_kernel<T, true><<<nM * nN, H_NTHR, H_LDS, st>>>(a);
     return (int)hipGetLastError();
 }
