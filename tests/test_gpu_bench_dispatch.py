@@ -789,3 +789,84 @@ def test_split_k_plan_leaves_filled_launches_alone():
                   (geom(37, 64, 64, 128, 64, 64, 128, 128, 128, S1), BF16),   # 592 tiles on the 16x16-tile kernel
                   (geom(4, 16, 16, 64, 16, 16, 128, 128, 128, S1), BF16)):    # one K chunk: nothing to split
         assert ops.conv_splitk_plan(g, dt) == (1, 0)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16, F32])
+@pytest.mark.parametrize("case", [("512->512 @8x8 paired, B = 128: 256 workgroups", 128, 8, 512, 512),
+                                  ("384->384 @16x16, B = 32: 192 workgroups", 32, 16, 384, 384),
+                                  ("256->256 @32x32, B = 4: 64 workgroups, residual + multiplier", 4, 32, 256, 256)],
+                         ids=["pair", "16x16", "32x32"])
+def test_eight_wave_tile_kernel_gives_the_four_wave_kernels_bits(case, dt, monkeypatch):
+    """Round 6, conv_patch_half8_kernel (launches of at most one workgroup per CU): the same tile, the same K order per output element
+    (chunks, taps, the two K halves of a stage) on eight waves instead of four -- every output bit for bit what C2W_NO_HALF8=1 gives,
+    over the epilogue flavours the 8x16-tile kernels carry (bias + SiLU pair, multiplier + residual, plain) and the split-K form."""
+    name, B, H, Cin, Cout = case
+    if dt == F32:
+        Cin = Cin // 2
+    g = geom(B, H, H, Cin, H, H, Cout, Cout, Cout, S1)
+    assert ops.conv_dispatch(g, dt) in (PAIR, HALF)
+    npix = B * H * H
+    x = rnd((npix, Cin), dt, 1)
+    w = rnd((Cout, 9, Cin), dt, 2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd((Cout,), F32, 3)
+    res, mul = rnd((npix, Cout), dt, 4), rnd((npix, Cout), dt, 5)
+    outs = {}
+    for half8 in (True, False):
+        if not half8:
+            monkeypatch.setenv("C2W_NO_HALF8", "1")
+        ops.knobs_reload()
+        got = []
+        y, y2 = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev()), torch.full((npix, Cout), 3.0, dtype=TD[dt], device=dev())
+        ops.conv(x, w, bias, y, g, dt, act=ops.ACT_SILU_PAIR, y2=y2)
+        got += [y, y2]
+        y = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev())
+        ops.conv(x, w, None, y, g, dt, mul=mul, mulmode=ops.MUL_DSILU, res=res)
+        got.append(y)
+        y = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev())
+        ops.conv(x, w, bias, y, g, dt)
+        got.append(y)
+        ns, nbytes = ops.conv_splitk_plan(g, dt)
+        if ns > 1:
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev())
+            y = torch.full((npix, Cout), 5.0, dtype=TD[dt], device=dev())
+            ops.conv(x, w, bias, y, g, dt, res=res, splitk=(ws, ns))
+            got.append(y)
+        torch.cuda.synchronize()
+        outs[half8] = got
+    monkeypatch.delenv("C2W_NO_HALF8")
+    ops.knobs_reload()
+    assert len(outs[True]) == len(outs[False])
+    for i, (a, b_) in enumerate(zip(outs[True], outs[False])):
+        assert a.float().abs().sum().item() > 0 and torch.equal(a, b_), (name, i)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("case", [("128->128 from 16x16 (two chunks, one channel tile), residual", 8, 16, 128, 128),
+                                  ("256->128 from 8x16 (four chunks), residual", 16, 8, 256, 128),
+                                  ("128->256 from 32x32 (two channel tiles), no residual", 4, 32, 128, 256)], ids=["a", "b", "c"])
+def test_two_class_stride2_input_gradient_gives_the_one_class_kernels_bits(case, dt, monkeypatch):
+    """Round 6, conv_patch_ts2_pairs_kernel (model/nn.py:169-174 backward): two output-parity classes per workgroup, each class's taps in the
+    order the one-class kernel walks them -- every output bit for bit what C2W_TS2_PAIRS=0 gives (the fp16 form runs its stages without
+    the deferred K half: the same order of accumulation)."""
+    name, B, Hd, Cdy, Cdx = case
+    Wd = 16 if Hd == 8 else Hd
+    g = geom(B, Hd, Wd, Cdy, 2 * Hd, 2 * Wd, Cdx, Cdx, Cdx, TS2)
+    assert ops.conv_dispatch(g, dt) == TS2P
+    dy = rnd((B * Hd * Wd, Cdy), dt, 1)
+    wt = rnd((Cdx, 9, Cdy), dt, 2, scale=1.0 / math.sqrt(9 * Cdy))
+    res = rnd((B * 4 * Hd * Wd, Cdx), dt, 3) if "no residual" not in name else None
+    outs = []
+    for pairs in (True, False):
+        if not pairs:
+            monkeypatch.setenv("C2W_TS2_PAIRS", "0")
+        ops.knobs_reload()
+        dx = torch.full((B * 4 * Hd * Wd, Cdx), 5.0, dtype=TD[dt], device=dev())
+        ops.conv(dy, wt, None, dx, g, dt, res=res)
+        torch.cuda.synchronize()
+        outs.append(dx)
+    monkeypatch.delenv("C2W_TS2_PAIRS")
+    ops.knobs_reload()
+    assert outs[0].float().abs().sum().item() > 0 and torch.equal(outs[0], outs[1]), name
+    ref = torch.empty_like(outs[0])
+    E.conv(dy, wt, None, ref, g, dt, res=res)
+    close(outs[0], ref, TOL[dt], name)
