@@ -1022,7 +1022,16 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const C2wConv
 }
 
 // at most one workgroup per CU: the eight-wave form (two waves per SIMD instead of one)
-static inline bool half8_wanted(long long wgs) { return c2w_knobs().half8 && wgs <= 256; }
+// Which 8x16-tile launches take the eight-wave form.  At most one workgroup per CU: always worth it (two waves per SIMD instead of one).  Above
+// that the two forms are within 0.1 ms per step of each other (profiles/r06t_ab_half8_max_wgs_*.txt: B = 128 46.40-46.46 ms with every launch
+// on eight waves against 46.47-46.58 with the 256-workgroup limit; B = 64 and the sampler: equal) -- the 16-bit builds fit two
+// workgroups per CU (114-125 registers), so they take it everywhere; the fp32 builds (131-132 registers: one workgroup per CU) only
+// where there is one per CU anyway.  C2W_HALF8_MAX_WGS=N overrides.
+template <typename T>
+static inline bool half8_wanted(long long wgs) {
+    const int lim = c2w_knobs().half8_max_wgs;
+    return c2w_knobs().half8 && (lim > 0 ? wgs <= lim : (sizeof(T) == 2 || wgs <= 256));
+}
 
 template <typename T, bool PAIR, bool SPLITK>
 int launch_half8(const C2wConvArgs& a, int nwg, hipStream_t st) {
@@ -1043,7 +1052,7 @@ int launch_splitk(const C2wConvArgs& a, int ntiles, hipStream_t st) {
         attr = true;
     }
     int rc;
-    if (half8_wanted((long long)ntiles * a.splitk)) {
+    if (half8_wanted<T>((long long)ntiles * a.splitk)) {
         rc = launch_half8<T, PAIR, true>(a, ntiles * a.splitk, st);
     } else {
         conv_patch_half_kernel<T, PAIR, true><<<ntiles * a.splitk, H_NTHR, H_LDS, st>>>(a);
@@ -1066,7 +1075,7 @@ int launch(const C2wConvArgs& a, hipStream_t st) {  // two 8x16-tile workgroups 
     const int nN = (a.Cout + 127) / 128;
     const int nMh = a.B * (a.Hout >> 3) * (a.Wout >> 4);
     if (a.splitk > 1) return launch_splitk<T, false>(a, nMh * nN, st);
-    if (half8_wanted((long long)nMh * nN)) return launch_half8<T, false, false>(a, nMh * nN, st);
+    if (half8_wanted<T>((long long)nMh * nN)) return launch_half8<T, false, false>(a, nMh * nN, st);
     conv_patch_half_kernel<T><<<nMh * nN, H_NTHR, H_LDS, st>>>(a);
     return (int)hipGetLastError();
 }
@@ -1084,7 +1093,7 @@ int launch_pair(const C2wConvArgs& a, hipStream_t st) {
     const int nN = (a.Cout + 127) / 128;
     const int nM = ((a.B + 1) >> 1) * (a.Hin >> 3);
     if (a.splitk > 1) return launch_splitk<T, true>(a, nM * nN, st);
-    if (half8_wanted((long long)nM * nN)) return launch_half8<T, true, false>(a, nM * nN, st);
+    if (half8_wanted<T>((long long)nM * nN)) return launch_half8<T, true, false>(a, nM * nN, st);
     conv_patch_half_kernel<T, true><<<nM * nN, H_NTHR, H_LDS, st>>>(a);
     return (int)hipGetLastError();
 }
