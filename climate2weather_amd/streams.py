@@ -32,7 +32,7 @@ def overtakes(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = N
     return yes >= need
 
 
-_SPIN_MS = [None]  # measured once: milliseconds one _PROBE_CYCLES / 4 spin kernel takes on this chip
+_SPIN_MS: dict = {}  # device index -> milliseconds one _PROBE_CYCLES / 4 spin kernel takes on that chip (measured once)
 
 
 def _overtakes_once(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream"] = None) -> bool:
@@ -50,7 +50,8 @@ def _overtakes_once(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream
         torch.cuda._sleep(1000)
     main.synchronize()
     side.synchronize()
-    if _SPIN_MS[0] is None:
+    dkey = side.device.index
+    if dkey not in _SPIN_MS:
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(main):
             torch.cuda._sleep(cyc)  # (the first spin kernel of a process also loads its code object)
@@ -58,7 +59,7 @@ def _overtakes_once(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream
             torch.cuda._sleep(cyc)
             c1.record(main)
         main.synchronize()
-        _SPIN_MS[0] = c0.elapsed_time(c1)
+        _SPIN_MS[dkey] = c0.elapsed_time(c1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(main):
         e0.record(main)
@@ -71,7 +72,7 @@ def _overtakes_once(side: "torch.cuda.Stream", main: Optional["torch.cuda.Stream
         e1.record(main)
     main.synchronize()
     side.synchronize()
-    return e0.elapsed_time(e1) < 2.5 * _SPIN_MS[0]
+    return e0.elapsed_time(e1) < 2.5 * _SPIN_MS[dkey]
 
 
 def independent_stream(device, avoid=(), tries: int = 8, priority: int = 0) -> "torch.cuda.Stream":
