@@ -2,7 +2,7 @@
 # Round 6: every GPU call of the round as one stage of this script (one gpurun call each; output under gpurun_out/r06<stage>/, the files kept
 # for the record are copies under profiles/ -- profiles/README.md and profiles/r06_experiments.md say which).  The closing evidence of the
 # round (suite in both stream modes, step table, PMC passes, module-API legs, full bench line) is tools/run_prof_r06.sh.
-#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake
+#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 
 stage_a() {
@@ -361,6 +361,17 @@ done
 echo "whole tests/test_gpu_e2e.py, fresh process each time: $fail failures in ${N:-24} runs" | tee $O/flake_summary.txt
 ls gpurun_out/parity_fail* 2>/dev/null | tee -a $O/flake_summary.txt
 cp gpurun_out/parity_fail* $O/ 2>/dev/null
+}
+
+stage_z() {
+# last call of the round: the GPU suite at HEAD in both stream modes (Python-side changes after the closing evidence: the stream probe's
+# per-device calibration), smoke() and the default bench line as the driver runs them
+O=gpurun_out/r06z
+mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider > $O/gpu_tests_full.txt 2>&1; tail -4 $O/gpu_tests_full.txt > $O/gpu_tests_tail.txt; tail -1 $O/gpu_tests_tail.txt
+C2W_WGRAD_STREAM=1 timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider > $O/gpu_tests_two_streams_full.txt 2>&1; tail -4 $O/gpu_tests_two_streams_full.txt > $O/gpu_tests_tail_two_streams.txt; tail -1 $O/gpu_tests_tail_two_streams.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+timeout 1500 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 400 $O/bench_line.json
 }
 
 st=${1:?stage}; shift
