@@ -371,6 +371,7 @@ C2wKnobs read_knobs() {
     k.ln_chain = getenv("C2W_NO_LN_CHAIN") == nullptr;
     k.splitk = getenv("C2W_NO_SPLITK") == nullptr;
     k.half8 = getenv("C2W_NO_HALF8") == nullptr;
+    k.half8_db = !(getenv("C2W_HALF8_DB") && atoi(getenv("C2W_HALF8_DB")) == 0);
     k.half8_max_wgs = getenv("C2W_HALF8_MAX_WGS") && atoi(getenv("C2W_HALF8_MAX_WGS")) > 0 ? atoi(getenv("C2W_HALF8_MAX_WGS")) : 0;
     k.conv_t3_min_wgs = getenv("C2W_CONV_T3_MIN_WGS") && atoi(getenv("C2W_CONV_T3_MIN_WGS")) > 0 ? atoi(getenv("C2W_CONV_T3_MIN_WGS")) : 512;
     k.attn_valu = getenv("C2W_ATTN_VALU") != nullptr;

@@ -22,6 +22,7 @@ struct C2wKnobs {
     bool ln_chain;        // C2W_NO_LN_CHAIN=1    c2w_conv_lnfwd_chain_supported answers 0 (every residual block writes its output)
     int half8_max_wgs;    // C2W_HALF8_MAX_WGS=N  launches of up to N workgroups take the eight-wave 8x16-tile kernel (default 0 = automatic: every 16-bit launch, fp32 up to 256)
     bool half8;           // C2W_NO_HALF8=1       every 8x16-tile launch on the 4-wave kernel (rounds 1-5)
+    bool half8_db;        // C2W_HALF8_DB=0       eight-wave launches of at most 256 workgroups with ONE patch buffer (an exposed patch load per K chunk)
     bool splitk;          // C2W_NO_SPLITK=1      c2w_conv_splitk_plan answers 1 (no convolution splits its K chunks over workgroups)
     int conv_t3_min_wgs;  // C2W_CONV_T3_MIN_WGS=N  workgroups from which the 16x16-tile conv kernel replaces the 8x16 one (default 512 = one round of two workgroups per CU; 1024 in rounds 1-5)
     int wgrad_wgs;        // C2W_WGRAD_WGS=N      workgroups a halo-patch weight-gradient launch splits its K range into (default 256: one per CU)

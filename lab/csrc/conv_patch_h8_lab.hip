@@ -1,3 +1,6 @@
+#ifndef C2W_H8_EXP
+#define C2W_H8_EXP 0
+#endif
 // Halo-patch implicit GEMM for the 3x3 stride-1 convolutions (the 60 res-block convs and their input gradients:
 // 98.8 of the 116 GFLOP forward, model/nn.py:155,157) on gfx950 -- the 8x16-pixel-tile kernels: fp32 mode, 16-bit launches below
 // 1024 workgroups of the 16x16-tile kernel (conv_patch3.hip), 8-pixel-wide images (two per tile) and the stride-2 input gradient
@@ -270,39 +273,24 @@ __global__ __launch_bounds__(H_NTHR, 2) void conv_patch_half_kernel(const C2wCon
 // stage one after the other: 0.55 us per stage where the matrix work is 0.25 (512 -> 512 @8x8 at B = 128: 256 workgroups, 0.31 of peak;
 // the deep levels of a sampler step on a short trajectory: 76-228).  Eight waves = 2 (channel halves) x 4 (pixel-row pairs), wave tile
 // 64 co x 32 px = 32 accumulator registers, two waves per SIMD: one's waits are the other's MFMAs.  Same LDS plan, same weight ring
-// (two 1-KiB pieces per wave and stage: counted vmcnt), same patch, same epilogues (EpiStore<T, 128, 512>).
-//
-// What a stage is made of (ablation builds, profiles/r06u_ab_h8_stage_ablation.txt, 512 -> 512 @8x8, B = 128: 39.5 us; launch + prologue +
-// epilogue + the eight exposed patch loads 11): MFMAs + barriers alone 27.3 us, fragment reads + barriers alone 27.7, weight LDS-DMA +
-// barriers alone 27.1 -- three chains of about the same length, 16 us each, that overlapped to 28.  Two changes came out of it:
-//   * the stage's two weight pieces are issued BETWEEN its two MFMA groups, not right behind the barrier: an LDS-DMA piece takes the wave
-//     ~100 issue cycles, and behind the barrier both waves of a SIMD pay them at the same time with the matrix pipe idle; behind the first
-//     group they run beside its eight MFMAs.  -12 ... -15 % at the 8x8 level, -3 ... -5 % at 16x16 (r06v_ab_h8_p32_db.txt; results
-//     bit-identical; in the middle of a group or behind the second one it is worth half of that or nothing);
-//   * DB (launches of at most 256 workgroups: one per CU whatever the LDS size): a SECOND patch buffer behind the weight ring (110,592 B).
-//     The next chunk's patch is issued behind stage 0's weight pieces and may stay in flight until the wait of stage 3 (vmcnt(6) at stages
-//     1 and 2: the pieces older than it are the ones those waits are for), instead of one exposed vmcnt(0) + barrier per chunk: a further
-//     -5 ... -7 %.  (Round 6's earlier attempt at this -- two patch buffers AND a five-slot weight ring, ten loads in flight -- was 6 us
-//     slower than the plain kernel; section 10 of profiles/r06_experiments.md.)
+// (two 1-KiB pieces per wave and stage: counted vmcnt(2)), same patch, same epilogues (EpiStore<T, 128, 512>).
 constexpr int H8_NTHR = 512;
-constexpr int H8_LDS_DB = H_LDS + H_PBYTES;  // 110,592
-__device__ __forceinline__ void wait_vm_h8(int n) {  // wave-uniform n in {0, 2, 4, 6}
-    if (n == 6) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (n == 4) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else if (n == 2) {
+// (A version with TWO patch buffers -- the next chunk's patch fetched during the current one -- and a five-slot weight ring filled four
+// stages ahead, 143 KB of LDS, was 6 us per launch SLOWER than this one at 512 -> 512 @8x8: 47.7 against 41.9 us, the 4-wave kernel 44.7;
+// whatever bounds these launches, it is not the distance of the prefetch.  profiles/r06_experiments.md section 11.)
+__device__ __forceinline__ void wait_vm2(int n) {  // wave-uniform n in {0, 2}
+    if (n == 2) {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
-template <typename T, bool PAIR = false, bool SPLITK = false, bool DB = false>
-__global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(const C2wConvArgs p) {
+template <typename T, bool PAIR = false, bool SPLITK = false>
+__global__ __launch_bounds__(H8_NTHR, 2) void conv_patch_half8_kernel(const C2wConvArgs p) {
     constexpr int ESZ = sizeof(T);
     constexpr int CK = 128 / ESZ;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [patch | W0 | W1 | W2 | DB: second patch]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [patch | W0 | W1 | W2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -366,9 +354,9 @@ __global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(c
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(rw, smem + H_PBYTES + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
     };
-    auto issue_patch = [&](int chunk, uint32_t pbase) {
+    auto issue_patch = [&](int chunk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) glds16(rx, smem + pbase + pdst[r], pvo[r], (uint32_t)chunk * 128u);
+        for (int r = 0; r < 4; ++r) glds16(rx, smem + pdst[r], pvo[r], (uint32_t)chunk * 128u);
     };
 
     // fragment addresses as in conv_patch_ts2_pair: A row m = + m * 2048, patch row n = + n * PW * 128 (immediates), second K half = ^ 64
@@ -385,59 +373,90 @@ __global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(c
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    issue_patch(c_lo, 0);
+    issue_patch(c_lo);
     issue_w(c_lo, 0, 0);
     issue_w(c_lo, 1, 1);
     int np = 2;  // LDS-DMA pieces of the next stage that may still be in flight
-    u32x4_t da[4] = {}, dq[2] = {};
-    const int c_hi = c_lo + nchunk;
+    u32x4_t da[4] = {}, db[2] = {};
 
     auto stage = [&](auto TAPc, int c) {
         constexpr int TAP = decltype(TAPc)::value;
         constexpr int KH = TAP / 3, KW = TAP % 3, WS = TAP % 3, T2 = (TAP + 2) % 9;
+        constexpr int X = C2W_H8_EXP;
         const int s = (c - c_lo) * 9 + TAP;
-        const bool pnext = DB && c + 1 < c_hi;  // this chunk fetches the next one's patch into the other buffer (stage 0, behind the weights)
-        const uint32_t pb = DB && ((c - c_lo) & 1) ? (uint32_t)H_LDS : 0u;
-        // the weights of this stage were issued two stages ago; younger than them: the previous stage's pieces (np) and, at stages 1 and 2
-        // of a chunk, the four patch pieces issued behind stage 0's
-        wait_vm_h8(np + ((TAP == 1 || TAP == 2) && pnext ? 4 : 0));
-        __builtin_amdgcn_s_barrier();
-        if (!DB && TAP == 0 && c > c_lo) {  // single patch buffer: every wave is past the previous chunk only now
-            issue_patch(c, 0);
+        wait_vm2(np);
+        if constexpr (!(X & 8)) __builtin_amdgcn_s_barrier();
+        if (TAP == 0 && c > c_lo) {
+            issue_patch(c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(X & 8)) __builtin_amdgcn_s_barrier();
         }
         np = 0;
+        const bool ahead = s + 2 < NS;
+        auto issue_piece = [&](int i) {
+            if constexpr (!(X & 1)) {
+                const uint32_t so = (uint32_t)(T2 * p.Cin + (TAP + 2 >= 9 ? c + 1 : c) * CK) * ESZ;
+                glds16(rw, smem + H_PBYTES + ((TAP + 2) % 3) * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
+            }
+        };
+        auto issue_now = [&](int lo, int hi) {
+            if (ahead) {
+                __builtin_amdgcn_sched_barrier(0);
+                for (int i = lo; i < hi; ++i) issue_piece(i);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(X & 1)) np = 2;
+            }
+        };
+        constexpr int PLACE = X & (16 | 32 | 64 | 128);
+        if (PLACE == 0 || s == 0) issue_now(0, 2);
+        else if (PLACE == 128) issue_now(0, 1);
         u32x4_t a0[4], b0[2];
+        if constexpr (!(X & 2)) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA0 + WS * WBYTES + m * 2048);
+            for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA0 + WS * WBYTES + m * 2048);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) b0[n] = *(const u32x4_t*)(smem + pb + preB0[KW] + n * (PW * 128) + KH * PROW);
+            for (int n = 0; n < 2; ++n) b0[n] = *(const u32x4_t*)(smem + preB0[KW] + n * (PW * 128) + KH * PROW);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a0[m] = da[m];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b0[n] = db[n];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s > 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                if (PLACE == 16 && m == 2) issue_now(0, 2);
+                if constexpr (!(X & 4)) {
 #pragma unroll
-                for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], dq[n], acc[m][n]);
+                    for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
+                } else {
+                    asm volatile("" ::"v"(da[m]), "v"(db[0]), "v"(db[1]));
+                }
+            }
+            if (PLACE == 32) issue_now(0, 2);
+            if (PLACE == 128) issue_now(1, 2);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < NS) {  // the weight pieces of stage s + 2 (the slot read in stage s - 1: every wave is behind this stage's barrier)
-            issue_w(TAP + 2 >= 9 ? c + 1 : c, T2, (TAP + 2) % 3);
-            np = 2;
+        if constexpr (!(X & 2)) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + WS * WBYTES + m * 2048);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) db[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
         }
-        if (TAP == 0 && pnext) issue_patch(c + 1, pb ? 0u : (uint32_t)H_LDS);  // the buffer chunk c - 1 was read from
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + WS * WBYTES + m * 2048);
+        for (int m = 0; m < 4; ++m) {
+            if (PLACE == 64 && m == 2 && s > 0) issue_now(0, 2);
+            if constexpr (!(X & 4)) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) dq[n] = *(const u32x4_t*)(smem + pb + (preB0[KW] ^ 64u) + n * (PW * 128) + KH * PROW);
+                for (int n = 0; n < 2; ++n) Mma<T>::run(a0[m], b0[n], acc[m][n]);
+            } else {
+                asm volatile("" ::"v"(a0[m]), "v"(b0[0]), "v"(b0[1]));
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) Mma<T>::run(a0[m], b0[n], acc[m][n]);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 #pragma unroll 1
     for (int c = c_lo; c < c_lo + nchunk; ++c) {
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(c
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], dq[n], acc[m][n]);
+        for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], db[n], acc[m][n]);
 
     if constexpr (SPLITK) {
         float* const dst = p.splitk_ws + ((size_t)sp * (gridDim.x / nsplit) + Lt) * (128 * 128);
@@ -1055,22 +1074,15 @@ static inline bool half8_wanted(long long wgs) {
     return c2w_knobs().half8 && (lim > 0 ? wgs <= lim : (sizeof(T) == 2 || wgs <= 256));
 }
 
-template <typename T, bool PAIR, bool SPLITK, bool DB>
-int launch_half8_db(const C2wConvArgs& a, int nwg, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half8_kernel<T, PAIR, SPLITK, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-        attr = true;
-    }
-    conv_patch_half8_kernel<T, PAIR, SPLITK, DB><<<nwg, H8_NTHR, DB ? H8_LDS_DB : H_LDS, st>>>(a);
-    return (int)hipGetLastError();
-}
-
-// one workgroup per CU at most: the second patch buffer costs nothing (C2W_HALF8_DB=0: never)
 template <typename T, bool PAIR, bool SPLITK>
 int launch_half8(const C2wConvArgs& a, int nwg, hipStream_t st) {
-    if (nwg <= 256 && c2w_knobs().half8_db) return launch_half8_db<T, PAIR, SPLITK, true>(a, nwg, st);
-    return launch_half8_db<T, PAIR, SPLITK, false>(a, nwg, st);
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_half8_kernel<T, PAIR, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr = true;
+    }
+    conv_patch_half8_kernel<T, PAIR, SPLITK><<<nwg, H8_NTHR, H_LDS, st>>>(a);
+    return (int)hipGetLastError();
 }
 
 template <typename T, bool PAIR>

@@ -794,12 +794,15 @@ def test_split_k_plan_leaves_filled_launches_alone():
 @pytest.mark.parametrize("dt", [BF16, F16, F32])
 @pytest.mark.parametrize("case", [("512->512 @8x8 paired, B = 128: 256 workgroups", 128, 8, 512, 512),
                                   ("384->384 @16x16, B = 32: 192 workgroups", 32, 16, 384, 384),
-                                  ("256->256 @32x32, B = 4: 64 workgroups, residual + multiplier", 4, 32, 256, 256)],
-                         ids=["pair", "16x16", "32x32"])
+                                  ("256->256 @32x32, B = 4: 64 workgroups, residual + multiplier", 4, 32, 256, 256),
+                                  ("384->384 @16x16, B = 96: 576 workgroups (one patch buffer, two workgroups per CU)", 96, 16, 384, 384),
+                                  ("1024->512 @8x8 paired, B = 24: 48 workgroups, sixteen K chunks", 24, 8, 1024, 512)],
+                         ids=["pair", "16x16", "32x32", "16x16-576wg", "pair-16chunks"])
 def test_eight_wave_tile_kernel_gives_the_four_wave_kernels_bits(case, dt, monkeypatch):
     """Round 6, conv_patch_half8_kernel (launches of at most one workgroup per CU): the same tile, the same K order per output element
     (chunks, taps, the two K halves of a stage) on eight waves instead of four -- every output bit for bit what C2W_NO_HALF8=1 gives,
-    over the epilogue flavours the 8x16-tile kernels carry (bias + SiLU pair, multiplier + residual, plain) and the split-K form."""
+    over the epilogue flavours the 8x16-tile kernels carry (bias + SiLU pair, multiplier + residual, plain) and the split-K form; and
+    the same bits with one patch buffer (C2W_HALF8_DB=0) as with the two that launches of at most 256 workgroups get by default."""
     name, B, H, Cin, Cout = case
     if dt == F32:
         Cin = Cin // 2
@@ -811,8 +814,11 @@ def test_eight_wave_tile_kernel_gives_the_four_wave_kernels_bits(case, dt, monke
     bias = rnd((Cout,), F32, 3)
     res, mul = rnd((npix, Cout), dt, 4), rnd((npix, Cout), dt, 5)
     outs = {}
-    for half8 in (True, False):
+    for half8 in (True, "one patch buffer", False):
+        if half8 == "one patch buffer":
+            monkeypatch.setenv("C2W_HALF8_DB", "0")
         if not half8:
+            monkeypatch.delenv("C2W_HALF8_DB")
             monkeypatch.setenv("C2W_NO_HALF8", "1")
         ops.knobs_reload()
         got = []
@@ -835,9 +841,9 @@ def test_eight_wave_tile_kernel_gives_the_four_wave_kernels_bits(case, dt, monke
         outs[half8] = got
     monkeypatch.delenv("C2W_NO_HALF8")
     ops.knobs_reload()
-    assert len(outs[True]) == len(outs[False])
-    for i, (a, b_) in enumerate(zip(outs[True], outs[False])):
-        assert a.float().abs().sum().item() > 0 and torch.equal(a, b_), (name, i)
+    assert len(outs[True]) == len(outs[False]) == len(outs["one patch buffer"])
+    for i, (a, a1, b_) in enumerate(zip(outs[True], outs["one patch buffer"], outs[False])):
+        assert a.float().abs().sum().item() > 0 and torch.equal(a, b_) and torch.equal(a1, b_), (name, i)
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])

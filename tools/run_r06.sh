@@ -2,7 +2,7 @@
 # Round 6: every GPU call of the round as one stage of this script (one gpurun call each; output under gpurun_out/r06<stage>/, the files kept
 # for the record are copies under profiles/ -- profiles/README.md and profiles/r06_experiments.md say which).  The closing evidence of the
 # round (suite in both stream modes, step table, PMC passes, module-API legs, full bench line) is tools/run_prof_r06.sh.
-#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z
+#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z h8x h8y v t3p
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 
 stage_a() {
@@ -361,6 +361,80 @@ done
 echo "whole tests/test_gpu_e2e.py, fresh process each time: $fail failures in ${N:-24} runs" | tee $O/flake_summary.txt
 ls gpurun_out/parity_fail* 2>/dev/null | tee -a $O/flake_summary.txt
 cp gpurun_out/parity_fail* $O/ 2>/dev/null
+}
+
+stage_h8x() {
+# ablation builds of the eight-wave 8x16-tile kernel's stage (lab/h8/make_variants.py; libraries under climate2weather_amd/build/alt/):
+# which of weight LDS-DMA / fragment reads / MFMAs / barriers the ~1200 cycles of a stage are made of, and four other places for the DMA issue
+O=gpurun_out/r06h8x
+mkdir -p $O
+L=""
+for v in ${H8_VARIANTS:-0 1 2 4 8 3 5 6 7 11 16 32 64 128}; do L="$L climate2weather_amd/build/alt/libc2w_h8_$v.so"; done
+for b in 128 16 38; do
+  echo "== B=$b" >> $O/ab_h8_variants.txt
+  B=$b SHAPES=4 ROUNDS=9 timeout 600 python tools/ab_conv.py $L >> $O/ab_h8_variants.txt 2>&1
+done
+echo "== B=128, 16x16 levels" >> $O/ab_h8_variants.txt
+B=128 SHAPES=3,7 ROUNDS=7 timeout 600 python tools/ab_conv.py $L >> $O/ab_h8_variants.txt 2>&1
+tail -80 $O/ab_h8_variants.txt
+}
+
+stage_h8y() {
+# second lab A/B of the eight-wave kernel: weight pieces between the MFMA groups (p32), plus a second patch buffer at <= 256 workgroups (db)
+O=gpurun_out/r06h8y
+mkdir -p $O
+L=""
+for v in ${H8_VARIANTS:-0 p32 db}; do L="$L climate2weather_amd/build/alt/libc2w_h8_$v.so"; done
+for b in 128 64 38 16; do
+  echo "== B=$b" >> $O/ab_h8_variants2.txt
+  B=$b SHAPES=4 ROUNDS=9 timeout 600 python tools/ab_conv.py $L >> $O/ab_h8_variants2.txt 2>&1
+  B=$b SHAPE=1,8,1024,512 ROUNDS=9 timeout 600 python tools/ab_conv.py $L >> $O/ab_h8_variants2.txt 2>&1
+done
+echo "== B=128, 16x16 levels; B=38 16x16" >> $O/ab_h8_variants2.txt
+B=128 SHAPES=3,7 ROUNDS=7 timeout 600 python tools/ab_conv.py $L >> $O/ab_h8_variants2.txt 2>&1
+B=38 SHAPES=3 ROUNDS=7 timeout 600 python tools/ab_conv.py $L >> $O/ab_h8_variants2.txt 2>&1
+grep -v amdgpu.ids $O/ab_h8_variants2.txt | tail -80
+}
+
+stage_v() {
+# the eight-wave kernel with its weight pieces between the MFMA groups and the second patch buffer (<= 256 workgroups), in the product
+# library: conv + dispatch tests, then same-call A/Bs against the previous kernels (C2W_LIB = the lab build of the old conv_patch.hip) and
+# against one patch buffer (C2W_HALF8_DB=0): training step B = 128 / B = 64, one member at L = 49 / 121
+O=gpurun_out/r06v
+mkdir -p $O
+timeout 1200 python -m pytest tests/test_gpu_bench_dispatch.py tests/test_gpu_kernels.py tests/test_gpu_e2e.py -m gpu -q -x -p no:cacheprovider > $O/gpu_tests_conv.txt 2>&1
+tail -3 $O/gpu_tests_conv.txt | cut -c1-300
+OLD=climate2weather_amd/build/alt/libc2w_h8_0.so
+J='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["step_ms"]["median"], d["final_loss"])'
+for bs in 128 64; do
+  B="python3 bench.py --steps 20 --warmup 5 --batch $bs --no-cpu-baseline --no-extras"
+  for rep in 1 2 3; do
+    echo "B=$bs new rep $rep: $(timeout 300 $B 2>/dev/null | python3 -c "$J")"
+    echo "B=$bs one patch buffer rep $rep: $(C2W_HALF8_DB=0 timeout 300 $B 2>/dev/null | python3 -c "$J")"
+    echo "B=$bs old kernels rep $rep: $(C2W_LIB=$OLD timeout 300 $B 2>/dev/null | python3 -c "$J")"
+  done
+done | tee $O/ab_step.txt
+for rep in 1 2 3; do
+  echo "new rep $rep: $(timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+  echo "one patch buffer rep $rep: $(C2W_HALF8_DB=0 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+  echo "old kernels rep $rep: $(C2W_LIB=$OLD timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+done | tee $O/ab_sampler.txt
+}
+
+stage_t3p() {
+# lab A/B of the 16x16-tile kernel: the stage's weight piece behind the first 2 / 4 / 6 pixel columns (8 / 16 / 24 of 32 MFMAs) of its MFMA
+# group instead of right behind the barrier (lab/h8/make_t3_variants.py)
+O=gpurun_out/r06t3p
+mkdir -p $O
+L=""
+for v in 0 2 4 6; do L="$L climate2weather_amd/build/alt/libc2w_t3p_$v.so"; done
+for act in 0 1; do
+  echo "== ACT=$act" >> $O/ab_t3_place.txt
+  ACT=$act B=128 SHAPES=0,1,2 ROUNDS=7 timeout 900 python tools/ab_conv.py $L >> $O/ab_t3_place.txt 2>&1
+done
+echo "== B=37 (one member at L = 49)" >> $O/ab_t3_place.txt
+ACT=1 B=37 SHAPES=0,1 ROUNDS=7 timeout 900 python tools/ab_conv.py $L >> $O/ab_t3_place.txt 2>&1
+grep -v amdgpu.ids $O/ab_t3_place.txt | tail -60
 }
 
 stage_z() {
