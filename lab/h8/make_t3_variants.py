@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Lab builds of conv_patch_t3_kernel with the stage's weight piece issued behind the first C2W_T3_PLACE pixel columns of its MFMA group
-(each column = 4 MFMAs; 0 = right behind the barrier, the product schedule).  python lab/h8/make_t3_variants.py 0 2 4 6"""
+(each column = 4 MFMAs; 0 = right behind the barrier, the product schedule).  python lab/h8/make_t3_variants.py 0 2 4 6
+STATE: a record; patches the product conv_patch3.hip by text (applies as long as the stage's `issue_ahead` / `mfmas` hook lines are unchanged); the generated
+lab source is not tracked."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(root, "climate2weather_amd/csrc/conv_patch3.hip")).read()

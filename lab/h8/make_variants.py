@@ -11,7 +11,9 @@ replaced by one that takes -DC2W_H8_EXP=<bits>:
     64  ... behind the first 4 MFMAs of the second group                                                        (correct)
     128 one piece behind the barrier, the other behind the first MFMA group                                     (correct)
 and compiles + links one library per variant into climate2weather_amd/build/alt/libc2w_h8_<bits>.so (other objects: the product build).
-    python lab/h8/make_variants.py 0 1 2 4 8 16 32 64 128"""
+    python lab/h8/make_variants.py 0 1 2 4 8 16 32 64 128
+STATE: a record. The script patches the PRODUCT source by text; it applies to csrc/ as of commit d0ee3af (`git worktree add /tmp/w d0ee3af`, run it there).
+The product kernel has since taken over variants 32 / db, so the text it looks for is gone from HEAD; the generated lab sources are not tracked."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(root, "climate2weather_amd/csrc/conv_patch.hip")).read()

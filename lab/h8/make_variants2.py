@@ -3,7 +3,9 @@
 32 of make_variants.py: -11 % at 512 -> 512 @8x8) plus, with -DC2W_H8_DB=1, a SECOND patch buffer for launches of at most 256 workgroups
 (one per CU anyway: 110,592 B of LDS): the next chunk's patch is issued behind stage 0's weight pieces and may stay in flight until the
 wait of stage 3 (counted vmcnt(6) at stages 1 and 2), instead of one exposed vmcnt(0) + barrier per chunk.
-    python lab/h8/make_variants2.py p32 db      -> climate2weather_amd/build/alt/libc2w_h8_{p32,db}.so"""
+    python lab/h8/make_variants2.py p32 db      -> climate2weather_amd/build/alt/libc2w_h8_{p32,db}.so
+STATE: a record. The script patches the PRODUCT source by text; it applies to csrc/ as of commit d0ee3af (`git worktree add /tmp/w d0ee3af`, run it there).
+The product kernel has since taken over variants 32 / db, so the text it looks for is gone from HEAD; the generated lab sources are not tracked."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(root, "climate2weather_amd/csrc/conv_patch.hip")).read()
