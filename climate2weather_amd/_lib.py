@@ -16,7 +16,7 @@ CONV_1X1, CONV_S1, CONV_S2, CONV_UP, CONV_TS2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_SILU_PAIR, ACT_RELU, ACT_RELU_PAIR = 0, 1, 2, 3, 4
 MUL_PLAIN, MUL_DSILU = 0, 1
 CONV_POOL2, CONV_WPACKED, CONV_NO_Y = 1, 2, 4  # ConvArgs.flags (bit set)
-KERNEL_GATHER, KERNEL_PATCH_8X16, KERNEL_PATCH_16X16, KERNEL_PATCH_PAIR, KERNEL_PATCH_TS2 = 0, 1, 2, 3, 4  # c2w_conv_dispatch
+KERNEL_GATHER, KERNEL_PATCH_8X16, KERNEL_PATCH_16X16, KERNEL_PATCH_PAIR, KERNEL_PATCH_TS2, KERNEL_PATCH_S2 = 0, 1, 2, 3, 4, 5  # c2w_conv_dispatch
 
 
 class C2wError(RuntimeError):

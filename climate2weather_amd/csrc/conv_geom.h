@@ -36,6 +36,9 @@ __device__ __forceinline__ int fast_div(int n, FastDiv d) { return d.magic ? (in
 // halo-patch kernel for 3x3 stride-1 convolutions on 16x16-tileable images (conv_patch.hip)
 bool c2w_conv_patch_eligible(const C2wConvArgs& a);
 int c2w_conv_patch_s1(const C2wConvArgs& a, int dtype, hipStream_t st);
+// stride-2 forward on the parity planes of the halo patch (conv_patch.hip; 16-bit)
+bool c2w_conv_s2_patch_eligible(const C2wConvArgs& a, int dtype);
+int c2w_conv_patch_s2(const C2wConvArgs& a, int dtype, hipStream_t st);
 // stride-2 input gradient per output-parity class on the halo patch (conv_patch.hip)
 bool c2w_conv_ts2_patch_eligible(const C2wConvArgs& a);
 int c2w_conv_patch_ts2(const C2wConvArgs& a, int dtype, hipStream_t st);

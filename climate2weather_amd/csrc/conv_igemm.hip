@@ -357,6 +357,7 @@ C2wKnobs read_knobs() {
     k.conv_t3 = getenv("C2W_CONV_T3") ? atoi(getenv("C2W_CONV_T3")) : -1;
     k.conv_pair = !off0("C2W_CONV_PAIR");
     k.conv_ts2_patch = !off0("C2W_CONV_TS2_PATCH");
+    k.conv_s2_patch = getenv("C2W_CONV_S2_PATCH") ? atoi(getenv("C2W_CONV_S2_PATCH")) : 1;
     k.ts2_one_launch = getenv("C2W_TS2_FOUR_LAUNCHES") == nullptr;
     k.ts2_pairs = !off0("C2W_TS2_PAIRS");
     k.up_patch = getenv("C2W_NO_UP_PATCH") == nullptr;
@@ -441,6 +442,7 @@ extern "C" int c2w_conv_dispatch(const C2wConvArgs* a, int dtype) {
     if (!gather && c2w_conv_patch_eligible(*a)) return c2w_conv_patch3_wanted(*a, dtype) ? C2W_KERNEL_PATCH_16X16 : C2W_KERNEL_PATCH_8X16;
     if (!gather && c2w_conv_pair_eligible(*a)) return C2W_KERNEL_PATCH_PAIR;
     if (!gather && c2w_conv_ts2_patch_eligible(*a)) return C2W_KERNEL_PATCH_TS2;
+    if (!gather && c2w_conv_s2_patch_eligible(*a, dtype)) return C2W_KERNEL_PATCH_S2;
     return C2W_KERNEL_GATHER;
 }
 
@@ -475,6 +477,7 @@ extern "C" int c2w_conv_forward(const C2wConvArgs* a, int dtype, int naive, void
     if (patch && c2w_conv_patch_eligible(*a)) return c2w_conv_patch_s1(*a, dtype, st);
     if (patch && c2w_conv_pair_eligible(*a)) return c2w_conv_patch_pair(*a, dtype, st);
     if (patch && c2w_conv_ts2_patch_eligible(*a)) return c2w_conv_patch_ts2(*a, dtype, st);
+    if (patch && c2w_conv_s2_patch_eligible(*a, dtype)) return c2w_conv_patch_s2(*a, dtype, st);
     if (naive == 2) naive = 0;  // force the general gather kernel
     if (dtype == C2W_DTYPE_F32) return launch_dtype<float>(*a, naive, st);
     if (dtype == C2W_DTYPE_BF16) return launch_dtype<bf16_t>(*a, naive, st);

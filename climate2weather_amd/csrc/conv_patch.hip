@@ -486,6 +486,202 @@ __global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// FORWARD of the stride-2 convolutions (C2W_CONV_S2: the three down-convs whose output is at least 16 pixels wide, model/nn.py:169-174) on
+// the halo patch (round 6; 16-bit).  Output pixel (n, j) of an 8x16 output tile reads, for tap (kh, kw), input pixel (2n + kh, 2j + kw) of
+// the (17 x 33)-pixel patch whose origin is (2 oh0 - 1, 2 ow0 - 1).  The patch is staged as its four PARITY PLANES -- plane (p, q) holds
+// patch pixels (2a + p, 2b + q) -- so that tap (kh, kw) is a stride-1 view of plane (kh & 1, kw & 1) shifted by (kh >> 1, kw >> 1): every
+// fragment address is register + immediate as in the stride-1 kernels, and the LDS-DMA does the de-interleaving (a piece = 8 consecutive
+// plane pixels = 8 source pixels two apart; per-lane source offsets anyway).  Planes are packed (pitch 17 / 16 pixels, padded to whole
+// pieces): 160 + 136 + 144 + 128 pixels x 128 B = 72,704 B per 64-channel chunk, + the 3-slot weight ring = 121,856 B: one workgroup of
+// EIGHT waves per CU (the tile, the wave tiling, the stage body and the epilogue are conv_patch_half8_kernel's).
+// There is no room for a second patch, but the two ROW parities are not live at the same time: the taps run kh = 1, 0, 2; the odd patch
+// rows (planes (1, .): 8 rows, 34 KB) are read by the three kh = 1 stages only and the even ones (planes (0, .): 9 rows, 38 KB) by the six
+// others.  So the even rows of chunk c are fetched during ITS OWN kh = 1 stages (issued behind stage 0's weight pieces, needed at stage 3)
+// and the odd rows of chunk c + 1 during stages 3-5 (issued behind stage 3's weights, needed six stages later): five pieces per wave each
+// time, allowed in flight by counted vmcnt(7) at the two following stages -- no exposed patch load after the prologue.
+// Replaces the gather kernel (0.15-0.26 of peak on these launches: ~290 non-MFMA instructions per 32 MFMAs, each input pixel fetched 2.25
+// times).  The 16 -> 8 down-conv (8-pixel-wide output) and fp32 stay there.
+constexpr int S2_NP00 = 160, S2_NP10 = 136, S2_NP01 = 144, S2_NP11 = 128;  // plane pixels, padded to whole 8-pixel pieces (9x17, 8x17, 9x16, 8x16)
+constexpr int S2_B00 = 0, S2_B10 = S2_NP00 * 128;                           // column parity 0: [even rows | odd rows]
+constexpr int S2_B01 = (S2_NP00 + S2_NP10) * 128, S2_B11 = S2_B01 + S2_NP01 * 128;  // column parity 1
+constexpr int S2_PBYTES = S2_B11 + S2_NP11 * 128;                           // 72,704
+constexpr int S2_LDS = S2_PBYTES + 3 * WBYTES;                              // 121,856
+static_assert(128 * (128 * 2 + 16) + 512 <= S2_LDS, "output staging fits");
+
+__device__ __forceinline__ void wait_vm_s2(int n) {  // wave-uniform n in {0, 2, 5, 7}
+    if (n == 7) {
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else if (n == 5) {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else if (n == 2) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConvArgs p) {
+    constexpr int ESZ = sizeof(T);
+    static_assert(ESZ == 2, "16-bit operands");
+    constexpr int CK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [plane 00 | 10 | 01 | 11 | W0 | W1 | W2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm = wid & 1, wn = wid >> 1;  // wn: output rows 2 wn, 2 wn + 1 of the tile
+
+    const int nN = (p.Cout + 127) / 128;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = L % nN, tm = L / nN;
+    const int co0 = tn * 128;
+    const int H = p.Hout, W = p.Wout, Hi = p.Hin, Wi = p.Win;
+    const int tw = W >> 4, tpi = (H >> 3) * tw;
+    const int b = tm / tpi, tt = tm - b * tpi;
+    const int ty = tt / tw, tx = tt - ty * tw;
+    const int oh0 = ty << 3, ow0 = tx << 4;
+
+    const size_t img_bytes = (size_t)Hi * Wi * p.Cin * ESZ;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
+    const int nchunk = p.Cin / CK;
+    const int NS = nchunk * 9;
+
+    // patch pieces, five per wave and row parity rp (rp = 0: the 9 even patch rows = taps kh 0 / 2; rp = 1: the 8 odd ones = kh 1) (pieces past the end repeat the last one: the same bytes to the same place).
+    // Row parity rp: planes (rp, 0) then (rp, 1); piece pc of the set -> plane, local piece k; lane -> plane pixel i = 8 k + lane / 8 = (a, b_)
+    uint32_t pvo[2][5];
+    int pdst[2][5];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        const int n0 = (rp ? S2_NP10 : S2_NP00) >> 3, n1 = (rp ? S2_NP11 : S2_NP01) >> 3;  // pieces of the two planes: 20 + 18 / 17 + 16
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            int pc = r * 8 + wid;
+            pc = pc < n0 + n1 ? pc : n0 + n1 - 1;
+            const int cq = pc >= n0 ? 1 : 0;  // column parity of the piece's plane
+            const int k = pc - cq * n0;
+            const int pitch = cq ? 16 : 17, rows = rp ? 8 : 9;
+            const int i = k * 8 + (lane >> 3);
+            const int a = i / pitch, b_ = i - a * pitch;
+            const int ih = 2 * oh0 - 1 + 2 * a + rp, iw = 2 * ow0 - 1 + 2 * b_ + cq;
+            const bool ok = a < rows && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+            const uint32_t lc = (uint32_t)((lane & 7) ^ (b_ & 7));
+            pvo[rp][r] = ok ? (uint32_t)((ih * Wi + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
+            pdst[rp][r] = (rp ? (cq ? S2_B11 : S2_B10) : (cq ? S2_B01 : S2_B00)) + k * 1024;
+        }
+    }
+    uint32_t wvo[2];  // weight tile: 128 rows x 8 chunks = 2 rounds of 512 threads
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        wvo[i] = (uint32_t)(co0 + row) * (uint32_t)(9 * p.Cin * ESZ) + (uint32_t)(((tid & 7) ^ (row & 7)) << 4);
+    }
+    auto issue_w = [&](int chunk, int tap, int wslot) {
+        const uint32_t so = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rw, smem + S2_PBYTES + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
+    };
+    auto issue_rows = [&](auto RPc, int chunk) {  // the two planes of one row parity
+        constexpr int RP = decltype(RPc)::value;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) glds16(rx, smem + pdst[RP][r], pvo[RP][r], (uint32_t)chunk * 128u);
+    };
+
+    // fragment addresses: A row m = + m * 2048; B: per kw the column-parity region, the lane's plane column li + (kw >> 1) and the wave's
+    // first output row; row parity, row and the second output row are immediates; second K half = ^ 64
+    const uint32_t offA0 = (uint32_t)(S2_PBYTES + (wm * 64 + li) * 128 + ((lg ^ (li & 7)) << 4));
+    uint32_t preB0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int cq = kw & 1, b_ = li + (kw >> 1), pitch = cq ? 16 : 17;
+        preB0[kw] = (uint32_t)((cq ? S2_B01 : S2_B00) + (wn * 2 * pitch + b_) * 128 + ((lg ^ (b_ & 7)) << 4));
+    }
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // stage k of a chunk = tap (kh, kw) with kh = 1, 0, 2 for k / 3 = 0, 1, 2 and kw = k % 3; its weights live in ring slot k % 3
+    issue_rows(IC<1>{}, 0);  // odd patch rows: the kh = 1 taps
+    issue_w(0, 3, 0);  // stage 0 = tap (1, 0)
+    issue_w(0, 4, 1);  // stage 1 = tap (1, 1)
+    int np = 2;        // weight pieces of the next stage that may still be in flight
+    u32x4_t da[4] = {}, dq[2] = {};
+
+    auto stage = [&](auto Kc, int c) {
+        constexpr int K = decltype(Kc)::value;
+        constexpr int KH = K < 3 ? 1 : (K < 6 ? 0 : 2), KW = K % 3, WS = K % 3;
+        constexpr int K2 = (K + 2) % 9, KH2 = K2 < 3 ? 1 : (K2 < 6 ? 0 : 2), T2 = KH2 * 3 + K2 % 3;  // the tap two stages on
+        constexpr int RP = KH & 1, CQ = KW & 1, PITCH = CQ ? 16 : 17;
+        constexpr int IMM = (RP ? (CQ ? S2_NP01 : S2_NP00) * 128 : 0) + (KH >> 1) * PITCH * 128;  // plane within the region + the tap's row shift
+        const int s = c * 9 + K;
+        const bool pnext = c + 1 < nchunk;
+        // younger than this stage's weights: the previous stage's weight pieces (np) and, behind stage 0's / stage 3's, five patch pieces
+        wait_vm_s2(np + ((K == 1 || K == 2 || ((K == 4 || K == 5) && pnext)) ? 5 : 0));
+        __builtin_amdgcn_s_barrier();
+        np = 0;
+        u32x4_t a0[4], b0[2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a0[m] = *(const u32x4_t*)(smem + offA0 + WS * WBYTES + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b0[n] = *(const u32x4_t*)(smem + preB0[KW] + IMM + n * (PITCH * 128));
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], dq[n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < NS) {
+            issue_w(K + 2 >= 9 ? c + 1 : c, T2, (K + 2) % 3);
+            np = 2;
+        }
+        if (K == 0) issue_rows(IC<0>{}, c);               // even patch rows of THIS chunk (kh = 0, 2): last read in stage 8 of the previous one, first in stage 3
+        if (K == 3 && pnext) issue_rows(IC<1>{}, c + 1);  // odd patch rows of the next chunk (kh = 1): last read in stage 2, first in its stage 0
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) da[m] = *(const u32x4_t*)(smem + (offA0 ^ 64u) + WS * WBYTES + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) dq[n] = *(const u32x4_t*)(smem + (preB0[KW] ^ 64u) + IMM + n * (PITCH * 128));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) Mma<T>::run(a0[m], b0[n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // deferred fragments are in registers before their slot / plane may be refilled
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        stage(IC<0>{}, c); stage(IC<1>{}, c); stage(IC<2>{}, c); stage(IC<3>{}, c); stage(IC<4>{}, c);
+        stage(IC<5>{}, c); stage(IC<6>{}, c); stage(IC<7>{}, c); stage(IC<8>{}, c);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) Mma<T>::run(da[m], dq[n], acc[m][n]);
+
+    float bv[4][4];
+    epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
+    constexpr int OS = 128 * ESZ + 16;
+    EpiStore<T, 128, H8_NTHR> est;
+    est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    __syncthreads();
+    char* const O = smem;
+    epi_acc_to_lds_n<T, 2>(O, OS, acc, bv, p.act, wm * 64, wn * 32, li, lg);
+    __syncthreads();
+    est.finish(p, O, OS, tid);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Input gradient of the stride-2 convolutions (C2W_CONV_TS2) on the halo patch.  Output pixel (2i + py, 2j + px) of parity class
 // (py, px) receives   sum over kh in K(py), kw in K(px) of  w[.][kh*3 + kw][.] . dy[i + a(kh)][j + a(kw)],   K(0) = {1}, K(1) = {0, 2},
 // a(0) = 1, a(1) = a(2) = 0  (conv_geom.h::src_pixel, TS2) -- a stride-1 convolution over dy with 1 / 2 / 2 / 4 taps whose result
@@ -1149,6 +1345,42 @@ int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long lon
     if (best < 2) return 1;
     if (ws_bytes != nullptr) *ws_bytes = (unsigned long long)best * tiles * 128 * 128 * sizeof(float);
     return best;
+}
+
+// forward of the stride-2 convs on the parity planes of the halo patch (conv_patch_s2_kernel; 16-bit, output at least one 8x16 tile wide)
+// Where it is taken: one workgroup per CU (121 KB of LDS) means nothing covers a workgroup's prologue and epilogue, and at Cin = 128 a
+// workgroup is only 18 stages long -- measured per launch against the gather kernel (profiles/r06x_ab_s2_forward.txt): 256 -> 384 @32^2 -> 16^2
+// 88 -> 64 us at B = 128 and 34 -> 22 us at B = 37; 128 -> 256 @64^2 -> 32^2 113 -> 112 / 50 -> 40 us; 128 -> 128 @128^2 -> 64^2 244 -> 251 us at
+// B = 128 (8192 workgroups: slower) but 79 -> 73 us at B = 37 (2368).  So: from four K chunks on, or up to 4096 workgroups
+// (C2W_CONV_S2_PATCH=0: never; =2: wherever the geometry allows).
+bool c2w_conv_s2_patch_eligible(const C2wConvArgs& a, int dtype) {
+    const int knob = c2w_knobs().conv_s2_patch;
+    const long long nwg = (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
+    const bool pays = knob == 2 || a.Cin >= 256 || nwg <= 4096;
+    return knob != 0 && pays && dtype != C2W_DTYPE_F32 && a.mode == C2W_CONV_S2 && a.Hin == 2 * a.Hout && a.Win == 2 * a.Wout && (a.Hout & 7) == 0 &&
+           (a.Wout & 15) == 0 && a.Cin % 64 == 0 && a.ln_x == nullptr && a.lnf_y == nullptr && a.y2 == nullptr && a.loss_sum == nullptr && a.splitk <= 1 &&
+           (a.act == C2W_ACT_NONE || a.act == C2W_ACT_SILU || a.act == C2W_ACT_RELU) && (a.flags & (C2W_CONV_POOL2 | C2W_CONV_NO_Y | C2W_CONV_WPACKED)) == 0 &&
+           (long long)a.Hin * a.Win * a.Cin * 2 < (1ll << 32) && (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
+}
+
+namespace {
+template <typename T>
+int launch_s2(const C2wConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_s2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr = true;
+    }
+    const int nwg = a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
+    conv_patch_s2_kernel<T><<<nwg, H8_NTHR, S2_LDS, st>>>(a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+int c2w_conv_patch_s2(const C2wConvArgs& a, int dtype, hipStream_t st) {
+    if (dtype == C2W_DTYPE_BF16) return launch_s2<bf16_t>(a, st);
+    if (dtype == C2W_DTYPE_F16) return launch_s2<f16_t>(a, st);
+    return C2W_ERR_BAD_ARG;
 }
 
 // input gradient of the stride-2 convs per output-parity class on the halo patch (conv_patch_ts2_kernel)

@@ -2,7 +2,7 @@
 # Round 6: every GPU call of the round as one stage of this script (one gpurun call each; output under gpurun_out/r06<stage>/, the files kept
 # for the record are copies under profiles/ -- profiles/README.md and profiles/r06_experiments.md say which).  The closing evidence of the
 # round (suite in both stream modes, step table, PMC passes, module-API legs, full bench line) is tools/run_prof_r06.sh.
-#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z h8x h8y v t3p
+#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z h8x h8y v t3p s2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 
 stage_a() {
@@ -435,6 +435,34 @@ done
 echo "== B=37 (one member at L = 49)" >> $O/ab_t3_place.txt
 ACT=1 B=37 SHAPES=0,1 ROUNDS=7 timeout 900 python tools/ab_conv.py $L >> $O/ab_t3_place.txt 2>&1
 grep -v amdgpu.ids $O/ab_t3_place.txt | tail -60
+}
+
+stage_s2() {
+# stride-2 forward on the parity planes of the halo patch: its tests + the conv parity suites, per-launch A/B against the gather kernel
+# (C2W_CONV_S2_PATCH=0) on the four down-convs at B = 128 and B = 37, then the step and one member at L = 49 / 121
+O=gpurun_out/r06s2
+mkdir -p $O
+timeout 1200 python -m pytest tests/test_gpu_bench_dispatch.py tests/test_gpu_kernels.py -m gpu -q -x -p no:cacheprovider -k "stride2 or S2 or down or conv" > $O/gpu_tests_conv.txt 2>&1
+tail -3 $O/gpu_tests_conv.txt | cut -c1-300
+for b in 128 37; do
+  for knob in 1 0; do
+    echo "== B=$b C2W_CONV_S2_PATCH=$knob" >> $O/ab_s2_launches.txt
+    C2W_CONV_S2_PATCH=$knob B=$b SHAPES=8,9,10,11 ROUNDS=7 timeout 600 python tools/ab_conv.py climate2weather_amd/libc2w_hip.so 2>&1 | grep -v amdgpu.ids >> $O/ab_s2_launches.txt
+  done
+done
+cat $O/ab_s2_launches.txt
+J='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["step_ms"]["median"], d["final_loss"])'
+for bs in 128 64; do
+  B="python3 bench.py --steps 20 --warmup 5 --batch $bs --no-cpu-baseline --no-extras"
+  for rep in 1 2 3; do
+    echo "B=$bs parity planes rep $rep: $(timeout 300 $B 2>/dev/null | python3 -c "$J")"
+    echo "B=$bs gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 $B 2>/dev/null | python3 -c "$J")"
+  done
+done | tee $O/ab_step.txt
+for rep in 1 2 3; do
+  echo "parity planes rep $rep: $(timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+  echo "gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+done | tee $O/ab_sampler.txt
 }
 
 stage_z() {
