@@ -1351,12 +1351,12 @@ int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long lon
 // Where it is taken: one workgroup per CU (121 KB of LDS) means nothing covers a workgroup's prologue and epilogue, and at Cin = 128 a
 // workgroup is only 18 stages long -- measured per launch against the gather kernel (profiles/r06x_ab_s2_forward.txt): 256 -> 384 @32^2 -> 16^2
 // 88 -> 64 us at B = 128 and 34 -> 22 us at B = 37; 128 -> 256 @64^2 -> 32^2 113 -> 112 / 50 -> 40 us; 128 -> 128 @128^2 -> 64^2 244 -> 251 us at
-// B = 128 (8192 workgroups: slower) but 79 -> 73 us at B = 37 (2368).  So: from four K chunks on, or up to 4096 workgroups
+// B = 128 (4096 workgroups: slower) but 79 -> 73 us at B = 37 (1184).  So: from four K chunks on, or up to 2048 workgroups
 // (C2W_CONV_S2_PATCH=0: never; =2: wherever the geometry allows).
 bool c2w_conv_s2_patch_eligible(const C2wConvArgs& a, int dtype) {
     const int knob = c2w_knobs().conv_s2_patch;
     const long long nwg = (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
-    const bool pays = knob == 2 || a.Cin >= 256 || nwg <= 4096;
+    const bool pays = knob == 2 || a.Cin >= 256 || nwg <= 2048;
     return knob != 0 && pays && dtype != C2W_DTYPE_F32 && a.mode == C2W_CONV_S2 && a.Hin == 2 * a.Hout && a.Win == 2 * a.Wout && (a.Hout & 7) == 0 &&
            (a.Wout & 15) == 0 && a.Cin % 64 == 0 && a.ln_x == nullptr && a.lnf_y == nullptr && a.y2 == nullptr && a.loss_sum == nullptr && a.splitk <= 1 &&
            (a.act == C2W_ACT_NONE || a.act == C2W_ACT_SILU || a.act == C2W_ACT_RELU) && (a.flags & (C2W_CONV_POOL2 | C2W_CONV_NO_Y | C2W_CONV_WPACKED)) == 0 &&

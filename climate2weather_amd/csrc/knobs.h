@@ -8,7 +8,7 @@ struct C2wKnobs {
     int conv_t3;          // C2W_CONV_T3          -1 (default): 16x16-tile conv kernel from conv_t3_min_wgs workgroups; 0: never; 16: wherever the image is tiled
     bool conv_pair;       // C2W_CONV_PAIR=0      8-pixel-wide images NOT paired on the halo-patch kernels (gather kernels instead)
     bool conv_ts2_patch;  // C2W_CONV_TS2_PATCH=0 stride-2 input gradient NOT on the parity-class halo-patch kernel
-    int conv_s2_patch;    // C2W_CONV_S2_PATCH    1 (default): stride-2 FORWARD on the parity-plane halo-patch kernel where it pays (>= 4 K chunks or <= 4096 workgroups); 0: never (gather kernel, rounds 1-5); 2: wherever the geometry allows
+    int conv_s2_patch;    // C2W_CONV_S2_PATCH    1 (default): stride-2 FORWARD on the parity-plane halo-patch kernel where it pays (>= 4 K chunks or <= 2048 workgroups); 0: never (gather kernel, rounds 1-5); 2: wherever the geometry allows
     bool ts2_one_launch;  // C2W_TS2_FOUR_LAUNCHES=1 stride-2 input gradient as one launch per parity class instead of one launch for the four
     bool ts2_pairs;       // C2W_TS2_PAIRS=0      stride-2 input gradient with one class per workgroup (round 4) instead of two (round 6; 16-bit)
     bool up_patch;        // C2W_NO_UP_PATCH=1    up-convs NOT on the halo-patch kernels (upsampling folded into the gather kernel instead)

@@ -169,9 +169,9 @@ def test_conv_kernels_at_the_bench_dispatch(case, dt):
 
 
 def test_stride2_forward_dispatch_rule(monkeypatch):
-    """The parity-plane kernel is taken from four K chunks on or up to 4096 workgroups (one workgroup per CU: short chains in big launches
+    """The parity-plane kernel is taken from four K chunks on or up to 2048 workgroups (one workgroup per CU: short chains in big launches
     lose to the gather kernel, profiles/r06x_ab_s2_forward.txt); C2W_CONV_S2_PATCH=2 takes it wherever the geometry allows, =0 never."""
-    big = geom(128, 128, 128, 128, 64, 64, 128, 128, 128, S2)    # 8192 workgroups, two K chunks
+    big = geom(128, 128, 128, 128, 64, 64, 128, 128, 128, S2)    # 4096 workgroups, two K chunks
     deep = geom(128, 32, 32, 256, 16, 16, 384, 384, 256, S2)     # four K chunks
     mid = geom(128, 64, 64, 128, 32, 32, 256, 256, 128, S2)      # 2048 workgroups
     narrow = geom(128, 16, 16, 384, 8, 8, 512, 512, 384, S2)     # 8-pixel-wide output: never
