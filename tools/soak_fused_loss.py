@@ -25,7 +25,8 @@ if len(sys.argv) > 1:
     print(" ".join(out), "| steps taken", tr.optimizer_steps_taken(), "finite", bool(torch.isfinite(tr.eng.flat).all()), flush=True)
     sys.exit(0)
 for prec in ("bf16", "fp16"):
-    for tag, env in (("fused loss tail (default)", {}), ("C2W_NO_LOSS_FUSION=1", {"C2W_NO_LOSS_FUSION": "1"}), ("C2W_LN_CHAIN=1", {"C2W_LN_CHAIN": "1"})):
+    for tag, env in (("fused loss tail (default)", {}), ("C2W_NO_LOSS_FUSION=1", {"C2W_NO_LOSS_FUSION": "1"}), ("C2W_LN_CHAIN=1", {"C2W_LN_CHAIN": "1"}),
+                     ("C2W_CONV_S2_PATCH=0 C2W_NO_HALF8=1 C2W_TS2_PAIRS=0 (round 5's kernel selection)", {"C2W_CONV_S2_PATCH": "0", "C2W_NO_HALF8": "1", "C2W_TS2_PAIRS": "0"})):
         r = subprocess.run([sys.executable, __file__, prec], env=dict(os.environ, **env), capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if "steps taken" in l]
         print(f"{prec:5s} {tag:28s}: mean loss per 25 steps {line[-1] if line else 'FAILED ' + r.stderr[-300:]}", flush=True)
