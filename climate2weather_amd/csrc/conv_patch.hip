@@ -1,7 +1,8 @@
 // Halo-patch implicit GEMM for the 3x3 stride-1 convolutions (the 60 res-block convs and their input gradients:
 // 98.8 of the 116 GFLOP forward, model/nn.py:155,157) on gfx950 -- the 8x16-pixel-tile kernels: fp32 mode, 16-bit launches below
-// 1024 workgroups of the 16x16-tile kernel (conv_patch3.hip), 8-pixel-wide images (two per tile) and the stride-2 input gradient
-// per output-parity class.
+// 512 workgroups of the 16x16-tile kernel (conv_patch3.hip; C2W_CONV_T3_MIN_WGS), 8-pixel-wide images (two per tile), the stride-2 input
+// gradient per output-parity class (conv_patch_ts2_*) and the stride-2 forward on the parity planes of its patch (conv_patch_s2_kernel).
+// Four-wave form conv_patch_half_kernel (rounds 1-5; fp32 above 256 workgroups), eight-wave form conv_patch_half8_kernel (round 6).
 //
 // Why a halo patch: PMC on the gather kernel (profiles/r01_pmc_conv_gather_b32.md) shows ~290 non-MFMA instructions per 32 MFMAs
 // per wave -- per-tap gather address arithmetic and scalar loop overhead -- so the wave's in-order issue stream, not the matrix
