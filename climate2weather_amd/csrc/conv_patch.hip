@@ -487,8 +487,8 @@ __global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// FORWARD of the stride-2 convolutions (C2W_CONV_S2: the three down-convs whose output is at least 16 pixels wide, model/nn.py:169-174) on
-// the halo patch (round 6; 16-bit).  Output pixel (n, j) of an 8x16 output tile reads, for tap (kh, kw), input pixel (2n + kh, 2j + kw) of
+// FORWARD of the stride-2 convolutions (C2W_CONV_S2: the four down-convs, model/nn.py:169-174) on the halo patch (round 6; 16-bit; outputs
+// 16 pixels wide or more, or exactly 8: S2Plan<PAIR>).  Output pixel (n, j) of an 8x16 output tile reads, for tap (kh, kw), input pixel (2n + kh, 2j + kw) of
 // the (17 x 33)-pixel patch whose origin is (2 oh0 - 1, 2 ow0 - 1).  The patch is staged as its four PARITY PLANES -- plane (p, q) holds
 // patch pixels (2a + p, 2b + q) -- so that tap (kh, kw) is a stride-1 view of plane (kh & 1, kw & 1) shifted by (kh >> 1, kw >> 1): every
 // fragment address is register + immediate as in the stride-1 kernels, and the LDS-DMA does the de-interleaving (a piece = 8 consecutive
@@ -501,13 +501,22 @@ __global__ __launch_bounds__(H8_NTHR, DB ? 1 : 2) void conv_patch_half8_kernel(c
 // and the odd rows of chunk c + 1 during stages 3-5 (issued behind stage 3's weights, needed six stages later): five pieces per wave each
 // time, allowed in flight by counted vmcnt(7) at the two following stages -- no exposed patch load after the prologue.
 // Replaces the gather kernel (0.15-0.26 of peak on these launches: ~290 non-MFMA instructions per 32 MFMAs, each input pixel fetched 2.25
-// times).  The 16 -> 8 down-conv (8-pixel-wide output) and fp32 stay there.
-constexpr int S2_NP00 = 160, S2_NP10 = 136, S2_NP01 = 144, S2_NP11 = 128;  // plane pixels, padded to whole 8-pixel pieces (9x17, 8x17, 9x16, 8x16)
-constexpr int S2_B00 = 0, S2_B10 = S2_NP00 * 128;                           // column parity 0: [even rows | odd rows]
-constexpr int S2_B01 = (S2_NP00 + S2_NP10) * 128, S2_B11 = S2_B01 + S2_NP01 * 128;  // column parity 1
-constexpr int S2_PBYTES = S2_B11 + S2_NP11 * 128;                           // 72,704
-constexpr int S2_LDS = S2_PBYTES + 3 * WBYTES;                              // 121,856
-static_assert(128 * (128 * 2 + 16) + 512 <= S2_LDS, "output staging fits");
+// times).  fp32 stays there.
+// PAIR: 8-pixel-wide OUTPUT (the 16x16 -> 8x8 down-conv): the tile is two images side by side as in conv_patch_half_kernel<T, PAIR>; every plane
+// holds the two images' columns one after the other (9 + 9 / 8 + 8 per row), each image with its own zero border.
+template <bool PAIR>
+struct S2Plan {
+    static constexpr int W0 = 9, W1 = 8;                                   // plane columns of ONE 8-wide image, column parity 0 / 1
+    static constexpr int PITCH0 = PAIR ? 2 * W0 : 17, PITCH1 = 16;          // plane row pitch in pixels
+    // plane pixels, padded to whole 8-pixel pieces: 9 / 8 rows x pitch
+    static constexpr int NP00 = (9 * PITCH0 + 7) / 8 * 8, NP10 = 8 * PITCH0, NP01 = 9 * PITCH1, NP11 = 8 * PITCH1;  // 160 136 144 128 | 168 144 144 128
+    static constexpr int B00 = 0, B10 = NP00 * 128;                        // column parity 0: [even rows | odd rows]
+    static constexpr int B01 = (NP00 + NP10) * 128, B11 = B01 + NP01 * 128;  // column parity 1
+    static constexpr int PBYTES = B11 + NP11 * 128;                        // 72,704 | 74,752
+    static constexpr int LDS = PBYTES + 3 * WBYTES;                        // 121,856 | 123,904
+    static_assert((NP00 + NP01) / 8 <= 40 && (NP10 + NP11) / 8 <= 40, "five rounds of eight waves cover a row parity's pieces");
+    static_assert(128 * (128 * 2 + 16) + 512 <= LDS, "output staging fits");
+};
 
 __device__ __forceinline__ void wait_vm_s2(int n) {  // wave-uniform n in {0, 2, 5, 7}
     if (n == 7) {
@@ -521,11 +530,12 @@ __device__ __forceinline__ void wait_vm_s2(int n) {  // wave-uniform n in {0, 2,
     }
 }
 
-template <typename T>
+template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConvArgs p) {
     constexpr int ESZ = sizeof(T);
     static_assert(ESZ == 2, "16-bit operands");
     constexpr int CK = 64;
+    using PL = S2Plan<PAIR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [plane 00 | 10 | 01 | 11 | W0 | W1 | W2]
 
     const int tid = threadIdx.x;
@@ -543,13 +553,14 @@ __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConv
     const int tn = L % nN, tm = L / nN;
     const int co0 = tn * 128;
     const int H = p.Hout, W = p.Wout, Hi = p.Hin, Wi = p.Win;
-    const int tw = W >> 4, tpi = (H >> 3) * tw;
-    const int b = tm / tpi, tt = tm - b * tpi;
+    const int tw = PAIR ? 1 : W >> 4, tpi = (H >> 3) * tw;
+    const int b = PAIR ? 2 * (tm / tpi) : tm / tpi, tt = tm - (tm / tpi) * tpi;
     const int ty = tt / tw, tx = tt - ty * tw;
     const int oh0 = ty << 3, ow0 = tx << 4;
 
     const size_t img_bytes = (size_t)Hi * Wi * p.Cin * ESZ;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)img_bytes);
+    const int nimg = PAIR ? (b + 1 < p.B ? 2 : 1) : 1;  // images under the descriptor: a missing partner reads as zeros (out of range)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p.x + (size_t)b * img_bytes, (uint32_t)(img_bytes * nimg));
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (uint32_t)((size_t)p.wrows * 9 * p.Cin * ESZ));
     const int nchunk = p.Cin / CK;
     const int NS = nchunk * 9;
@@ -560,21 +571,24 @@ __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConv
     int pdst[2][5];
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
-        const int n0 = (rp ? S2_NP10 : S2_NP00) >> 3, n1 = (rp ? S2_NP11 : S2_NP01) >> 3;  // pieces of the two planes: 20 + 18 / 17 + 16
+        const int n0 = (rp ? PL::NP10 : PL::NP00) >> 3, n1 = (rp ? PL::NP11 : PL::NP01) >> 3;  // pieces of the two planes: 20 + 18 / 17 + 16 (PAIR: 21 + 18 / 18 + 16)
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
             int pc = r * 8 + wid;
             pc = pc < n0 + n1 ? pc : n0 + n1 - 1;
             const int cq = pc >= n0 ? 1 : 0;  // column parity of the piece's plane
             const int k = pc - cq * n0;
-            const int pitch = cq ? 16 : 17, rows = rp ? 8 : 9;
+            const int pitch = cq ? PL::PITCH1 : PL::PITCH0, rows = rp ? 8 : 9;
             const int i = k * 8 + (lane >> 3);
-            const int a = i / pitch, b_ = i - a * pitch;
+            const int a = i / pitch, bc = i - a * pitch;                     // plane row, plane column
+            const int wq = cq ? PL::W1 : PL::W0;
+            const int pimg = PAIR && bc >= wq ? 1 : 0;                        // PAIR: the second image's columns follow the first's
+            const int b_ = bc - pimg * wq;
             const int ih = 2 * oh0 - 1 + 2 * a + rp, iw = 2 * ow0 - 1 + 2 * b_ + cq;
             const bool ok = a < rows && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
-            const uint32_t lc = (uint32_t)((lane & 7) ^ (b_ & 7));
-            pvo[rp][r] = ok ? (uint32_t)((ih * Wi + iw) * p.Cin) * ESZ + (lc << 4) : C2W_OOB;
-            pdst[rp][r] = (rp ? (cq ? S2_B11 : S2_B10) : (cq ? S2_B01 : S2_B00)) + k * 1024;
+            const uint32_t lc = (uint32_t)((lane & 7) ^ (bc & 7));
+            pvo[rp][r] = ok ? (uint32_t)((ih * Wi + iw) * p.Cin) * ESZ + (uint32_t)pimg * (uint32_t)img_bytes + (lc << 4) : C2W_OOB;
+            pdst[rp][r] = (rp ? (cq ? PL::B11 : PL::B10) : (cq ? PL::B01 : PL::B00)) + k * 1024;
         }
     }
     uint32_t wvo[2];  // weight tile: 128 rows x 8 chunks = 2 rounds of 512 threads
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConv
     auto issue_w = [&](int chunk, int tap, int wslot) {
         const uint32_t so = (uint32_t)(tap * p.Cin + chunk * CK) * ESZ;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(rw, smem + S2_PBYTES + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
+        for (int i = 0; i < 2; ++i) glds16(rw, smem + PL::PBYTES + wslot * WBYTES + wid * 1024 + i * 8192, wvo[i], so);
     };
     auto issue_rows = [&](auto RPc, int chunk) {  // the two planes of one row parity
         constexpr int RP = decltype(RPc)::value;
@@ -596,12 +610,13 @@ __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConv
 
     // fragment addresses: A row m = + m * 2048; B: per kw the column-parity region, the lane's plane column li + (kw >> 1) and the wave's
     // first output row; row parity, row and the second output row are immediates; second K half = ^ 64
-    const uint32_t offA0 = (uint32_t)(S2_PBYTES + (wm * 64 + li) * 128 + ((lg ^ (li & 7)) << 4));
+    const uint32_t offA0 = (uint32_t)(PL::PBYTES + (wm * 64 + li) * 128 + ((lg ^ (li & 7)) << 4));
     uint32_t preB0[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int cq = kw & 1, b_ = li + (kw >> 1), pitch = cq ? 16 : 17;
-        preB0[kw] = (uint32_t)((cq ? S2_B01 : S2_B00) + (wn * 2 * pitch + b_) * 128 + ((lg ^ (b_ & 7)) << 4));
+        const int cq = kw & 1, pitch = cq ? PL::PITCH1 : PL::PITCH0;
+        const int b_ = PAIR ? (li >> 3) * (cq ? PL::W1 : PL::W0) + (li & 7) + (kw >> 1) : li + (kw >> 1);  // PAIR: tile column >= 8 = the second image's columns
+        preB0[kw] = (uint32_t)((cq ? PL::B01 : PL::B00) + (wn * 2 * pitch + b_) * 128 + ((lg ^ (b_ & 7)) << 4));
     }
 
     f32x4_t acc[4][2];
@@ -620,8 +635,8 @@ __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConv
         constexpr int K = decltype(Kc)::value;
         constexpr int KH = K < 3 ? 1 : (K < 6 ? 0 : 2), KW = K % 3, WS = K % 3;
         constexpr int K2 = (K + 2) % 9, KH2 = K2 < 3 ? 1 : (K2 < 6 ? 0 : 2), T2 = KH2 * 3 + K2 % 3;  // the tap two stages on
-        constexpr int RP = KH & 1, CQ = KW & 1, PITCH = CQ ? 16 : 17;
-        constexpr int IMM = (RP ? (CQ ? S2_NP01 : S2_NP00) * 128 : 0) + (KH >> 1) * PITCH * 128;  // plane within the region + the tap's row shift
+        constexpr int RP = KH & 1, CQ = KW & 1, PITCH = CQ ? PL::PITCH1 : PL::PITCH0;
+        constexpr int IMM = (RP ? (CQ ? PL::NP01 : PL::NP00) * 128 : 0) + (KH >> 1) * PITCH * 128;  // plane within the region + the tap's row shift
         const int s = c * 9 + K;
         const bool pnext = c + 1 < nchunk;
         // younger than this stage's weights: the previous stage's weight pieces (np) and, behind stage 0's / stage 3's, five patch pieces
@@ -674,7 +689,8 @@ __global__ __launch_bounds__(H8_NTHR, 1) void conv_patch_s2_kernel(const C2wConv
     epi_load_bias(p, co0 + wm * 64 + lg * 4, bv);
     constexpr int OS = 128 * ESZ + 16;
     EpiStore<T, 128, H8_NTHR> est;
-    est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
+    if constexpr (PAIR) est.prefetch_pair8(p, tid, co0, ((long long)b * H + oh0) * W, H * W, nimg);
+    else est.prefetch_tile16(p, tid, co0, ((long long)b * H + oh0) * W + ow0, W);
     __syncthreads();
     char* const O = smem;
     epi_acc_to_lds_n<T, 2>(O, OS, acc, bv, p.act, wm * 64, wn * 32, li, lg);
@@ -1348,7 +1364,8 @@ int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long lon
     return best;
 }
 
-// forward of the stride-2 convs on the parity planes of the halo patch (conv_patch_s2_kernel; 16-bit, output at least one 8x16 tile wide)
+// forward of the stride-2 convs on the parity planes of the halo patch (conv_patch_s2_kernel; 16-bit; output tiled by 8x16 pixels, or 8 pixels
+// wide with two images per tile)
 // Where it is taken: one workgroup per CU (121 KB of LDS) means nothing covers a workgroup's prologue and epilogue, and at Cin = 128 a
 // workgroup is only 18 stages long -- measured per launch against the gather kernel (profiles/r06x_ab_s2_forward.txt): 256 -> 384 @32^2 -> 16^2
 // 88 -> 64 us at B = 128 and 34 -> 22 us at B = 37; 128 -> 256 @64^2 -> 32^2 113 -> 112 / 50 -> 40 us; 128 -> 128 @128^2 -> 64^2 244 -> 251 us at
@@ -1356,31 +1373,33 @@ int c2w_conv_splitk_plan_impl(const C2wConvArgs& a, int dtype, unsigned long lon
 // (C2W_CONV_S2_PATCH=0: never; =2: wherever the geometry allows).
 bool c2w_conv_s2_patch_eligible(const C2wConvArgs& a, int dtype) {
     const int knob = c2w_knobs().conv_s2_patch;
-    const long long nwg = (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
+    const bool pair = a.Wout == 8;  // 8-pixel-wide output: two images per tile
+    const long long nwg = (pair ? (long long)((a.B + 1) >> 1) * (a.Hout >> 3) : (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4)) * ((a.Cout + 127) / 128);
     const bool pays = knob == 2 || a.Cin >= 256 || nwg <= 2048;
     return knob != 0 && pays && dtype != C2W_DTYPE_F32 && a.mode == C2W_CONV_S2 && a.Hin == 2 * a.Hout && a.Win == 2 * a.Wout && (a.Hout & 7) == 0 &&
-           (a.Wout & 15) == 0 && a.Cin % 64 == 0 && a.ln_x == nullptr && a.lnf_y == nullptr && a.y2 == nullptr && a.loss_sum == nullptr && a.splitk <= 1 &&
+           (pair || (a.Wout & 15) == 0) && a.Cin % 64 == 0 && a.ln_x == nullptr && a.lnf_y == nullptr && a.y2 == nullptr && a.loss_sum == nullptr && a.splitk <= 1 &&
            (a.act == C2W_ACT_NONE || a.act == C2W_ACT_SILU || a.act == C2W_ACT_RELU) && (a.flags & (C2W_CONV_POOL2 | C2W_CONV_NO_Y | C2W_CONV_WPACKED)) == 0 &&
-           (long long)a.Hin * a.Win * a.Cin * 2 < (1ll << 32) && (long long)a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128) < (1ll << 31);
+           (long long)a.Hin * a.Win * a.Cin * 4 < (1ll << 32) && nwg < (1ll << 31);
 }
 
 namespace {
-template <typename T>
+template <typename T, bool PAIR>
 int launch_s2(const C2wConvArgs& a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_s2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_patch_s2_kernel<T, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
-    const int nwg = a.B * (a.Hout >> 3) * (a.Wout >> 4) * ((a.Cout + 127) / 128);
-    conv_patch_s2_kernel<T><<<nwg, H8_NTHR, S2_LDS, st>>>(a);
+    const int nN = (a.Cout + 127) / 128;
+    const int nwg = (PAIR ? ((a.B + 1) >> 1) * (a.Hout >> 3) : a.B * (a.Hout >> 3) * (a.Wout >> 4)) * nN;
+    conv_patch_s2_kernel<T, PAIR><<<nwg, H8_NTHR, S2Plan<PAIR>::LDS, st>>>(a);
     return (int)hipGetLastError();
 }
 }  // namespace
 
 int c2w_conv_patch_s2(const C2wConvArgs& a, int dtype, hipStream_t st) {
-    if (dtype == C2W_DTYPE_BF16) return launch_s2<bf16_t>(a, st);
-    if (dtype == C2W_DTYPE_F16) return launch_s2<f16_t>(a, st);
+    if (dtype == C2W_DTYPE_BF16) return a.Wout == 8 ? launch_s2<bf16_t, true>(a, st) : launch_s2<bf16_t, false>(a, st);
+    if (dtype == C2W_DTYPE_F16) return a.Wout == 8 ? launch_s2<f16_t, true>(a, st) : launch_s2<f16_t, false>(a, st);
     return C2W_ERR_BAD_ARG;
 }
 

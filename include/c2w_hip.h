@@ -160,8 +160,8 @@ int c2w_conv_splitk_plan(const C2wConvArgs* args, int dtype, unsigned long long*
  * the dtype and the fusion fields; the parity tests assert with it that a case reaches the kernel it is meant to cover.
  * GATHER: conv_igemm / wgrad gather kernels; PATCH_8X16: conv_patch_half_kernel / wgrad_patch_kernel; PATCH_16X16:
  * conv_patch_t3_kernel<16> (16-bit launches of >= 512 workgroups of that tile, C2W_CONV_T3_MIN_WGS); PATCH_PAIR: 8-pixel-wide images, two per tile; PATCH_TS2: the
- * stride-2 input gradient per output-parity class; PATCH_S2: the stride-2 FORWARD on the parity planes of the halo patch (16-bit, output at
- * least 16 pixels wide; from four K chunks on or up to 2048 workgroups). */
+ * stride-2 input gradient per output-parity class; PATCH_S2: the stride-2 FORWARD on the parity planes of the halo patch (16-bit; output
+ * tiled by 8x16 pixels, or 8 pixels wide with two images per tile; from four K chunks on or up to 2048 workgroups). */
 enum { C2W_KERNEL_GATHER = 0, C2W_KERNEL_PATCH_8X16 = 1, C2W_KERNEL_PATCH_16X16 = 2, C2W_KERNEL_PATCH_PAIR = 3, C2W_KERNEL_PATCH_TS2 = 4, C2W_KERNEL_PATCH_S2 = 5 };
 int c2w_conv_dispatch(const C2wConvArgs* args, int dtype);
 int c2w_conv_wgrad_dispatch(const C2wConvArgs* args, int dtype);

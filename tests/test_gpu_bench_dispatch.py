@@ -82,12 +82,12 @@ FWD_CASES = [
     ("network output's input gradient 65(128)->128 @128^2", T3, S1, 16, 128, 128, 128, 128, 65, ["plain"]),
     ("K of 3 chunks, the last one half void: 160(192)->128 @64^2", T3, S1, 64, 64, 192, 128, 128, 160, ["bias+res"]),
     ("K promise that leaves whole chunks out: 40(192)->128 @64^2", T3, S1, 64, 64, 192, 128, 128, 40, ["bias"]),
-    # stride-2 family (model/nn.py:169-174): forward on the parity planes of the halo patch (round 6; the 8-pixel-wide output on the gather
-    # kernel), input gradient per output-parity class (+ skip gradient)
+    # stride-2 family (model/nn.py:169-174): forward on the parity planes of the halo patch (round 6; the 8-pixel-wide output with two images
+    # per tile), input gradient per output-parity class (+ skip gradient)
     ("down 128->128 128^2->64^2", S2P, S2, 16, 128, 128, 128, 128, 128, ["bias"]),
     ("down 128->256 64^2->32^2 (two output-channel tiles)", S2P, S2, 128, 64, 128, 256, 256, 128, ["bias", "bias+silu", "bias+res"]),
     ("down 256->384 32^2->16^2", S2P, S2, 128, 32, 256, 384, 384, 256, ["bias", "plain"]),
-    ("down 384->512 16^2->8^2 (8-pixel-wide output)", GATHER, S2, 128, 16, 384, 512, 512, 384, ["bias"]),
+    ("down 384->512 16^2->8^2 (8-pixel-wide output: two images per tile)", S2P, S2, 128, 16, 384, 512, 512, 384, ["bias", "bias+silu"]),
     ("down dgrad 128->128 64^2->128^2", TS2P, TS2, 16, 64, 128, 128, 128, 128, ["res"]),
     ("down dgrad 384->256 16^2->32^2", TS2P, TS2, 128, 16, 384, 256, 256, 384, ["res"]),
     ("down dgrad 512->384 8^2->16^2", GATHER, TS2, 128, 8, 512, 384, 384, 512, ["res"]),
@@ -174,13 +174,14 @@ def test_stride2_forward_dispatch_rule(monkeypatch):
     big = geom(128, 128, 128, 128, 64, 64, 128, 128, 128, S2)    # 4096 workgroups, two K chunks
     deep = geom(128, 32, 32, 256, 16, 16, 384, 384, 256, S2)     # four K chunks
     mid = geom(128, 64, 64, 128, 32, 32, 256, 256, 128, S2)      # 2048 workgroups
-    narrow = geom(128, 16, 16, 384, 8, 8, 512, 512, 384, S2)     # 8-pixel-wide output: never
-    assert [ops.conv_dispatch(g, BF16) for g in (big, deep, mid, narrow)] == [GATHER, S2P, S2P, GATHER]
+    narrow = geom(128, 16, 16, 384, 8, 8, 512, 512, 384, S2)     # 8-pixel-wide output: two images per tile, six K chunks
+    odd = geom(128, 24, 24, 128, 12, 12, 128, 128, 128, S2)      # 12-pixel-wide output: no tiling covers it
+    assert [ops.conv_dispatch(g, BF16) for g in (big, deep, mid, narrow, odd)] == [GATHER, S2P, S2P, S2P, GATHER]
     assert ops.conv_dispatch(deep, F32) == GATHER
     monkeypatch.setenv("C2W_CONV_S2_PATCH", "2")
     ops.knobs_reload()
     try:
-        assert [ops.conv_dispatch(g, F16) for g in (big, deep, mid, narrow)] == [S2P, S2P, S2P, GATHER]
+        assert [ops.conv_dispatch(g, F16) for g in (big, deep, mid, narrow, odd)] == [S2P, S2P, S2P, S2P, GATHER]
     finally:
         monkeypatch.delenv("C2W_CONV_S2_PATCH")
         ops.knobs_reload()
@@ -190,13 +191,15 @@ def test_stride2_forward_dispatch_rule(monkeypatch):
 @pytest.mark.parametrize("case", [("one tile, one K chunk, one image", 1, 16, 32, 64, 128),
                                   ("non-square 32x64 -> 16x32 (four tiles), three K chunks, three images", 3, 32, 64, 192, 128),
                                   ("192 output channels (the second channel tile half empty), two K chunks", 2, 32, 32, 128, 192),
-                                  ("48 x 96 -> 24 x 48: tile rows and columns in the image's interior and at all four edges", 2, 48, 96, 64, 128)],
-                         ids=["tile", "nonsquare", "cout192", "edges"])
+                                  ("48 x 96 -> 24 x 48: tile rows and columns in the image's interior and at all four edges", 2, 48, 96, 64, 128),
+                                  ("8-pixel-wide output, THREE images (the last tile's partner is missing), two K chunks", 3, 16, 16, 128, 128),
+                                  ("8-pixel-wide output of 16 rows (two tiles per image pair), four images, 192 output channels", 4, 32, 16, 64, 192)],
+                         ids=["tile", "nonsquare", "cout192", "edges", "pair-odd", "pair-tall"])
 def test_stride2_forward_on_parity_planes_against_the_gather_kernel(case, dt, monkeypatch):
     """Round 6, conv_patch_s2_kernel (model/nn.py:169-174 forward): the parity-plane halo kernel against the PyTorch restatement AND
     against the gather kernel it replaces (C2W_CONV_S2_PATCH=0) on shapes that exercise what the bench's launches do not: a single tile
     (every patch edge is padding), non-square images, a partial output-channel tile, several K chunks (the two row parities refilled in
-    turn), bias / activation / residual epilogues."""
+    turn), 8-pixel-wide outputs (two images per tile; an odd batch), bias / activation / residual epilogues."""
     name, B, Hin, Win, Cin, Cout = case
     Hout, Wout = Hin // 2, Win // 2
     g = geom(B, Hin, Win, Cin, Hout, Wout, Cout, Cout, Cout, S2)

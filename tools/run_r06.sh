@@ -2,7 +2,7 @@
 # Round 6: every GPU call of the round as one stage of this script (one gpurun call each; output under gpurun_out/r06<stage>/, the files kept
 # for the record are copies under profiles/ -- profiles/README.md and profiles/r06_experiments.md say which).  The closing evidence of the
 # round (suite in both stream modes, step table, PMC passes, module-API legs, full bench line) is tools/run_prof_r06.sh.
-#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z h8x h8y v t3p s2
+#   usage: bash tools/run_r06.sh <stage>     stages: a b c d e g h i m n o r t flake z h8x h8y v t3p s2 s2p
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 
 stage_a() {
@@ -459,6 +459,26 @@ for bs in 128 64; do
     echo "B=$bs gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 $B 2>/dev/null | python3 -c "$J")"
   done
 done | tee $O/ab_step.txt
+for rep in 1 2 3; do
+  echo "parity planes rep $rep: $(timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+  echo "gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+done | tee $O/ab_sampler.txt
+}
+
+stage_s2p() {
+# the stride-2 forward kernel's two-images-per-tile form (8-pixel-wide output: the 16x16 -> 8x8 down-conv): tests, per-launch A/B against the
+# gather kernel at B = 128 / 37, one member at L = 49 / 121
+O=gpurun_out/r06s2p
+mkdir -p $O
+timeout 1200 python -m pytest tests/test_gpu_bench_dispatch.py tests/test_gpu_kernels.py tests/test_gpu_e2e.py -m gpu -q -x -p no:cacheprovider -k "stride2 or down or conv or full_size or bench_size" > $O/gpu_tests_conv.txt 2>&1
+tail -3 $O/gpu_tests_conv.txt | cut -c1-300
+for b in 128 37; do
+  for knob in 1 0; do
+    echo "== B=$b C2W_CONV_S2_PATCH=$knob" >> $O/ab_s2_pair.txt
+    C2W_CONV_S2_PATCH=$knob B=$b SHAPES=11 ROUNDS=9 timeout 600 python tools/ab_conv.py climate2weather_amd/libc2w_hip.so 2>&1 | grep -v amdgpu.ids >> $O/ab_s2_pair.txt
+  done
+done
+cat $O/ab_s2_pair.txt
 for rep in 1 2 3; do
   echo "parity planes rep $rep: $(timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
   echo "gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
