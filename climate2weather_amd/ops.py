@@ -102,7 +102,7 @@ KNOBS_GENERATION = 0  # bumped by knobs_reload(): callers that memoise dispatch 
 def knobs_reload() -> None:
     """Re-read the library's run-time knobs (C2W_* dispatch overrides) from the environment: it reads them once, at load."""
     global KNOBS_GENERATION
-    _lib.load().c2w_knobs_reload()
+    _lib.load().c2w_knobs_reload()  # (load() re-applies the host's knob defaults: a test that deleted a variable gets the HOST default back)
     KNOBS_GENERATION += 1
 
 

@@ -82,12 +82,10 @@ FWD_CASES = [
     ("network output's input gradient 65(128)->128 @128^2", T3, S1, 16, 128, 128, 128, 128, 65, ["plain"]),
     ("K of 3 chunks, the last one half void: 160(192)->128 @64^2", T3, S1, 64, 64, 192, 128, 128, 160, ["bias+res"]),
     ("K promise that leaves whole chunks out: 40(192)->128 @64^2", T3, S1, 64, 64, 192, 128, 128, 40, ["bias"]),
-    # stride-2 family (model/nn.py:169-174): forward on the parity planes of the halo patch (round 6; the 8-pixel-wide output with two images
-    # per tile), input gradient per output-parity class (+ skip gradient)
-    ("down 128->128 128^2->64^2", S2P, S2, 16, 128, 128, 128, 128, 128, ["bias"]),
-    ("down 128->256 64^2->32^2 (two output-channel tiles)", S2P, S2, 128, 64, 128, 256, 256, 128, ["bias", "bias+silu", "bias+res"]),
-    ("down 256->384 32^2->16^2", S2P, S2, 128, 32, 256, 384, 384, 256, ["bias", "plain"]),
-    ("down 384->512 16^2->8^2 (8-pixel-wide output: two images per tile)", S2P, S2, 128, 16, 384, 512, 512, 384, ["bias", "bias+silu"]),
+    # stride-2 family (model/nn.py:169-174): forward on the gather kernel (the parity-plane halo kernel of round 6 is opt-in:
+    # S2_FWD_CASES below), input gradient per output-parity class (+ skip gradient)
+    ("down 128->128 128^2->64^2", GATHER, S2, 16, 128, 128, 128, 128, 128, ["bias"]),
+    ("down 256->384 32^2->16^2", GATHER, S2, 128, 32, 256, 384, 384, 256, ["bias"]),
     ("down dgrad 128->128 64^2->128^2", TS2P, TS2, 16, 64, 128, 128, 128, 128, ["res"]),
     ("down dgrad 384->256 16^2->32^2", TS2P, TS2, 128, 16, 384, 256, 256, 384, ["res"]),
     ("down dgrad 512->384 8^2->16^2", GATHER, TS2, 128, 8, 512, 384, 384, 512, ["res"]),
@@ -168,23 +166,52 @@ def test_conv_kernels_at_the_bench_dispatch(case, dt):
         _run_conv_case(case, dt, ep)
 
 
+# the four down-convs at the bench's batch on the parity-plane halo kernel (C2W_CONV_S2_PATCH=1: opt-in, see _lib.HOST_KNOB_DEFAULTS)
+S2_FWD_CASES = [
+    ("down 128->128 128^2->64^2", S2P, S2, 16, 128, 128, 128, 128, 128, ["bias"]),
+    ("down 128->256 64^2->32^2 (two output-channel tiles)", S2P, S2, 128, 64, 128, 256, 256, 128, ["bias", "bias+silu", "bias+res"]),
+    ("down 256->384 32^2->16^2", S2P, S2, 128, 32, 256, 384, 384, 256, ["bias", "plain"]),
+    ("down 384->512 16^2->8^2 (8-pixel-wide output: two images per tile)", S2P, S2, 128, 16, 384, 512, 512, 384, ["bias", "bias+silu"]),
+]
+
+
+@pytest.fixture
+def s2_patch_on(monkeypatch):
+    monkeypatch.setenv("C2W_CONV_S2_PATCH", "1")
+    ops.knobs_reload()
+    yield
+    monkeypatch.delenv("C2W_CONV_S2_PATCH")
+    ops.knobs_reload()  # back to the host default (off)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("case", S2_FWD_CASES, ids=[c[0] for c in S2_FWD_CASES])
+def test_stride2_forward_kernel_at_the_bench_dispatch(case, dt, s2_patch_on):
+    for ep in case[-1]:
+        _run_conv_case(case, dt, ep)
+
+
 def test_stride2_forward_dispatch_rule(monkeypatch):
-    """The parity-plane kernel is taken from four K chunks on or up to 2048 workgroups (one workgroup per CU: short chains in big launches
+    """Off unless C2W_CONV_S2_PATCH says otherwise (host default); with =1 the parity-plane kernel is taken from four K chunks on or up to 2048 workgroups (one workgroup per CU: short chains in big launches
     lose to the gather kernel, profiles/r06x_ab_s2_forward.txt); C2W_CONV_S2_PATCH=2 takes it wherever the geometry allows, =0 never."""
     big = geom(128, 128, 128, 128, 64, 64, 128, 128, 128, S2)    # 4096 workgroups, two K chunks
     deep = geom(128, 32, 32, 256, 16, 16, 384, 384, 256, S2)     # four K chunks
     mid = geom(128, 64, 64, 128, 32, 32, 256, 256, 128, S2)      # 2048 workgroups
     narrow = geom(128, 16, 16, 384, 8, 8, 512, 512, 384, S2)     # 8-pixel-wide output: two images per tile, six K chunks
     odd = geom(128, 24, 24, 128, 12, 12, 128, 128, 128, S2)      # 12-pixel-wide output: no tiling covers it
-    assert [ops.conv_dispatch(g, BF16) for g in (big, deep, mid, narrow, odd)] == [GATHER, S2P, S2P, S2P, GATHER]
-    assert ops.conv_dispatch(deep, F32) == GATHER
-    monkeypatch.setenv("C2W_CONV_S2_PATCH", "2")
-    ops.knobs_reload()
+    assert [ops.conv_dispatch(g, BF16) for g in (big, deep, mid, narrow, odd)] == [GATHER] * 5  # the host's default: off (_lib.HOST_KNOB_DEFAULTS)
     try:
+        monkeypatch.setenv("C2W_CONV_S2_PATCH", "1")
+        ops.knobs_reload()
+        assert [ops.conv_dispatch(g, BF16) for g in (big, deep, mid, narrow, odd)] == [GATHER, S2P, S2P, S2P, GATHER]
+        assert ops.conv_dispatch(deep, F32) == GATHER
+        monkeypatch.setenv("C2W_CONV_S2_PATCH", "2")
+        ops.knobs_reload()
         assert [ops.conv_dispatch(g, F16) for g in (big, deep, mid, narrow, odd)] == [S2P, S2P, S2P, S2P, GATHER]
     finally:
         monkeypatch.delenv("C2W_CONV_S2_PATCH")
         ops.knobs_reload()
+    assert ops.conv_dispatch(deep, BF16) == GATHER
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
@@ -195,7 +222,7 @@ def test_stride2_forward_dispatch_rule(monkeypatch):
                                   ("8-pixel-wide output, THREE images (the last tile's partner is missing), two K chunks", 3, 16, 16, 128, 128),
                                   ("8-pixel-wide output of 16 rows (two tiles per image pair), four images, 192 output channels", 4, 32, 16, 64, 192)],
                          ids=["tile", "nonsquare", "cout192", "edges", "pair-odd", "pair-tall"])
-def test_stride2_forward_on_parity_planes_against_the_gather_kernel(case, dt, monkeypatch):
+def test_stride2_forward_on_parity_planes_against_the_gather_kernel(case, dt, monkeypatch, s2_patch_on):
     """Round 6, conv_patch_s2_kernel (model/nn.py:169-174 forward): the parity-plane halo kernel against the PyTorch restatement AND
     against the gather kernel it replaces (C2W_CONV_S2_PATCH=0) on shapes that exercise what the bench's launches do not: a single tile
     (every patch edge is padding), non-square images, a partial output-channel tile, several K chunks (the two row parities refilled in
@@ -217,7 +244,7 @@ def test_stride2_forward_on_parity_planes_against_the_gather_kernel(case, dt, mo
         ops.knobs_reload()
         assert ops.conv_dispatch(g, dt) == GATHER
         ops.conv(x, w, bias, y_g, g, dt, **kw)
-        monkeypatch.delenv("C2W_CONV_S2_PATCH")
+        monkeypatch.setenv("C2W_CONV_S2_PATCH", "1")
         ops.knobs_reload()
         torch.cuda.synchronize()
         close(y, y_ref, TOL[dt], f"{name} {sorted(kw)}")

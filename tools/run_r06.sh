@@ -455,12 +455,12 @@ J='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); pri
 for bs in 128 64; do
   B="python3 bench.py --steps 20 --warmup 5 --batch $bs --no-cpu-baseline --no-extras"
   for rep in 1 2 3; do
-    echo "B=$bs parity planes rep $rep: $(timeout 300 $B 2>/dev/null | python3 -c "$J")"
+    echo "B=$bs parity planes rep $rep: $(C2W_CONV_S2_PATCH=1 timeout 300 $B 2>/dev/null | python3 -c "$J")"
     echo "B=$bs gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 $B 2>/dev/null | python3 -c "$J")"
   done
 done | tee $O/ab_step.txt
 for rep in 1 2 3; do
-  echo "parity planes rep $rep: $(timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+  echo "parity planes rep $rep: $(C2W_CONV_S2_PATCH=1 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
   echo "gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
 done | tee $O/ab_sampler.txt
 }
@@ -480,7 +480,7 @@ for b in 128 37; do
 done
 cat $O/ab_s2_pair.txt
 for rep in 1 2 3; do
-  echo "parity planes rep $rep: $(timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
+  echo "parity planes rep $rep: $(C2W_CONV_S2_PATCH=1 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
   echo "gather kernel rep $rep: $(C2W_CONV_S2_PATCH=0 timeout 300 python3 tools/bench_sampler.py --lengths 49,121 --steps 32 2>&1 | grep window-forwards | tr '\n' '|')"
 done | tee $O/ab_sampler.txt
 }
